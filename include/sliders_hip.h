@@ -1,0 +1,310 @@
+/*
+ * sliders_hip.h - C ABI of libsliders_hip.so, the MI355X (gfx950) UNet-denoise hot path for
+ * concept-slider LoRA training.
+ *
+ * What this boundary replaces in the reference (rohitgandikota/sliders):
+ *   the model call  unet(latent_model_input, timestep, encoder_hidden_states=..., added_cond_kwargs=...)
+ *   at trainscripts/textsliders/train_util.py:159-163 and :242-247 (diffusers-0.20.2
+ *   UNet2DConditionModel.forward, a third-party dependency), the per-layer LoRA patch
+ *   LoRAModule.forward at trainscripts/textsliders/lora.py:108-112, the CFG combine at
+ *   train_util.py:166-169 / 250-253, scheduler.step at train_util.py:193 / 291, the guidance loss at
+ *   trainscripts/textsliders/prompt_util.py:108-148, loss.backward()/optimizer.step() at
+ *   trainscripts/textsliders/train_lora_xl.py:345-346.
+ *
+ * Conventions
+ *   - every entry point is asynchronous on the caller-supplied hipStream_t, takes raw device pointers,
+ *     never allocates, returns 0 on success and a negative code on a bad descriptor / launch failure
+ *     (message via slh_last_error()).
+ *   - activations are bf16, "pixel-major": a (B,C,H,W) tensor of the reference is stored as the row-major
+ *     matrix [B*H*W][C] with an explicit row stride (ld, in elements).  Latents at the model boundary stay
+ *     in the reference's (B,4,H,W) layout.
+ *   - fp32 accumulation everywhere; bf16 is rounded once per op output.
+ *   - one host thread per GPU/process; no global mutable state besides the last-error string.
+ */
+#ifndef SLIDERS_HIP_H
+#define SLIDERS_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* slh_stream_t; /* hipStream_t */
+
+int slh_version(void);
+const char* slh_last_error(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * slh_gemm: C[M][N] = epilogue( A[M][K] . W[N][K]^T )   bf16 MFMA (32x32x16), fp32 accumulate.
+ * Replaces every nn.Linear / 1x1 Conv2d / 3x3 Conv2d of the diffusers UNet together
+ * with the LoRA up-projection of LoRAModule.forward (lora.py:108-112): the rank-r product
+ * lora_scale * T[M][r] . Bup[N][r]^T is added in the epilogue (T comes from slh_skinny).
+ * mode 1 gathers A on the fly from a pixel-major image (implicit-GEMM 3x3 conv, pad 1, stride 1|2,
+ * optional nearest-2x upsample read (Upsample2D) or zero-dilated read (dgrad of the stride-2 conv),
+ * optional two-source channel concat (up-block skip cat)); K index = tap*Cin + c.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct slh_gemm_desc {
+    const void* a0;          /* source 0 (bf16) */
+    const void* a1;          /* source 1 or NULL: channels [ca0, ca0+ca1) */
+    const void* w;           /* [N][K] bf16 */
+    const void* bias;        /* [N] bf16 or NULL */
+    const void* rowbias;     /* [batch][ld_rowbias] bf16 or NULL: per-sample per-channel add (time embedding) */
+    const float* lora_t;     /* [M][ld_t] fp32 or NULL */
+    const void* lora_up;     /* [N][4] bf16 */
+    const float* lora_scale; /* device scalar: multiplier * alpha / rank */
+    const void* residual;    /* [M][ld_res] bf16 or NULL (may alias c) */
+    void* c;                 /* [M][ldc] bf16 (N/2 columns when geglu) */
+    int32_t lda0, lda1, ca0, ca1;
+    int32_t mode;            /* 0 dense, 1 conv3x3 */
+    int32_t batch, hs, ws;   /* conv: source image dims */
+    int32_t src_xform;       /* conv: 0 none, 1 nearest upsample x2, 2 zero-dilate x2 */
+    int32_t stride;          /* conv: 1 or 2 */
+    int32_t ho, wo;          /* conv: output dims */
+    int32_t ldw;
+    int32_t M, N, K;
+    int32_t ld_rowbias, rows_per_sample;
+    int32_t ld_t, lora_groups; /* N/lora_groups columns share one rank-4 slice of T */
+    int32_t ld_res, ldc;
+    int32_t geglu;           /* 1: out[:, j] = a_j * gelu(g_j); W rows pre-permuted in 64-row blocks [32 a | 32 g] */
+    int32_t tile;            /* 0 auto; else (MI<<4)|NI with MI,NI in {1,2}: block tile (64*MI) x (64*NI) */
+} slh_gemm_desc;
+int slh_gemm(const slh_gemm_desc* d, slh_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * slh_skinny: T[M][R] = A[M][K] . Wd[R][K]^T (+bias), R <= 16, same A addressing as slh_gemm.
+ * LoRA down-projection lora_down(x) of lora.py:108-112 (Linear: (r,in); Conv: (r,Cin,k,k) repacked
+ * [r][tap][Cin]) and the UNet's conv_out (320 -> 4).  Output fp32 [M][ldo] or bf16 NCHW (conv_out).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct slh_skinny_desc {
+    const void* a0; const void* a1;
+    const void* w;           /* [R][K] bf16 */
+    const void* bias;        /* [R] bf16 or NULL */
+    void* out;
+    int32_t lda0, lda1, ca0, ca1;
+    int32_t mode, batch, hs, ws, src_xform, stride, ho, wo;
+    int32_t M, R, K;
+    int32_t ldo;
+    int32_t out_kind;        /* 0: fp32 [M][ldo]; 1: bf16 NCHW [batch][R][ho][wo] */
+} slh_skinny_desc;
+int slh_skinny(const slh_skinny_desc* d, slh_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * slh_gemv: y[b][n] = x'[b][:] . W[n][:] + bias[n] + addend[b][n] + lora,  b < nb <= 8 (weight-streaming).
+ * TimestepEmbedding MLPs, add_embedding, and all ResnetBlock2D.time_emb_proj layers batched into one
+ * launch (they only depend on emb).  in_act 1 applies SiLU to x first.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct slh_gemv_desc {
+    const void* x;           /* [nb][ldx] bf16 */
+    const void* w;           /* [N][K] bf16 */
+    const void* bias;        /* [N] bf16 or NULL */
+    const void* addend;      /* [nb][ld_add] bf16 or NULL */
+    const float* lora_t;     /* [nb][ld_t] fp32 or NULL */
+    const int32_t* lora_tcol;/* [N] first T column of row n (NULL: 0) */
+    const void* lora_up;     /* [N][4] bf16 */
+    const float* lora_scale;
+    void* y;                 /* [nb][ldy] bf16 (out_f32: fp32) */
+    int32_t nb, N, K, ldx, ld_add, ld_t, ldy;
+    int32_t in_act, out_f32;
+} slh_gemv_desc;
+int slh_gemv(const slh_gemv_desc* d, slh_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * GroupNorm (+SiLU) on pixel-major images; x may be a two-source channel concat.
+ * stats: per (sample, group) sum / sum-of-squares accumulated with atomics into stats[b][G][2] (fp32,
+ * zeroed by the caller).  apply: y = act((x-mean)*rstd*gamma+beta).
+ * diffusers ResnetBlock2D.norm1/norm2 (+nonlinearity), Transformer2DModel.norm, conv_norm_out.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct slh_gn_desc {
+    const void* x0; const void* x1;
+    const void* gamma; const void* beta; /* [C] bf16 */
+    float* stats;            /* [batch][groups][2] fp32 */
+    void* y;                 /* [batch*hw][ldy] bf16 */
+    int32_t ldx0, ldx1, c0, c1;
+    int32_t batch, hw, groups, ldy;
+    float eps;
+    int32_t act;             /* 0 none, 1 SiLU */
+} slh_gn_desc;
+int slh_gn_stats(const slh_gn_desc* d, slh_stream_t stream);
+int slh_gn_apply(const slh_gn_desc* d, slh_stream_t stream);
+
+/* GroupNorm backward (dx only: gamma/beta are frozen).  Two launches like the forward:
+ * bwd_stats accumulates per (b,g) sum(dyhat) and sum(dyhat*xhat) into bstats (zeroed by caller),
+ * bwd_apply writes dx (+= into dx if accumulate).  dy is the gradient of the post-activation output. */
+typedef struct slh_gn_bwd_desc {
+    const void* x0; const void* x1;
+    const void* gamma; const void* beta;
+    const float* stats;      /* forward stats */
+    float* bstats;           /* [batch][groups][2] fp32 */
+    const void* dy;          /* [batch*hw][lddy] bf16 */
+    void* dx0; void* dx1;    /* gradient w.r.t. source 0 / 1 */
+    int32_t ldx0, ldx1, c0, c1;
+    int32_t batch, hw, groups, lddy, lddx0, lddx1;
+    float eps;
+    int32_t act;
+    int32_t accumulate0, accumulate1; /* dx += instead of = */
+} slh_gn_bwd_desc;
+int slh_gn_bwd_stats(const slh_gn_bwd_desc* d, slh_stream_t stream);
+int slh_gn_bwd_apply(const slh_gn_bwd_desc* d, slh_stream_t stream);
+
+/* LayerNorm over the last dim (BasicTransformerBlock.norm1/2/3), one wave per row. */
+typedef struct slh_ln_desc {
+    const void* x; const void* gamma; const void* beta;
+    void* y;
+    float* mean_rstd;        /* [M][2] fp32 or NULL (saved for backward) */
+    int32_t M, C, ldx, ldy;
+    float eps;
+} slh_ln_desc;
+int slh_layernorm(const slh_ln_desc* d, slh_stream_t stream);
+
+typedef struct slh_ln_bwd_desc {
+    const void* x; const void* gamma; const void* dy;
+    const float* mean_rstd;
+    void* dx;                /* dx (+)= LN-backward(dy) */
+    int32_t M, C, ldx, lddy, lddx;
+    int32_t accumulate;
+} slh_ln_bwd_desc;
+int slh_layernorm_bwd(const slh_ln_bwd_desc* d, slh_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Attention, head_dim 64 (SDXL) : O = softmax(Q K^T * scale) V per (sample, head).
+ * Q [B][Tq][ldq] (head h at columns h*64..), K [B][Tk][ldk], VT [B][H][64][ldvt] (V transposed by
+ * slh_transpose_heads), O [B][Tq][ldo]; lse [B][H][Tq] fp32 (log2 domain) or NULL.
+ * Replaces Attention + XFormersAttnProcessor (train_lora.py:68).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct slh_attn_desc {
+    const void* q; const void* k; const void* vt;
+    void* o;
+    float* lse;
+    int32_t B, H, Tq, Tk, ldq, ldk, ldvt, ldo;
+    float scale;
+} slh_attn_desc;
+int slh_attn_fwd(const slh_attn_desc* d, slh_stream_t stream);
+
+/* src [B][T][ld] columns [h*64,(h+1)*64) -> dst [B][H][64][ldt] (columns >= T zero-filled up to ldt) */
+typedef struct slh_transpose_desc {
+    const void* src; void* dst;
+    int32_t B, H, T, ld, ldt;
+} slh_transpose_desc;
+int slh_transpose_heads(const slh_transpose_desc* d, slh_stream_t stream);
+
+/* Attention backward.  dQ (and dK/dV when self-attention) given dO, Q, K, V, O, lse.
+ * All operands [B][T][ld] pixel-major with heads in columns; transposed copies are built internally
+ * in the caller-provided workspace.  need_dkv = 0 for cross-attention (text K/V carry no gradient). */
+typedef struct slh_attn_bwd_desc {
+    const void* q; const void* k; const void* v; const void* o; const void* d_o;
+    const float* lse;
+    void* dq; void* dk; void* dv;
+    float* delta;            /* [B][H][Tq] fp32 workspace */
+    int32_t B, H, Tq, Tk, ldq, ldk, ldv, ldo, lddo, lddq, lddk, lddv;
+    float scale;
+    int32_t need_dkv;
+} slh_attn_bwd_desc;
+int slh_attn_bwd(const slh_attn_bwd_desc* d, slh_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * small ops
+ * ---------------------------------------------------------------------------------------------- */
+/* sinusoidal timestep embedding (Timesteps(dim, flip_sin_to_cos=True, freq_shift=0)), fp32 math -> bf16.
+ * out[b][col0 + j*dim + 0..dim) for each of the n_vals values vals[b][j] (fp32). */
+typedef struct slh_tembed_desc {
+    const float* vals; void* out;
+    int32_t nb, n_vals, dim, ldo, col0;
+} slh_tembed_desc;
+int slh_timestep_embed(const slh_tembed_desc* d, slh_stream_t stream);
+
+/* conv_in: (B,Cin<=8,H,W) bf16 NCHW -> pixel-major [B*H*W][Cout], 3x3 pad 1, w [Cout][9*Cin] (tap-major) */
+typedef struct slh_convin_desc {
+    const void* x; const void* w; const void* bias; void* y;
+    int32_t batch, cin, h, wd, cout, ldy;
+} slh_convin_desc;
+int slh_conv_in(const slh_convin_desc* d, slh_stream_t stream);
+
+/* generic elementwise helpers on bf16 matrices [M][C] (8 channels per thread) */
+typedef struct slh_ew_desc {
+    const void* a; const void* b; void* out;
+    int32_t M, C, lda, ldb, ldo;
+    int32_t op;              /* see SLH_EW_* */
+    int32_t iarg, iarg2;
+    float alpha;
+    int32_t pad_;
+} slh_ew_desc;
+enum {
+    SLH_EW_COPY = 0,         /* out = a */
+    SLH_EW_ADD = 1,          /* out = a + b */
+    SLH_EW_GEGLU_FWD = 2,    /* a = GEGLU.proj output [M][2C] in 64-column blocks [32 values | 32 gates] ->
+                                out[M][C] = value * gelu(gate)  (training forward keeps the pre-activation) */
+    SLH_EW_GEGLU_BWD = 3,    /* a as above, b = d(out) [M][C] -> out = d(proj) [M][2C], same blocked layout */
+    SLH_EW_UPSAMPLE_BWD = 4, /* a = d(upsampled) (2h x 2w image) -> out = 2x2 block sums; M = B*h*w, iarg = w, iarg2 = h*w */
+    SLH_EW_COLSUM = 5        /* out (fp32 [B][ldo], +=) = per-sample column sums of a; iarg2 = rows per sample */
+};
+int slh_elementwise(const slh_ew_desc* d, slh_stream_t stream);
+
+/* CFG combine + DDIM step (train_util.py:166-169 + scheduler.step, eta = 0), bf16 rounding points as the
+ * reference's tensor ops.  eps [2*nb][chw] (uncond half first), x [nb][chw] -> x_prev; also used with
+ * do_step = 0 to produce only the guided epsilon (predict_noise). */
+typedef struct slh_cfg_ddim_desc {
+    const void* eps; const void* x; void* out;
+    int32_t nb, chw;
+    float guidance;
+    float c_sqrt_beta_t, c_sqrt_alpha_t, c_sqrt_alpha_prev, c_dir;
+    int32_t do_step;
+} slh_cfg_ddim_desc;
+int slh_cfg_ddim(const slh_cfg_ddim_desc* d, slh_stream_t stream);
+
+/* guidance loss (prompt_util.py:108-148): loss = mean((target - (neutral +- gs*(positive-uncond)))^2);
+ * writes loss (fp32 scalar, atomically accumulated: zero it first) and d(loss)/d(target) (bf16). */
+typedef struct slh_loss_desc {
+    const void* target; const void* positive; const void* neutral; const void* uncond;
+    float* loss; void* dtarget;
+    int32_t n; float guidance; int32_t erase;
+} slh_loss_desc;
+int slh_guidance_loss(const slh_loss_desc* d, slh_stream_t stream);
+
+/* LoRA weight gradients: out (fp32, +=) = scale * sum_m Z[m][c] * V[m][r]; Z bf16 with the same addressing
+ * as slh_gemm's A (mode 1: column index = tap*Cin + c), V fp32 [M][ldv].  R is 4 or 12. */
+typedef struct slh_wgrad_desc {
+    const void* z0; const void* z1;
+    const float* v;
+    float* out;              /* dense: [C][ldo]; conv: [9][C][ldo] */
+    const float* scale;      /* device scalar */
+    int32_t ldz0, ldz1, c0, c1;
+    int32_t mode, batch, hs, ws, src_xform, stride, ho, wo;
+    int32_t M, R, ldv, ldo;
+    int32_t out_rmajor;      /* 1: out is [R][ldo] (down-weight layout), 0: [C][ldo] (up-weight layout) */
+    int32_t vgroup_cols;     /* >0: channel c uses V columns 4*(c/vgroup_cols).. (fused q/k/v up grads) */
+} slh_wgrad_desc;
+int slh_lora_wgrad(const slh_wgrad_desc* d, slh_stream_t stream);
+
+/* flat AdamW over the packed LoRA parameter buffer (bf16 params and moments, torch.optim.AdamW op order
+ * and bf16 rounding points; train_util.py:362-363, train_lora_xl.py:346). grads fp32. */
+typedef struct slh_adamw_desc {
+    void* param; void* exp_avg; void* exp_avg_sq; const float* grad;
+    int64_t n;
+    double lr, beta1, beta2, eps, weight_decay;  /* python floats of torch.optim.AdamW */
+    int32_t step;            /* 1-based */
+    float grad_scale;        /* multiply grads first (1/world_size after all-reduce) */
+} slh_adamw_desc;
+int slh_adamw(const slh_adamw_desc* d, slh_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * program executor: a whole UNet forward / backward is a flat command buffer built once by the host
+ * planner (sliders_amd/plan.py) and replayed with ONE call.  Record layout: {int32 opcode; int32
+ * nbytes; desc bytes (8-byte aligned)}.
+ * ---------------------------------------------------------------------------------------------- */
+enum {
+    SLH_OP_GEMM = 1, SLH_OP_SKINNY = 2, SLH_OP_GEMV = 3, SLH_OP_GN_STATS = 4, SLH_OP_GN_APPLY = 5,
+    SLH_OP_LAYERNORM = 6, SLH_OP_ATTN_FWD = 7, SLH_OP_TRANSPOSE_HEADS = 8, SLH_OP_TEMBED = 9,
+    SLH_OP_CONV_IN = 10, SLH_OP_ELEMENTWISE = 11, SLH_OP_CFG_DDIM = 12, SLH_OP_LOSS = 13,
+    SLH_OP_WGRAD = 14, SLH_OP_ADAMW = 15, SLH_OP_GN_BWD_STATS = 16, SLH_OP_GN_BWD_APPLY = 17,
+    SLH_OP_LAYERNORM_BWD = 18, SLH_OP_ATTN_BWD = 19, SLH_OP_MEMSET = 20
+};
+typedef struct slh_memset_desc { void* ptr; int64_t nbytes; int32_t value; int32_t pad; } slh_memset_desc;
+int slh_run_program(const void* program, int64_t nbytes, slh_stream_t stream);
+/* sizeof() of every descriptor, in declaration order above, for binding self-checks */
+int slh_desc_sizes(int32_t* out, int32_t cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

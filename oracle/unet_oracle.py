@@ -99,7 +99,7 @@ def tiny_sd1_config() -> UNetConfig:
     return UNetConfig(
         sample_size=16,
         block_out_channels=(64, 128, 256, 256),
-        attention_head_dim=(2, 2, 2, 2),   # head dims 32/64/128/128
+        attention_head_dim=(1, 2, 4, 4),   # head dim 64 everywhere
         cross_attention_dim=128,
     )
 
@@ -373,13 +373,15 @@ class CrossAttnDownBlock2D(nn.Module):
     def __init__(self, in_channels, out_channels, temb_channels, num_layers, tlayers, heads,
                  cross_attention_dim, use_linear_projection, add_downsample, groups, eps):
         super().__init__()
-        self.resnets = nn.ModuleList([
-            ResnetBlock2D(in_channels if i == 0 else out_channels, out_channels, temb_channels, groups, eps)
-            for i in range(num_layers)])
+        resnets = [ResnetBlock2D(in_channels if i == 0 else out_channels, out_channels, temb_channels, groups, eps)
+                   for i in range(num_layers)]
+        # diffusers registers `attentions` before `resnets` in the cross-attention blocks; this fixes
+        # the named_modules() order the reference's LoRANetwork.create_modules walks (lora.py:175)
         self.attentions = nn.ModuleList([
             Transformer2DModel(heads, out_channels // heads, out_channels, tlayers, cross_attention_dim,
                                use_linear_projection, groups)
             for _ in range(num_layers)])
+        self.resnets = nn.ModuleList(resnets)
         self.downsamplers = nn.ModuleList([Downsample2D(out_channels)]) if add_downsample else None
 
     def forward(self, hidden_states, temb, encoder_hidden_states=None):
@@ -399,12 +401,12 @@ class UNetMidBlock2DCrossAttn(nn.Module):
     def __init__(self, in_channels, temb_channels, tlayers, heads, cross_attention_dim,
                  use_linear_projection, groups, eps):
         super().__init__()
-        self.resnets = nn.ModuleList([
-            ResnetBlock2D(in_channels, in_channels, temb_channels, groups, eps),
-            ResnetBlock2D(in_channels, in_channels, temb_channels, groups, eps)])
+        resnets = [ResnetBlock2D(in_channels, in_channels, temb_channels, groups, eps),
+                   ResnetBlock2D(in_channels, in_channels, temb_channels, groups, eps)]
         self.attentions = nn.ModuleList([
             Transformer2DModel(heads, in_channels // heads, in_channels, tlayers, cross_attention_dim,
                                use_linear_projection, groups)])
+        self.resnets = nn.ModuleList(resnets)
 
     def forward(self, hidden_states, temb, encoder_hidden_states=None):
         hidden_states = self.resnets[0](hidden_states, temb)
@@ -451,8 +453,8 @@ class CrossAttnUpBlock2D(nn.Module):
                                          temb_channels, groups, eps))
             attentions.append(Transformer2DModel(heads, out_channels // heads, out_channels, tlayers,
                                                  cross_attention_dim, use_linear_projection, groups))
-        self.resnets = nn.ModuleList(resnets)
         self.attentions = nn.ModuleList(attentions)
+        self.resnets = nn.ModuleList(resnets)
         self.upsamplers = nn.ModuleList([Upsample2D(out_channels)]) if add_upsample else None
 
     def forward(self, hidden_states, res_hidden_states_tuple, temb, encoder_hidden_states=None):
@@ -502,7 +504,9 @@ class UNet2DConditionModel(nn.Module):
             self.add_time_proj = Timesteps(cfg.addition_time_embed_dim, True, 0.0)
             self.add_embedding = TimestepEmbedding(cfg.projection_class_embeddings_input_dim, ted)
 
+        # diffusers creates both ModuleLists up front, so `up_blocks` precedes `mid_block` in named_modules()
         self.down_blocks = nn.ModuleList()
+        self.up_blocks = nn.ModuleList()
         output_channel = boc[0]
         for i, t in enumerate(cfg.down_block_types):
             input_channel, output_channel = output_channel, boc[i]
@@ -521,7 +525,6 @@ class UNet2DConditionModel(nn.Module):
             boc[-1], ted, cfg.transformer_layers_per_block[-1], cfg.attention_head_dim[-1],
             cfg.cross_attention_dim, cfg.use_linear_projection, g, eps)
 
-        self.up_blocks = nn.ModuleList()
         rboc = tuple(reversed(boc))
         rheads = tuple(reversed(cfg.attention_head_dim))
         rtl = tuple(reversed(cfg.transformer_layers_per_block))

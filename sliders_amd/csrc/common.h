@@ -1,0 +1,69 @@
+// Shared device/host helpers for the sliders_amd HIP library (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+
+typedef unsigned short bf16_t;  // raw storage type used in host-visible signatures
+
+#define SLH_WAVE 64
+
+// 64 B of zeros that out-of-image im2col taps read from (device globals are zero-initialised).
+static __device__ __attribute__((aligned(64))) unsigned int slh_zero_page[64];
+
+__device__ __forceinline__ float bf2f(__bf16 x) { return (float)x; }
+__device__ __forceinline__ __bf16 f2bf(float x) { return (__bf16)x; }
+
+__device__ __forceinline__ float bfraw2f(unsigned short u) {
+    return __builtin_bit_cast(float, ((unsigned int)u) << 16);
+}
+// round-to-nearest-even fp32 -> bf16 bits (matches torch's CPU/GPU conversion; NaN kept quiet)
+__device__ __forceinline__ unsigned short f2bfraw(float f) {
+    return __builtin_bit_cast(unsigned short, (__bf16)f);
+}
+__device__ __forceinline__ float round_bf16(float f) { return (float)((__bf16)f); }
+
+__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// async 16-byte global -> LDS copy (dest = wave-uniform base + lane*16)
+__device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+// ---- host side -------------------------------------------------------------------------------
+void slh_set_error(const char* fmt, ...);
+#define SLH_CHECK(cond, ...)            \
+    do {                                \
+        if (!(cond)) {                  \
+            slh_set_error(__VA_ARGS__); \
+            return -1;                  \
+        }                               \
+    } while (0)
+#define SLH_LAUNCH_CHECK(name)                                              \
+    do {                                                                    \
+        hipError_t e_ = hipGetLastError();                                  \
+        if (e_ != hipSuccess) {                                             \
+            slh_set_error("%s: launch failed: %s", name, hipGetErrorString(e_)); \
+            return -2;                                                      \
+        }                                                                   \
+    } while (0)

@@ -1,0 +1,338 @@
+// bf16 MFMA GEMM / implicit-GEMM 3x3 convolution with fused LoRA-up, bias, time-embedding, residual
+// and GEGLU epilogues.  gfx950 (CDNA4) only.
+//
+//   C[M][N] = epi( A[M][K] . W[N][K]^T )
+//
+// Structure: 256 threads = 4 waves (2 x 2), block tile (64*MI) x (64*NI), K-step 64, double-buffered LDS
+// filled with global_load_lds_dwordx4 (16 B/lane, no VGPR round trip), one barrier per K-step.
+// LDS rows are 128 B (64 bf16); the 16-byte slot index is XOR-swizzled with (row>>1)&7 so that the 16-lane
+// groups of ds_read_b128 touch 16 distinct 16-B bank slots.  global_load_lds writes lane-linear, so the
+// swizzle is applied to the per-lane SOURCE address (inverse permutation) and again on the read.
+// MFMA operand roles are swapped (W rows feed the A operand, activation rows the B operand) so that each
+// lane ends up with 4 consecutive output columns of ONE output row per accumulator quad: 8-byte stores,
+// per-lane LoRA T[m][0..3], per-lane residual reads.
+//
+// Reference semantics replaced: torch.nn.functional.linear / conv2d inside diffusers-0.20.2
+// (ResnetBlock2D.conv1/conv2/conv_shortcut, Downsample2D.conv, Upsample2D.conv, Attention.to_q/k/v/out,
+// GEGLU.proj, FeedForward.net.2, Transformer2DModel.proj_in/out) plus the LoRA branch of
+// trainscripts/textsliders/lora.py:108-112.
+#include "common.h"
+#include "../../include/sliders_hip.h"
+
+namespace {
+
+struct GemmArgs {
+    const __bf16* a0; const __bf16* a1; const __bf16* w;
+    const __bf16* bias; const __bf16* rowbias; const float* lora_t; const __bf16* lora_up;
+    const float* lora_scale; const __bf16* residual; __bf16* c;
+    int lda0, lda1, ca0, ca1;
+    int hs, ws, src_xform, stride, ho, wo;
+    int ldw, M, N, K;
+    int ld_rowbias, rows_per_sample, ld_t, lora_cols_per_group, ld_res, ldc, geglu;
+    int tiles_m, tiles_n;
+};
+
+constexpr int BK = 64;
+
+// swizzled byte offset of (row, 16-byte slot) inside a [rows][64] bf16 LDS tile
+__device__ __forceinline__ int lds_off(int row, int slot) {
+    return row * 128 + ((slot ^ ((row >> 1) & 7)) << 4);
+}
+
+template <int MI, int NI, int MODE>
+__global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
+    constexpr int BM = 64 * MI;
+    constexpr int BN = 64 * NI;
+    constexpr int XI = BM / 32;  // glds instructions per wave for the X tile (8 rows each, 4 waves)
+    constexpr int WI = BN / 32;
+    __shared__ __attribute__((aligned(16))) char smem[2 * (BM + BN) * 128];
+    char* sX = smem;                   // [2][BM][128 B]
+    char* sW = smem + 2 * BM * 128;    // [2][BN][128 B]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+
+    // ---- XCD-aware tile mapping: block b runs on XCD b%8; give each XCD a contiguous chunk of the
+    // tile sequence (m fastest inside an n panel) so neighbours share the W panel in that XCD's L2.
+    int bid = blockIdx.x;
+    {
+        const int nblk = gridDim.x;
+        const int q = nblk >> 3, r = nblk & 7;
+        const int xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int tile_n = bid / p.tiles_m;
+    const int tile_m = bid - tile_n * p.tiles_m;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+    // ---- per-lane fill geometry --------------------------------------------------------------
+    const int frow = lane >> 3;   // row within the 8-row group written by one glds instruction
+    const int fslot = lane & 7;   // physical 16-B slot in the row
+    const int cin = p.ca0 + p.ca1;
+
+    long xrow_off0[XI];           // dense: element offset of the row in source 0 / 1
+    long xrow_off1[XI];
+    int xb[XI], xoy[XI], xox[XI]; // conv: sample / output pixel of the row
+    int xks[XI];                  // logical k-slot this lane fetches (inverse swizzle)
+#pragma unroll
+    for (int i = 0; i < XI; ++i) {
+        const int row = (wave + 4 * i) * 8 + frow;
+        int m = m0 + row;
+        m = m < p.M ? m : p.M - 1;
+        xks[i] = fslot ^ ((row >> 1) & 7);
+        if (MODE == 0) {
+            xrow_off0[i] = (long)m * p.lda0;
+            xrow_off1[i] = (long)m * p.lda1;
+        } else {
+            const int hw = p.ho * p.wo;
+            const int b = m / hw;
+            const int rem = m - b * hw;
+            const int oy = rem / p.wo;
+            xb[i] = b; xoy[i] = oy; xox[i] = rem - oy * p.wo;
+        }
+    }
+    const __bf16* wptr[WI];
+#pragma unroll
+    for (int i = 0; i < WI; ++i) {
+        const int row = (wave + 4 * i) * 8 + frow;
+        int n = n0 + row;
+        n = n < p.N ? n : p.N - 1;
+        wptr[i] = p.w + (long)n * p.ldw + ((fslot ^ ((row >> 1) & 7)) << 3);
+    }
+
+    auto stage = [&](int buf, int kt) {
+        const int k0 = kt * BK;
+        char* dX = sX + buf * (BM * 128);
+        char* dW = sW + buf * (BN * 128);
+        if (MODE == 0) {
+            const bool s1 = k0 >= p.ca0;
+            const __bf16* base = s1 ? p.a1 : p.a0;
+            const int kk = s1 ? k0 - p.ca0 : k0;
+#pragma unroll
+            for (int i = 0; i < XI; ++i) {
+                const __bf16* src = base + (s1 ? xrow_off1[i] : xrow_off0[i]) + kk + (xks[i] << 3);
+                glds16(src, dX + (wave + 4 * i) * 1024);
+            }
+        } else {
+            const int tap = k0 / cin;
+            const int c0 = k0 - tap * cin;
+            const int ky = tap / 3, kx = tap - ky * 3;
+            const bool s1 = c0 >= p.ca0;
+            const __bf16* base = s1 ? p.a1 : p.a0;
+            const int ld = s1 ? p.lda1 : p.lda0;
+            const int cc = s1 ? c0 - p.ca0 : c0;
+            const int sh = p.src_xform ? 1 : 0;
+            const int HL = p.hs << sh, WL = p.ws << sh;
+#pragma unroll
+            for (int i = 0; i < XI; ++i) {
+                const int iy = xoy[i] * p.stride + ky - 1;
+                const int ix = xox[i] * p.stride + kx - 1;
+                bool ok = (iy >= 0) & (iy < HL) & (ix >= 0) & (ix < WL);
+                if (p.src_xform == 2) ok = ok & (((iy | ix) & 1) == 0);
+                const int sy = iy >> sh, sx = ix >> sh;
+                const long pix = ((long)xb[i] * p.hs + sy) * p.ws + sx;
+                const __bf16* src = ok ? base + pix * ld + cc + (xks[i] << 3)
+                                       : (const __bf16*)slh_zero_page;
+                glds16(src, dX + (wave + 4 * i) * 1024);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < WI; ++i) glds16(wptr[i] + k0, dW + (wave + 4 * i) * 1024);
+    };
+
+    f32x16 acc[MI][NI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int nk = p.K / BK;
+    const int lrow = lane & 31, lhi = lane >> 5;
+
+    stage(0, 0);
+    for (int kt = 0; kt < nk; ++kt) {
+        __syncthreads();  // drains this wave's glds (vmcnt(0)) and orders all waves
+        if (kt + 1 < nk) stage((kt + 1) & 1, kt + 1);
+        const char* cX = sX + (kt & 1) * (BM * 128);
+        const char* cW = sW + (kt & 1) * (BN * 128);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            bf16x8 xf[MI], wf[NI];
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+                xf[i] = *(const bf16x8*)(cX + lds_off(wm * (32 * MI) + i * 32 + lrow, ks * 2 + lhi));
+#pragma unroll
+            for (int j = 0; j < NI; ++j)
+                wf[j] = *(const bf16x8*)(cW + lds_off(wn * (32 * NI) + j * 32 + lrow, ks * 2 + lhi));
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NI; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[j], xf[i], acc[i][j], 0, 0, 0);
+        }
+    }
+
+    // ---- epilogue ---------------------------------------------------------------------------------
+    // acc[i][j][r] = C[m = m0 + wm*32*MI + i*32 + lrow][n = n0 + wn*32*NI + j*32 + (r&3) + 8*(r>>2) + 4*lhi]
+    const float lscale = p.lora_t ? *p.lora_scale : 0.f;
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+        const int m = m0 + wm * (32 * MI) + i * 32 + lrow;
+        if (m >= p.M) continue;
+        f32x4 tv[3];
+        if (p.lora_t) {
+#pragma unroll
+            for (int g = 0; g < 3; ++g)
+                if (g * 4 < p.ld_t) tv[g] = *(const f32x4*)(p.lora_t + (long)m * p.ld_t + g * 4);
+        }
+        const __bf16* rb = p.rowbias ? p.rowbias + (long)(m / p.rows_per_sample) * p.ld_rowbias : nullptr;
+        if (!p.geglu) {
+#pragma unroll
+            for (int j = 0; j < NI; ++j) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int n = n0 + wn * (32 * NI) + j * 32 + q * 8 + lhi * 4;
+                    if (n >= p.N) continue;
+                    float v[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = acc[i][j][q * 4 + e];
+                    if (p.bias) {
+                        const bf16x4 b4 = *(const bf16x4*)(p.bias + n);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] += (float)b4[e];
+                    }
+                    if (rb) {
+                        const bf16x4 b4 = *(const bf16x4*)(rb + n);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] += (float)b4[e];
+                    }
+                    if (p.lora_t) {
+                        const int g = n / p.lora_cols_per_group;
+                        const f32x4 t = g == 0 ? tv[0] : (g == 1 ? tv[1] : tv[2]);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const bf16x4 u = *(const bf16x4*)(p.lora_up + (long)(n + e) * 4);
+                            v[e] += lscale * (t[0] * (float)u[0] + t[1] * (float)u[1] +
+                                              t[2] * (float)u[2] + t[3] * (float)u[3]);
+                        }
+                    }
+                    if (p.residual) {
+                        const bf16x4 r4 = *(const bf16x4*)(p.residual + (long)m * p.ld_res + n);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] += (float)r4[e];
+                    }
+                    bf16x4 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = (__bf16)v[e];
+                    *(bf16x4*)(p.c + (long)m * p.ldc + n) = o;
+                }
+            }
+        } else {
+            // GEGLU: W rows are stored in 64-row blocks [32 value rows | 32 gate rows]; NI is 2 here, so
+            // sub-tile j=0 holds the values and j=1 the gates of the same 32 output columns.
+            if (NI == 2) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int n = n0 + wn * 64 + q * 8 + lhi * 4;          // row index of the value rows
+                    const int nout = ((n0 + wn * 64) >> 1) + q * 8 + lhi * 4;
+                    if (n + 32 >= p.N) continue;
+                    float a[4], g[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { a[e] = acc[i][0][q * 4 + e]; g[e] = acc[i][NI - 1][q * 4 + e]; }
+                    if (p.bias) {
+                        const bf16x4 ba = *(const bf16x4*)(p.bias + n);
+                        const bf16x4 bg = *(const bf16x4*)(p.bias + n + 32);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { a[e] += (float)ba[e]; g[e] += (float)bg[e]; }
+                    }
+                    bf16x4 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        // reference rounds proj(x) to bf16 before chunk/gelu
+                        const float av = round_bf16(a[e]), gv = round_bf16(g[e]);
+                        o[e] = (__bf16)(av * round_bf16(gelu_erf_f(gv)));
+                    }
+                    *(bf16x4*)(p.c + (long)m * p.ldc + nout) = o;
+                }
+            }
+        }
+    }
+}
+
+template <int MI, int NI>
+int launch_gemm(const GemmArgs& a, int mode, hipStream_t s) {
+    const int grid = a.tiles_m * a.tiles_n;
+    if (mode == 0) hipLaunchKernelGGL((gemm_kernel<MI, NI, 0>), dim3(grid), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((gemm_kernel<MI, NI, 1>), dim3(grid), dim3(256), 0, s, a);
+    SLH_LAUNCH_CHECK("slh_gemm");
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int slh_gemm(const slh_gemm_desc* d, slh_stream_t stream) {
+    SLH_CHECK(d && d->a0 && d->w && d->c, "slh_gemm: null pointer");
+    SLH_CHECK(d->M > 0 && d->N > 0 && d->K > 0, "slh_gemm: bad shape M=%d N=%d K=%d", d->M, d->N, d->K);
+    SLH_CHECK(d->K % 64 == 0, "slh_gemm: K=%d must be a multiple of 64", d->K);
+    SLH_CHECK(d->N % 4 == 0, "slh_gemm: N=%d must be a multiple of 4", d->N);
+    SLH_CHECK(d->ca0 % 64 == 0 && d->ca1 % 64 == 0, "slh_gemm: channel counts must be multiples of 64");
+    SLH_CHECK((d->a1 != nullptr) == (d->ca1 > 0), "slh_gemm: a1/ca1 mismatch");
+    SLH_CHECK(d->lda0 % 8 == 0 && d->lda1 % 8 == 0 && d->ldw % 8 == 0 && d->ldc % 4 == 0,
+              "slh_gemm: leading dimensions must keep 16-byte loads / 8-byte stores aligned");
+    const int cin = d->ca0 + d->ca1;
+    if (d->mode == 0) {
+        SLH_CHECK(cin == d->K, "slh_gemm: dense K=%d != ca0+ca1=%d", d->K, cin);
+    } else {
+        SLH_CHECK(d->mode == 1, "slh_gemm: bad mode %d", d->mode);
+        SLH_CHECK(d->K == 9 * cin, "slh_gemm: conv K=%d != 9*Cin=%d", d->K, 9 * cin);
+        SLH_CHECK(d->stride == 1 || d->stride == 2, "slh_gemm: bad stride");
+        SLH_CHECK(d->src_xform >= 0 && d->src_xform <= 2, "slh_gemm: bad src_xform");
+        SLH_CHECK(d->M == d->batch * d->ho * d->wo, "slh_gemm: conv M mismatch");
+    }
+    if (d->lora_t) {
+        SLH_CHECK(d->lora_up && d->lora_scale, "slh_gemm: lora pointers");
+        SLH_CHECK(d->lora_groups >= 1 && d->lora_groups <= 3 && d->N % d->lora_groups == 0 &&
+                      d->ld_t >= 4 * d->lora_groups && d->ld_t % 4 == 0,
+                  "slh_gemm: bad lora grouping");
+        SLH_CHECK((d->N / d->lora_groups) % 4 == 0, "slh_gemm: lora group width");
+    }
+    if (d->rowbias) SLH_CHECK(d->rows_per_sample > 0 && d->ld_rowbias % 4 == 0, "slh_gemm: rowbias");
+    if (d->residual) SLH_CHECK(d->ld_res % 4 == 0, "slh_gemm: ld_res");
+    if (d->geglu) SLH_CHECK(d->N % 64 == 0 && !d->lora_t && !d->residual && !d->rowbias, "slh_gemm: geglu constraints");
+
+    int MI = 2, NI = 2;
+    if (d->tile) {
+        MI = (d->tile >> 4) & 15; NI = d->tile & 15;
+        SLH_CHECK((MI == 1 || MI == 2) && (NI == 1 || NI == 2), "slh_gemm: bad tile");
+    } else {
+        // heuristic: keep at least ~1.5 workgroups per CU when the problem allows it
+        auto tiles = [&](int mi, int ni) { return ((d->M + 64 * mi - 1) / (64 * mi)) * ((d->N + 64 * ni - 1) / (64 * ni)); };
+        if (tiles(2, 2) < 384) { MI = 2; NI = 1; }
+        if (!d->geglu && tiles(2, 2) < 192) { MI = 1; NI = 1; }
+        if (d->geglu) { NI = 2; if (tiles(2, 2) < 256) MI = 1; }
+    }
+    if (d->geglu) SLH_CHECK(NI == 2, "slh_gemm: geglu needs NI=2");
+
+    GemmArgs a;
+    a.a0 = (const __bf16*)d->a0; a.a1 = (const __bf16*)d->a1; a.w = (const __bf16*)d->w;
+    a.bias = (const __bf16*)d->bias; a.rowbias = (const __bf16*)d->rowbias; a.lora_t = d->lora_t;
+    a.lora_up = (const __bf16*)d->lora_up; a.lora_scale = d->lora_scale;
+    a.residual = (const __bf16*)d->residual; a.c = (__bf16*)d->c;
+    a.lda0 = d->lda0; a.lda1 = d->lda1; a.ca0 = d->ca0; a.ca1 = d->ca1;
+    a.hs = d->hs; a.ws = d->ws; a.src_xform = d->src_xform; a.stride = d->stride; a.ho = d->ho; a.wo = d->wo;
+    a.ldw = d->ldw; a.M = d->M; a.N = d->N; a.K = d->K;
+    a.ld_rowbias = d->ld_rowbias; a.rows_per_sample = d->rows_per_sample > 0 ? d->rows_per_sample : 1;
+    a.ld_t = d->ld_t; a.lora_cols_per_group = d->lora_t ? d->N / d->lora_groups : 1;
+    a.ld_res = d->ld_res; a.ldc = d->ldc; a.geglu = d->geglu;
+    a.tiles_m = (d->M + 64 * MI - 1) / (64 * MI);
+    a.tiles_n = (d->N + 64 * NI - 1) / (64 * NI);
+    hipStream_t s = (hipStream_t)stream;
+    if (MI == 2 && NI == 2) return launch_gemm<2, 2>(a, d->mode, s);
+    if (MI == 2 && NI == 1) return launch_gemm<2, 1>(a, d->mode, s);
+    if (MI == 1 && NI == 2) return launch_gemm<1, 2>(a, d->mode, s);
+    return launch_gemm<1, 1>(a, d->mode, s);
+}

@@ -1,0 +1,319 @@
+// Skinny (rank-r) products around the LoRA branch of trainscripts/textsliders/lora.py:108-112 and the
+// small weight-streaming GEMVs of the time-embedding path.  gfx950 only.  These are HBM/L2-bound: every
+// lane moves 16 B per load, reductions use wave shuffles, fp32 accumulation.
+//
+//   slh_skinny : T[M][R]   = A[M][K] . Wd[R][K]^T          (lora_down(x); also conv_out 320->4)
+//   slh_gemv   : y[nb][N]  = x[nb][K] . W[N][K]^T + ...     (TimestepEmbedding, time_emb_proj batch)
+//   slh_lora_wgrad : dW[C][R] += s * sum_m Z[m][c] V[m][r]  (LoRA up / down weight gradients)
+#include "common.h"
+#include "../../include/sliders_hip.h"
+
+namespace {
+
+struct AddrArgs {  // shared A-operand addressing (same meaning as slh_gemm_desc)
+    const __bf16* a0; const __bf16* a1;
+    int lda0, lda1, ca0, ca1;
+    int mode, hs, ws, src_xform, stride, ho, wo;
+};
+
+// ------------------------------------------------------------------------------------------------
+// skinny: 16 lanes per output row, 4 rows per wave, 16 rows per 256-thread block
+// ------------------------------------------------------------------------------------------------
+template <int RMAX>
+__global__ __launch_bounds__(256) void skinny_kernel(AddrArgs A, const __bf16* __restrict__ w,
+                                                     const __bf16* __restrict__ bias, void* out,
+                                                     int M, int R, int K, int ldo, int out_kind) {
+    const int tid = threadIdx.x;
+    const int sub = tid & 15;
+    const int m = blockIdx.x * 16 + (tid >> 4);
+    const bool active = m < M;
+    const int mm = active ? m : M - 1;
+    float acc[RMAX];
+#pragma unroll
+    for (int r = 0; r < RMAX; ++r) acc[r] = 0.f;
+    const int cin = A.ca0 + A.ca1;
+
+    auto fma_chunk = [&](const __bf16* src, int k) {
+        const bf16x8 x = *(const bf16x8*)src;
+        float xf[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) xf[e] = (float)x[e];
+#pragma unroll
+        for (int r = 0; r < RMAX; ++r) {
+            if (r < R) {
+                const bf16x8 wv = *(const bf16x8*)(w + (long)r * K + k);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[r] += xf[e] * (float)wv[e];
+            }
+        }
+    };
+
+    if (A.mode == 0) {
+        for (int k = sub * 8; k < K; k += 128) {
+            const __bf16* src = k < A.ca0 ? A.a0 + (long)mm * A.lda0 + k
+                                          : A.a1 + (long)mm * A.lda1 + (k - A.ca0);
+            fma_chunk(src, k);
+        }
+    } else {
+        const int hw = A.ho * A.wo;
+        const int b = mm / hw;
+        const int rem = mm - b * hw;
+        const int oy = rem / A.wo, ox = rem - oy * A.wo;
+        const int sh = A.src_xform ? 1 : 0;
+        const int HL = A.hs << sh, WL = A.ws << sh;
+        for (int tap = 0; tap < 9; ++tap) {
+            const int ky = tap / 3, kx = tap - ky * 3;
+            const int iy = oy * A.stride + ky - 1, ix = ox * A.stride + kx - 1;
+            bool ok = (iy >= 0) & (iy < HL) & (ix >= 0) & (ix < WL);
+            if (A.src_xform == 2) ok = ok & (((iy | ix) & 1) == 0);
+            if (!ok) continue;
+            const long pix = ((long)b * A.hs + (iy >> sh)) * A.ws + (ix >> sh);
+            for (int c = sub * 8; c < cin; c += 128) {
+                const __bf16* src = c < A.ca0 ? A.a0 + pix * A.lda0 + c : A.a1 + pix * A.lda1 + (c - A.ca0);
+                fma_chunk(src, tap * cin + c);
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < RMAX; ++r) {
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) acc[r] += __shfl_xor(acc[r], o, 64);
+    }
+    if (active && sub == 0) {
+        if (out_kind == 0) {
+            float* o = (float*)out + (long)m * ldo;
+#pragma unroll
+            for (int r = 0; r < RMAX; ++r)
+                if (r < R) o[r] = acc[r] + (bias ? (float)bias[r] : 0.f);
+        } else {
+            const int hw = A.ho * A.wo;
+            const int b = m / hw;
+            const int rem = m - b * hw;
+            __bf16* o = (__bf16*)out;
+#pragma unroll
+            for (int r = 0; r < RMAX; ++r)
+                if (r < R) o[((long)b * R + r) * hw + rem] = (__bf16)(acc[r] + (bias ? (float)bias[r] : 0.f));
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// gemv: one wave per output feature n, all nb <= 8 samples at once
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gemv_kernel(const slh_gemv_desc d) {
+    const int lane = threadIdx.x & 63;
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= d.N) return;
+    const __bf16* x = (const __bf16*)d.x;
+    const __bf16* w = (const __bf16*)d.w + (long)n * d.K;
+    float acc[8];
+#pragma unroll
+    for (int b = 0; b < 8; ++b) acc[b] = 0.f;
+    for (int k = lane * 8; k < d.K; k += 512) {
+        const bf16x8 wv = *(const bf16x8*)(w + k);
+        float wf[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) wf[e] = (float)wv[e];
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            if (b < d.nb) {
+                const bf16x8 xv = *(const bf16x8*)(x + (long)b * d.ldx + k);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    float xe = (float)xv[e];
+                    if (d.in_act == 1) xe = round_bf16(silu_f(xe));  // reference: nonlinearity(temb) in bf16
+                    acc[b] += xe * wf[e];
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int b = 0; b < 8; ++b) acc[b] = wave_sum(acc[b]);
+    if (lane == 0) {
+        const float bias = d.bias ? (float)((const __bf16*)d.bias)[n] : 0.f;
+        float up[4] = {0.f, 0.f, 0.f, 0.f};
+        float ls = 0.f;
+        int tcol = 0;
+        if (d.lora_t) {
+            ls = *d.lora_scale;
+            tcol = d.lora_tcol ? d.lora_tcol[n] : 0;
+            const bf16x4 u = *(const bf16x4*)((const __bf16*)d.lora_up + (long)n * 4);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) up[r] = (float)u[r];
+        }
+        for (int b = 0; b < d.nb; ++b) {
+            float v = acc[b] + bias;
+            if (d.lora_t) {
+                const float* t = d.lora_t + (long)b * d.ld_t + tcol;
+                v += ls * (t[0] * up[0] + t[1] * up[1] + t[2] * up[2] + t[3] * up[3]);
+            }
+            if (d.addend) v = round_bf16(v) + (float)((const __bf16*)d.addend)[(long)b * d.ld_add + n];
+            if (d.out_f32) ((float*)d.y)[(long)b * d.ldy + n] = v;
+            else ((__bf16*)d.y)[(long)b * d.ldy + n] = (__bf16)v;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// LoRA weight gradient: thread owns 8 channels (one 16-B chunk) and R accumulators per channel.
+// block = 32 chunk-columns x 8 row-lanes; grid = (chunk blocks, M splits, taps)
+// out index: rmajor ? r*ldo + col : col*ldo + r, col = tap*C + c (conv) or c.
+// vgroup_cols > 0: V column offset 4*(c / vgroup_cols) (fused q/k/v up-projection gradients).
+// ------------------------------------------------------------------------------------------------
+struct WgradArgs {
+    AddrArgs A;
+    const float* v; float* out; const float* scale;
+    int M, R, ldv, ldo, rows_per_block, rmajor, vgroup_cols;
+};
+
+template <int R>
+__global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p) {
+    __shared__ float red[4][32][8 * R + 1];
+    const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;
+    const int C = p.A.ca0 + p.A.ca1;
+    const int c = (blockIdx.x * 32 + cx) * 8;
+    const bool cvalid = c < C;
+    const int tap = blockIdx.z;
+    const int m_begin = blockIdx.y * p.rows_per_block;
+    const int m_end = min(p.M, m_begin + p.rows_per_block);
+    float acc[8][R];
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+#pragma unroll
+        for (int r = 0; r < R; ++r) acc[e][r] = 0.f;
+    const int voff = p.vgroup_cols > 0 ? 4 * (c / p.vgroup_cols) : 0;
+    const int sh = p.A.src_xform ? 1 : 0;
+    const int HL = p.A.hs << sh, WL = p.A.ws << sh;
+    const int ky = tap / 3, kx = tap - ky * 3;
+    const int hw = p.A.ho * p.A.wo;
+    if (cvalid) {
+        for (int m = m_begin + ry; m < m_end; m += 8) {
+            const __bf16* src;
+            if (p.A.mode == 0) {
+                src = c < p.A.ca0 ? p.A.a0 + (long)m * p.A.lda0 + c : p.A.a1 + (long)m * p.A.lda1 + (c - p.A.ca0);
+            } else {
+                const int b = m / hw;
+                const int rem = m - b * hw;
+                const int oy = rem / p.A.wo, ox = rem - oy * p.A.wo;
+                const int iy = oy * p.A.stride + ky - 1, ix = ox * p.A.stride + kx - 1;
+                bool ok = (iy >= 0) & (iy < HL) & (ix >= 0) & (ix < WL);
+                if (p.A.src_xform == 2) ok = ok & (((iy | ix) & 1) == 0);
+                if (!ok) continue;
+                const long pix = ((long)b * p.A.hs + (iy >> sh)) * p.A.ws + (ix >> sh);
+                src = c < p.A.ca0 ? p.A.a0 + pix * p.A.lda0 + c : p.A.a1 + pix * p.A.lda1 + (c - p.A.ca0);
+            }
+            const bf16x8 z = *(const bf16x8*)src;
+            float vv[R];
+#pragma unroll
+            for (int r = 0; r < R; ++r) vv[r] = p.v[(long)m * p.ldv + voff + r];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float ze = (float)z[e];
+#pragma unroll
+                for (int r = 0; r < R; ++r) acc[e][r] += ze * vv[r];
+            }
+        }
+    }
+    // lanes l and l+32 of a wave hold the same chunk for two row-lanes: fold them, then 4 waves via LDS
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            acc[e][r] += __shfl_xor(acc[e][r], 32, 64);
+            if ((threadIdx.x & 32) == 0) red[threadIdx.x >> 6][cx][e * R + r] = acc[e][r];
+        }
+    __syncthreads();
+    // 256 threads reduce 32 chunks x (8R) values over the 8 row-lanes
+    const float s = *p.scale;
+    for (int idx = threadIdx.x; idx < 32 * 8 * R; idx += 256) {
+        const int ccx = idx / (8 * R);
+        const int er = idx - ccx * (8 * R);
+        const int e = er / R, r = er - e * R;
+        const int cc = (blockIdx.x * 32 + ccx) * 8 + e;
+        if (cc >= C) continue;
+        float t = 0.f;
+#pragma unroll
+        for (int y = 0; y < 4; ++y) t += red[y][ccx][er];
+        const long col = (p.A.mode == 0 ? 0 : (long)tap * C) + cc;
+        float* o = p.rmajor ? p.out + (long)r * p.ldo + col : p.out + col * p.ldo + r;
+        atomicAdd(o, s * t);
+    }
+}
+
+}  // namespace
+
+static int fill_addr(AddrArgs& A, const void* a0, const void* a1, int lda0, int lda1, int ca0, int ca1, int mode,
+                     int hs, int ws, int src_xform, int stride, int ho, int wo) {
+    A.a0 = (const __bf16*)a0; A.a1 = (const __bf16*)a1;
+    A.lda0 = lda0; A.lda1 = lda1; A.ca0 = ca0; A.ca1 = ca1; A.mode = mode;
+    A.hs = hs; A.ws = ws; A.src_xform = src_xform; A.stride = stride; A.ho = ho; A.wo = wo;
+    return 0;
+}
+
+extern "C" int slh_skinny(const slh_skinny_desc* d, slh_stream_t stream) {
+    SLH_CHECK(d && d->a0 && d->w && d->out, "slh_skinny: null pointer");
+    SLH_CHECK(d->M > 0 && d->R > 0 && d->R <= 16 && d->K > 0, "slh_skinny: bad shape");
+    SLH_CHECK(d->ca0 % 8 == 0 && d->ca1 % 8 == 0 && d->lda0 % 8 == 0 && d->lda1 % 8 == 0 && d->K % 8 == 0,
+              "slh_skinny: 16-byte alignment");
+    SLH_CHECK((d->a1 != nullptr) == (d->ca1 > 0), "slh_skinny: a1/ca1 mismatch");
+    const int cin = d->ca0 + d->ca1;
+    if (d->mode == 0) SLH_CHECK(cin == d->K, "slh_skinny: dense K mismatch");
+    else {
+        SLH_CHECK(d->mode == 1 && d->K == 9 * cin, "slh_skinny: conv K mismatch");
+        SLH_CHECK(d->M == d->batch * d->ho * d->wo, "slh_skinny: conv M mismatch");
+        SLH_CHECK(d->stride == 1 || d->stride == 2, "slh_skinny: stride");
+    }
+    if (d->out_kind == 1) SLH_CHECK(d->mode == 1, "slh_skinny: NCHW output needs conv geometry");
+    AddrArgs A;
+    fill_addr(A, d->a0, d->a1, d->lda0, d->lda1, d->ca0, d->ca1, d->mode, d->hs, d->ws, d->src_xform, d->stride,
+              d->ho, d->wo);
+    const int grid = (d->M + 15) / 16;
+    hipStream_t s = (hipStream_t)stream;
+    if (d->R <= 4)
+        hipLaunchKernelGGL(skinny_kernel<4>, dim3(grid), dim3(256), 0, s, A, (const __bf16*)d->w,
+                           (const __bf16*)d->bias, d->out, d->M, d->R, d->K, d->ldo, d->out_kind);
+    else if (d->R <= 12)
+        hipLaunchKernelGGL(skinny_kernel<12>, dim3(grid), dim3(256), 0, s, A, (const __bf16*)d->w,
+                           (const __bf16*)d->bias, d->out, d->M, d->R, d->K, d->ldo, d->out_kind);
+    else
+        hipLaunchKernelGGL(skinny_kernel<16>, dim3(grid), dim3(256), 0, s, A, (const __bf16*)d->w,
+                           (const __bf16*)d->bias, d->out, d->M, d->R, d->K, d->ldo, d->out_kind);
+    SLH_LAUNCH_CHECK("slh_skinny");
+    return 0;
+}
+
+extern "C" int slh_gemv(const slh_gemv_desc* d, slh_stream_t stream) {
+    SLH_CHECK(d && d->x && d->w && d->y, "slh_gemv: null pointer");
+    SLH_CHECK(d->nb >= 1 && d->nb <= 8 && d->N > 0 && d->K > 0 && d->K % 8 == 0 && d->ldx % 8 == 0,
+              "slh_gemv: bad shape nb=%d N=%d K=%d", d->nb, d->N, d->K);
+    if (d->lora_t) SLH_CHECK(d->lora_up && d->lora_scale, "slh_gemv: lora pointers");
+    hipLaunchKernelGGL(gemv_kernel, dim3((d->N + 3) / 4), dim3(256), 0, (hipStream_t)stream, *d);
+    SLH_LAUNCH_CHECK("slh_gemv");
+    return 0;
+}
+
+extern "C" int slh_lora_wgrad(const slh_wgrad_desc* d, slh_stream_t stream) {
+    SLH_CHECK(d && d->z0 && d->v && d->out && d->scale, "slh_lora_wgrad: null pointer");
+    SLH_CHECK(d->R == 4 || d->R == 12, "slh_lora_wgrad: R must be 4 or 12");
+    SLH_CHECK(d->c0 % 8 == 0 && d->c1 % 8 == 0 && d->ldz0 % 8 == 0 && d->ldz1 % 8 == 0, "slh_lora_wgrad: alignment");
+    SLH_CHECK((d->z1 != nullptr) == (d->c1 > 0), "slh_lora_wgrad: z1/c1 mismatch");
+    WgradArgs p;
+    fill_addr(p.A, d->z0, d->z1, d->ldz0, d->ldz1, d->c0, d->c1, d->mode, d->hs, d->ws, d->src_xform, d->stride,
+              d->ho, d->wo);
+    if (d->mode == 1) SLH_CHECK(d->M == d->batch * d->ho * d->wo, "slh_lora_wgrad: conv M mismatch");
+    p.v = d->v; p.out = d->out; p.scale = d->scale;
+    p.M = d->M; p.R = d->R; p.ldv = d->ldv; p.ldo = d->ldo;
+    p.rmajor = d->out_rmajor;
+    p.vgroup_cols = d->vgroup_cols;
+    const int C = d->c0 + d->c1;
+    const int gx = (C / 8 + 31) / 32;
+    int splits = (d->M + 1023) / 1024;
+    if (splits < 1) splits = 1;
+    p.rows_per_block = (d->M + splits - 1) / splits;
+    dim3 grid(gx, splits, d->mode == 1 ? 9 : 1);
+    hipStream_t s = (hipStream_t)stream;
+    if (d->R == 4) hipLaunchKernelGGL(wgrad_kernel<4>, grid, dim3(256), 0, s, p);
+    else hipLaunchKernelGGL(wgrad_kernel<12>, grid, dim3(256), 0, s, p);
+    SLH_LAUNCH_CHECK("slh_lora_wgrad");
+    return 0;
+}

@@ -1,0 +1,378 @@
+// GroupNorm(+SiLU) and LayerNorm, forward and backward-data, on pixel-major bf16 activations.  gfx950 only.
+// HBM-bound: 16 B per lane per access, fp32 statistics, wave-shuffle / LDS reductions.
+//
+// Reference semantics replaced (diffusers-0.20.2, called through train_util.py:159-163 / 242-247):
+//   ResnetBlock2D.norm1/norm2 + nonlinearity (GroupNorm(32, eps 1e-5) -> SiLU), Transformer2DModel.norm
+//   (GroupNorm(32, eps 1e-6)), conv_norm_out + conv_act, BasicTransformerBlock.norm1/2/3 (LayerNorm eps 1e-5),
+//   and their autograd backward (loss.backward(), train_lora_xl.py:345).
+#include "common.h"
+#include "../../include/sliders_hip.h"
+
+namespace {
+
+constexpr int GN_ITERS = 8;  // rows per thread per block
+
+struct GnGeom {
+    int C, nchunk, rpi, threads, rows_per_block, row_blocks, cg;
+};
+
+static GnGeom gn_geom(int c0, int c1, int hw, int groups) {
+    GnGeom g;
+    g.C = c0 + c1;
+    g.nchunk = g.C / 8;
+    g.rpi = g.nchunk >= 256 ? 1 : 256 / g.nchunk;
+    g.threads = g.nchunk * g.rpi;
+    g.rows_per_block = g.rpi * GN_ITERS;
+    g.row_blocks = (hw + g.rows_per_block - 1) / g.rows_per_block;
+    g.cg = g.C / groups;
+    return g;
+}
+
+__device__ __forceinline__ const __bf16* gn_src(const slh_gn_desc& d, long row, int c) {
+    return c < d.c0 ? (const __bf16*)d.x0 + row * d.ldx0 + c : (const __bf16*)d.x1 + row * d.ldx1 + (c - d.c0);
+}
+
+// accumulate 8 per-channel values into per-group LDS slots, merging runs of equal group first
+__device__ __forceinline__ void group_accumulate(float* lds2, int c, int cg, const float* s, const float* q) {
+    int gcur = c / cg;
+    float a = 0.f, b = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int g = (c + e) / cg;
+        if (g != gcur) {
+            atomicAdd(&lds2[gcur * 2], a);
+            atomicAdd(&lds2[gcur * 2 + 1], b);
+            gcur = g; a = 0.f; b = 0.f;
+        }
+        a += s[e]; b += q[e];
+    }
+    atomicAdd(&lds2[gcur * 2], a);
+    atomicAdd(&lds2[gcur * 2 + 1], b);
+}
+
+__global__ void gn_stats_kernel(const slh_gn_desc d, int nchunk, int rpi, int rows_per_block, int cg) {
+    __shared__ float lg[2 * 64];
+    const int tid = threadIdx.x;
+    for (int i = tid; i < 2 * d.groups; i += blockDim.x) lg[i] = 0.f;
+    __syncthreads();
+    const int chunk = tid % nchunk, rl = tid / nchunk;
+    const int c = chunk * 8;
+    const int b = blockIdx.y;
+    const int r0 = blockIdx.x * rows_per_block;
+    const int r1 = min(d.hw, r0 + rows_per_block);
+    float s[8], q[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { s[e] = 0.f; q[e] = 0.f; }
+    for (int r = r0 + rl; r < r1; r += rpi) {
+        const bf16x8 v = *(const bf16x8*)gn_src(d, (long)b * d.hw + r, c);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { const float f = (float)v[e]; s[e] += f; q[e] += f * f; }
+    }
+    group_accumulate(lg, c, cg, s, q);
+    __syncthreads();
+    for (int i = tid; i < 2 * d.groups; i += blockDim.x) atomicAdd(&d.stats[(long)b * d.groups * 2 + i], lg[i]);
+}
+
+__global__ void gn_apply_kernel(const slh_gn_desc d, int nchunk, int rpi, int rows_per_block, int cg) {
+    const int tid = threadIdx.x;
+    const int chunk = tid % nchunk, rl = tid / nchunk;
+    const int c = chunk * 8;
+    const int b = blockIdx.y;
+    const int r0 = blockIdx.x * rows_per_block;
+    const int r1 = min(d.hw, r0 + rows_per_block);
+    const float inv_n = 1.f / ((float)d.hw * (float)cg);
+    float a[8], sft[8];
+    const bf16x8 gm = *(const bf16x8*)((const __bf16*)d.gamma + c);
+    const bf16x8 bt = *(const bf16x8*)((const __bf16*)d.beta + c);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int g = (c + e) / cg;
+        const float mean = d.stats[((long)b * d.groups + g) * 2] * inv_n;
+        const float var = fmaxf(d.stats[((long)b * d.groups + g) * 2 + 1] * inv_n - mean * mean, 0.f);
+        const float rstd = rsqrtf(var + d.eps);
+        a[e] = rstd * (float)gm[e];
+        sft[e] = (float)bt[e] - mean * a[e];
+    }
+    for (int r = r0 + rl; r < r1; r += rpi) {
+        const long row = (long)b * d.hw + r;
+        const bf16x8 v = *(const bf16x8*)gn_src(d, row, c);
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float y = (float)v[e] * a[e] + sft[e];
+            if (d.act == 1) y = silu_f(round_bf16(y));  // reference rounds the GroupNorm output to bf16 before SiLU
+            o[e] = (__bf16)y;
+        }
+        *(bf16x8*)((__bf16*)d.y + row * d.ldy + c) = o;
+    }
+}
+
+// ---- backward -------------------------------------------------------------------------------------
+__device__ __forceinline__ const __bf16* gnb_src(const slh_gn_bwd_desc& d, long row, int c) {
+    return c < d.c0 ? (const __bf16*)d.x0 + row * d.ldx0 + c : (const __bf16*)d.x1 + row * d.ldx1 + (c - d.c0);
+}
+
+// dxhat[e] = dy * act'(z) * gamma, xhat[e]; z = xhat*gamma+beta
+__device__ __forceinline__ void gnb_elem(const slh_gn_bwd_desc& d, const bf16x8& xv, const bf16x8& dyv,
+                                         const float* mean, const float* rstd, const float* gm, const float* bt,
+                                         float* dxh, float* xh) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const float xhat = ((float)xv[e] - mean[e]) * rstd[e];
+        float g = (float)dyv[e];
+        if (d.act == 1) {
+            const float z = round_bf16(xhat * gm[e] + bt[e]);
+            const float sg = 1.f / (1.f + __expf(-z));
+            g *= sg * (1.f + z * (1.f - sg));
+        }
+        dxh[e] = g * gm[e];
+        xh[e] = xhat;
+    }
+}
+
+__global__ void gn_bwd_stats_kernel(const slh_gn_bwd_desc d, int nchunk, int rpi, int rows_per_block, int cg) {
+    __shared__ float lg[2 * 64];
+    const int tid = threadIdx.x;
+    for (int i = tid; i < 2 * d.groups; i += blockDim.x) lg[i] = 0.f;
+    __syncthreads();
+    const int chunk = tid % nchunk, rl = tid / nchunk;
+    const int c = chunk * 8;
+    const int b = blockIdx.y;
+    const int r0 = blockIdx.x * rows_per_block;
+    const int r1 = min(d.hw, r0 + rows_per_block);
+    const float inv_n = 1.f / ((float)d.hw * (float)cg);
+    float mean[8], rstd[8], gm[8], bt[8];
+    const bf16x8 gmv = *(const bf16x8*)((const __bf16*)d.gamma + c);
+    const bf16x8 btv = *(const bf16x8*)((const __bf16*)d.beta + c);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int g = (c + e) / cg;
+        mean[e] = d.stats[((long)b * d.groups + g) * 2] * inv_n;
+        const float var = fmaxf(d.stats[((long)b * d.groups + g) * 2 + 1] * inv_n - mean[e] * mean[e], 0.f);
+        rstd[e] = rsqrtf(var + d.eps);
+        gm[e] = (float)gmv[e]; bt[e] = (float)btv[e];
+    }
+    float s[8], q[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { s[e] = 0.f; q[e] = 0.f; }
+    for (int r = r0 + rl; r < r1; r += rpi) {
+        const long row = (long)b * d.hw + r;
+        const bf16x8 xv = *(const bf16x8*)gnb_src(d, row, c);
+        const bf16x8 dyv = *(const bf16x8*)((const __bf16*)d.dy + row * d.lddy + c);
+        float dxh[8], xh[8];
+        gnb_elem(d, xv, dyv, mean, rstd, gm, bt, dxh, xh);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { s[e] += dxh[e]; q[e] += dxh[e] * xh[e]; }
+    }
+    group_accumulate(lg, c, cg, s, q);
+    __syncthreads();
+    for (int i = tid; i < 2 * d.groups; i += blockDim.x) atomicAdd(&d.bstats[(long)b * d.groups * 2 + i], lg[i]);
+}
+
+__global__ void gn_bwd_apply_kernel(const slh_gn_bwd_desc d, int nchunk, int rpi, int rows_per_block, int cg) {
+    const int tid = threadIdx.x;
+    const int chunk = tid % nchunk, rl = tid / nchunk;
+    const int c = chunk * 8;
+    const int b = blockIdx.y;
+    const int r0 = blockIdx.x * rows_per_block;
+    const int r1 = min(d.hw, r0 + rows_per_block);
+    const float inv_n = 1.f / ((float)d.hw * (float)cg);
+    float mean[8], rstd[8], gm[8], bt[8], m1[8], m2[8];
+    const bf16x8 gmv = *(const bf16x8*)((const __bf16*)d.gamma + c);
+    const bf16x8 btv = *(const bf16x8*)((const __bf16*)d.beta + c);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int g = (c + e) / cg;
+        const long si = ((long)b * d.groups + g) * 2;
+        mean[e] = d.stats[si] * inv_n;
+        const float var = fmaxf(d.stats[si + 1] * inv_n - mean[e] * mean[e], 0.f);
+        rstd[e] = rsqrtf(var + d.eps);
+        gm[e] = (float)gmv[e]; bt[e] = (float)btv[e];
+        m1[e] = d.bstats[si] * inv_n;
+        m2[e] = d.bstats[si + 1] * inv_n;
+    }
+    const bool first = c < d.c0;
+    __bf16* dxb = first ? (__bf16*)d.dx0 : (__bf16*)d.dx1;
+    const int ldd = first ? d.lddx0 : d.lddx1;
+    const int cc = first ? c : c - d.c0;
+    const int accum = first ? d.accumulate0 : d.accumulate1;
+    if (!dxb) return;
+    for (int r = r0 + rl; r < r1; r += rpi) {
+        const long row = (long)b * d.hw + r;
+        const bf16x8 xv = *(const bf16x8*)gnb_src(d, row, c);
+        const bf16x8 dyv = *(const bf16x8*)((const __bf16*)d.dy + row * d.lddy + c);
+        float dxh[8], xh[8];
+        gnb_elem(d, xv, dyv, mean, rstd, gm, bt, dxh, xh);
+        __bf16* dst = dxb + row * ldd + cc;
+        bf16x8 o;
+        if (accum) o = *(const bf16x8*)dst;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float v = rstd[e] * (dxh[e] - m1[e] - xh[e] * m2[e]);
+            if (accum) v += (float)o[e];
+            o[e] = (__bf16)v;
+        }
+        *(bf16x8*)dst = o;
+    }
+}
+
+// ---- LayerNorm: one wave per row, up to 3 x 8 elements per lane (C <= 1536) -------------------------
+__global__ __launch_bounds__(256) void layernorm_kernel(const slh_ln_desc d) {
+    const int lane = threadIdx.x & 63;
+    const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (m >= d.M) return;
+    const __bf16* x = (const __bf16*)d.x + (long)m * d.ldx;
+    float v[3][8];
+    float sum = 0.f;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const int c = (lane + 64 * j) * 8;
+        if (c < d.C) {
+            const bf16x8 t = *(const bf16x8*)(x + c);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { v[j][e] = (float)t[e]; sum += v[j][e]; }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[j][e] = 0.f;
+        }
+    }
+    const float mean = wave_sum(sum) / (float)d.C;
+    float sq = 0.f;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const int c = (lane + 64 * j) * 8;
+        if (c < d.C) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { const float t = v[j][e] - mean; sq += t * t; }
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(sq) / (float)d.C + d.eps);
+    if (d.mean_rstd && lane == 0) { d.mean_rstd[(long)m * 2] = mean; d.mean_rstd[(long)m * 2 + 1] = rstd; }
+    __bf16* y = (__bf16*)d.y + (long)m * d.ldy;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const int c = (lane + 64 * j) * 8;
+        if (c < d.C) {
+            const bf16x8 g = *(const bf16x8*)((const __bf16*)d.gamma + c);
+            const bf16x8 bt = *(const bf16x8*)((const __bf16*)d.beta + c);
+            bf16x8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = (__bf16)((v[j][e] - mean) * rstd * (float)g[e] + (float)bt[e]);
+            *(bf16x8*)(y + c) = o;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const slh_ln_bwd_desc d) {
+    const int lane = threadIdx.x & 63;
+    const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (m >= d.M) return;
+    const __bf16* x = (const __bf16*)d.x + (long)m * d.ldx;
+    const __bf16* dy = (const __bf16*)d.dy + (long)m * d.lddy;
+    const float mean = d.mean_rstd[(long)m * 2], rstd = d.mean_rstd[(long)m * 2 + 1];
+    float xh[3][8], dyh[3][8];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const int c = (lane + 64 * j) * 8;
+        if (c < d.C) {
+            const bf16x8 xv = *(const bf16x8*)(x + c);
+            const bf16x8 gv = *(const bf16x8*)((const __bf16*)d.gamma + c);
+            const bf16x8 dv = *(const bf16x8*)(dy + c);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                xh[j][e] = ((float)xv[e] - mean) * rstd;
+                dyh[j][e] = (float)dv[e] * (float)gv[e];
+                s1 += dyh[j][e]; s2 += dyh[j][e] * xh[j][e];
+            }
+        }
+    }
+    const float m1 = wave_sum(s1) / (float)d.C, m2 = wave_sum(s2) / (float)d.C;
+    __bf16* dx = (__bf16*)d.dx + (long)m * d.lddx;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const int c = (lane + 64 * j) * 8;
+        if (c < d.C) {
+            bf16x8 o;
+            if (d.accumulate) o = *(const bf16x8*)(dx + c);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float v = rstd * (dyh[j][e] - m1 - xh[j][e] * m2);
+                if (d.accumulate) v += (float)o[e];
+                o[e] = (__bf16)v;
+            }
+            *(bf16x8*)(dx + c) = o;
+        }
+    }
+}
+
+}  // namespace
+
+static int gn_check(const char* who, int c0, int c1, int groups, int ldx0, int ldx1, const void* x1) {
+    const int C = c0 + c1;
+    SLH_CHECK(C > 0 && C % 8 == 0 && c0 % 8 == 0 && c1 % 8 == 0, "%s: channels must be multiples of 8", who);
+    SLH_CHECK(groups > 0 && groups <= 64 && C % groups == 0, "%s: bad group count", who);
+    SLH_CHECK(ldx0 % 8 == 0 && ldx1 % 8 == 0, "%s: leading dims must be multiples of 8", who);
+    SLH_CHECK((x1 != nullptr) == (c1 > 0), "%s: x1/c1 mismatch", who);
+    SLH_CHECK(C / 8 <= 1024, "%s: too many channels", who);
+    return 0;
+}
+
+extern "C" int slh_gn_stats(const slh_gn_desc* d, slh_stream_t stream) {
+    SLH_CHECK(d && d->x0 && d->stats, "slh_gn_stats: null pointer");
+    if (gn_check("slh_gn_stats", d->c0, d->c1, d->groups, d->ldx0, d->ldx1, d->x1)) return -1;
+    const GnGeom g = gn_geom(d->c0, d->c1, d->hw, d->groups);
+    hipLaunchKernelGGL(gn_stats_kernel, dim3(g.row_blocks, d->batch), dim3(g.threads), 0, (hipStream_t)stream, *d,
+                       g.nchunk, g.rpi, g.rows_per_block, g.cg);
+    SLH_LAUNCH_CHECK("slh_gn_stats");
+    return 0;
+}
+
+extern "C" int slh_gn_apply(const slh_gn_desc* d, slh_stream_t stream) {
+    SLH_CHECK(d && d->x0 && d->stats && d->y && d->gamma && d->beta, "slh_gn_apply: null pointer");
+    if (gn_check("slh_gn_apply", d->c0, d->c1, d->groups, d->ldx0, d->ldx1, d->x1)) return -1;
+    SLH_CHECK(d->ldy % 8 == 0, "slh_gn_apply: ldy");
+    const GnGeom g = gn_geom(d->c0, d->c1, d->hw, d->groups);
+    hipLaunchKernelGGL(gn_apply_kernel, dim3(g.row_blocks, d->batch), dim3(g.threads), 0, (hipStream_t)stream, *d,
+                       g.nchunk, g.rpi, g.rows_per_block, g.cg);
+    SLH_LAUNCH_CHECK("slh_gn_apply");
+    return 0;
+}
+
+extern "C" int slh_gn_bwd_stats(const slh_gn_bwd_desc* d, slh_stream_t stream) {
+    SLH_CHECK(d && d->x0 && d->stats && d->bstats && d->dy, "slh_gn_bwd_stats: null pointer");
+    if (gn_check("slh_gn_bwd_stats", d->c0, d->c1, d->groups, d->ldx0, d->ldx1, d->x1)) return -1;
+    const GnGeom g = gn_geom(d->c0, d->c1, d->hw, d->groups);
+    hipLaunchKernelGGL(gn_bwd_stats_kernel, dim3(g.row_blocks, d->batch), dim3(g.threads), 0, (hipStream_t)stream,
+                       *d, g.nchunk, g.rpi, g.rows_per_block, g.cg);
+    SLH_LAUNCH_CHECK("slh_gn_bwd_stats");
+    return 0;
+}
+
+extern "C" int slh_gn_bwd_apply(const slh_gn_bwd_desc* d, slh_stream_t stream) {
+    SLH_CHECK(d && d->x0 && d->stats && d->bstats && d->dy, "slh_gn_bwd_apply: null pointer");
+    if (gn_check("slh_gn_bwd_apply", d->c0, d->c1, d->groups, d->ldx0, d->ldx1, d->x1)) return -1;
+    SLH_CHECK(d->lddx0 % 8 == 0 && d->lddx1 % 8 == 0 && d->lddy % 8 == 0, "slh_gn_bwd_apply: leading dims");
+    const GnGeom g = gn_geom(d->c0, d->c1, d->hw, d->groups);
+    hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(g.row_blocks, d->batch), dim3(g.threads), 0, (hipStream_t)stream,
+                       *d, g.nchunk, g.rpi, g.rows_per_block, g.cg);
+    SLH_LAUNCH_CHECK("slh_gn_bwd_apply");
+    return 0;
+}
+
+extern "C" int slh_layernorm(const slh_ln_desc* d, slh_stream_t stream) {
+    SLH_CHECK(d && d->x && d->y && d->gamma && d->beta, "slh_layernorm: null pointer");
+    SLH_CHECK(d->C % 8 == 0 && d->C <= 1536 && d->ldx % 8 == 0 && d->ldy % 8 == 0, "slh_layernorm: C=%d unsupported", d->C);
+    hipLaunchKernelGGL(layernorm_kernel, dim3((d->M + 3) / 4), dim3(256), 0, (hipStream_t)stream, *d);
+    SLH_LAUNCH_CHECK("slh_layernorm");
+    return 0;
+}
+
+extern "C" int slh_layernorm_bwd(const slh_ln_bwd_desc* d, slh_stream_t stream) {
+    SLH_CHECK(d && d->x && d->dy && d->dx && d->gamma && d->mean_rstd, "slh_layernorm_bwd: null pointer");
+    SLH_CHECK(d->C % 8 == 0 && d->C <= 1536 && d->ldx % 8 == 0 && d->lddy % 8 == 0 && d->lddx % 8 == 0,
+              "slh_layernorm_bwd: C=%d unsupported", d->C);
+    hipLaunchKernelGGL(layernorm_bwd_kernel, dim3((d->M + 3) / 4), dim3(256), 0, (hipStream_t)stream, *d);
+    SLH_LAUNCH_CHECK("slh_layernorm_bwd");
+    return 0;
+}

@@ -1,0 +1,291 @@
+// Small HBM-bound operators around the UNet: timestep embedding, conv_in, elementwise helpers, CFG + DDIM
+// step, guidance loss, flat AdamW.  gfx950 only.  bf16 rounding points follow the reference's tensor ops so
+// that these kernels can be checked bit-for-bit against the oracle.
+#include "common.h"
+#include "../../include/sliders_hip.h"
+
+namespace {
+
+// ---- Timesteps(dim, flip_sin_to_cos=True, downscale_freq_shift=0): [cos | sin], fp32 math -------------
+__global__ void tembed_kernel(const slh_tembed_desc d) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int per = d.n_vals * d.dim;
+    if (idx >= d.nb * per) return;
+    const int b = idx / per;
+    const int rem = idx - b * per;
+    const int j = rem / d.dim;
+    const int i = rem - j * d.dim;
+    const int half = d.dim / 2;
+    const int fi = i < half ? i : i - half;
+    const float exponent = (-9.210340371976184f * (float)fi) / (float)half;  // -ln(10000) * i / half
+    const float arg = d.vals[b * d.n_vals + j] * expf(exponent);
+    const float v = i < half ? cosf(arg) : sinf(arg);
+    ((__bf16*)d.out)[(long)b * d.ldo + d.col0 + rem] = (__bf16)v;
+}
+
+// ---- conv_in: NCHW (B,cin,H,W) -> pixel-major [B*H*W][cout], 3x3 pad 1 --------------------------------
+__global__ __launch_bounds__(256) void conv_in_kernel(const slh_convin_desc d) {
+    const int nchunk = d.cout / 8;
+    const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long total = (long)d.batch * d.h * d.wd * nchunk;
+    if (gid >= total) return;
+    const int chunk = (int)(gid % nchunk);
+    const long pix = gid / nchunk;
+    const int hw = d.h * d.wd;
+    const int b = (int)(pix / hw);
+    const int rem = (int)(pix - (long)b * hw);
+    const int oy = rem / d.wd, ox = rem - oy * d.wd;
+    const __bf16* x = (const __bf16*)d.x + (long)b * d.cin * hw;
+    const __bf16* w = (const __bf16*)d.w + (long)chunk * 8 * 9 * d.cin;
+    float acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = d.bias ? (float)((const __bf16*)d.bias)[chunk * 8 + e] : 0.f;
+    for (int tap = 0; tap < 9; ++tap) {
+        const int iy = oy + tap / 3 - 1, ix = ox + tap % 3 - 1;
+        if (iy < 0 || iy >= d.h || ix < 0 || ix >= d.wd) continue;
+        for (int ci = 0; ci < d.cin; ++ci) {
+            const float xv = (float)x[(long)ci * hw + iy * d.wd + ix];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] += xv * (float)w[(long)e * 9 * d.cin + tap * d.cin + ci];
+        }
+    }
+    bf16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (__bf16)acc[e];
+    *(bf16x8*)((__bf16*)d.y + pix * d.ldy + chunk * 8) = o;
+}
+
+// ---- elementwise ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ew_kernel(const slh_ew_desc d) {
+    const int nchunk = d.C / 8;
+    const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= (long)d.M * nchunk) return;
+    const int chunk = (int)(gid % nchunk);
+    const long m = gid / nchunk;
+    const int c = chunk * 8;
+    const __bf16* A = (const __bf16*)d.a;
+    const __bf16* B = (const __bf16*)d.b;
+    __bf16* O = (__bf16*)d.out;
+    if (d.op == SLH_EW_COPY) {
+        *(bf16x8*)(O + m * d.ldo + c) = *(const bf16x8*)(A + m * d.lda + c);
+    } else if (d.op == SLH_EW_ADD) {
+        const bf16x8 x = *(const bf16x8*)(A + m * d.lda + c);
+        const bf16x8 y = *(const bf16x8*)(B + m * d.ldb + c);
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (__bf16)((float)x[e] + (float)y[e]);
+        *(bf16x8*)(O + m * d.ldo + c) = o;
+    } else if (d.op == SLH_EW_GEGLU_FWD || d.op == SLH_EW_GEGLU_BWD) {
+        // a = proj output [M][2C] in the blocked layout: 64-column blocks [32 values | 32 gates]
+        const int jb = c >> 5, j = c & 31;
+        const __bf16* pa = A + m * d.lda + jb * 64 + j;
+        const bf16x8 hv = *(const bf16x8*)pa;
+        const bf16x8 gv = *(const bf16x8*)(pa + 32);
+        if (d.op == SLH_EW_GEGLU_FWD) {
+            bf16x8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = (__bf16)((float)hv[e] * round_bf16(gelu_erf_f((float)gv[e])));
+            *(bf16x8*)(O + m * d.ldo + c) = o;
+        } else {
+            const bf16x8 dy = *(const bf16x8*)(B + m * d.ldb + c);
+            bf16x8 dh, dg;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float g = (float)gv[e], hh = (float)hv[e], dd = (float)dy[e];
+                const float cdf = 0.5f * (1.f + erff(g * 0.70710678118654752f));
+                const float pdf = 0.3989422804014327f * __expf(-0.5f * g * g);
+                dh[e] = (__bf16)(dd * round_bf16(g * cdf));
+                dg[e] = (__bf16)(round_bf16(dd * hh) * (cdf + g * pdf));
+            }
+            __bf16* po = O + m * d.ldo + jb * 64 + j;
+            *(bf16x8*)po = dh;
+            *(bf16x8*)(po + 32) = dg;
+        }
+    } else if (d.op == SLH_EW_UPSAMPLE_BWD) {
+        // out pixel (b, y, x) of an h x w image (w = d.iarg, hw = d.iarg2) sums the 2x2 block of a
+        const int w = d.iarg, hw = d.iarg2;
+        const long b = m / hw;
+        const int rem = (int)(m - b * hw);
+        const int y = rem / w, x = rem - y * w;
+        const long base = (b * 4 * hw + (long)(2 * y) * (2 * w) + 2 * x);
+        float acc[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const long row = base + (q >> 1) * (2 * w) + (q & 1);
+            const bf16x8 v = *(const bf16x8*)(A + row * d.lda + c);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] += (float)v[e];
+        }
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (__bf16)acc[e];
+        *(bf16x8*)(O + m * d.ldo + c) = o;
+    }
+}
+
+// per-sample column sums: out[b][c] (fp32, +=) = sum over the sample's rows of a[row][c]
+__global__ __launch_bounds__(256) void colsum_kernel(const slh_ew_desc d) {
+    __shared__ float red[8][33][8];
+    const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;
+    const int c = (blockIdx.x * 32 + cx) * 8;
+    const int hw = d.iarg2;            // rows per sample
+    const int b = blockIdx.z;
+    const int r0 = blockIdx.y * 512, r1 = min(hw, r0 + 512);
+    float acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+    if (c < d.C) {
+        for (int r = r0 + ry; r < r1; r += 8) {
+            const bf16x8 v = *(const bf16x8*)((const __bf16*)d.a + ((long)b * hw + r) * d.lda + c);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] += (float)v[e];
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) red[ry][cx][e] = acc[e];
+    __syncthreads();
+    {
+        const int ccx = threadIdx.x >> 3, e = threadIdx.x & 7;
+        const int cc = (blockIdx.x * 32 + ccx) * 8 + e;
+        if (cc < d.C) {
+            float t = 0.f;
+#pragma unroll
+            for (int y = 0; y < 8; ++y) t += red[y][ccx][e];
+            atomicAdd((float*)d.out + (long)b * d.ldo + cc, t);
+        }
+    }
+}
+
+// ---- CFG combine + DDIM step ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void cfg_ddim_kernel(const slh_cfg_ddim_desc d) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long n = (long)d.nb * d.chw;
+    if (i >= n) return;
+    const __bf16* eps = (const __bf16*)d.eps;
+    const float u = (float)eps[i], t = (float)eps[n + i];
+    // train_util.py:166-169: uncond + g * (text - uncond), every tensor op rounds to bf16
+    const float diff = round_bf16(t - u);
+    const float scaled = round_bf16(d.guidance * diff);
+    const float e = round_bf16(u + scaled);
+    if (!d.do_step) { ((__bf16*)d.out)[i] = (__bf16)e; return; }
+    const float x = (float)((const __bf16*)d.x)[i];
+    // DDIMScheduler.step, eta = 0, epsilon prediction, fp32 0-dim scalars times bf16 tensors
+    const float r1 = round_bf16(d.c_sqrt_beta_t * e);
+    const float r2 = round_bf16(x - r1);
+    const float x0 = round_bf16(r2 / d.c_sqrt_alpha_t);
+    const float dir = round_bf16(d.c_dir * e);
+    const float r3 = round_bf16(d.c_sqrt_alpha_prev * x0);
+    ((__bf16*)d.out)[i] = (__bf16)(r3 + dir);
+}
+
+// ---- guidance loss (prompt_util.py:108-148) --------------------------------------------------------------
+__global__ __launch_bounds__(256) void loss_kernel(const slh_loss_desc d) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    float sq = 0.f;
+    if (i < d.n) {
+        const float tg = (float)((const __bf16*)d.target)[i];
+        const float po = (float)((const __bf16*)d.positive)[i];
+        const float ne = (float)((const __bf16*)d.neutral)[i];
+        const float un = (float)((const __bf16*)d.uncond)[i];
+        const float d1 = round_bf16(po - un);
+        const float d2 = round_bf16(d.guidance * d1);
+        const float y = round_bf16(d.erase ? ne - d2 : ne + d2);
+        const float diff = tg - y;
+        sq = diff * diff;
+        if (d.dtarget) ((__bf16*)d.dtarget)[i] = (__bf16)((2.0f / (float)d.n) * diff);
+    }
+    sq = wave_sum(sq);
+    __shared__ float part[4];
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = sq;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(d.loss, (part[0] + part[1] + part[2] + part[3]) / (float)d.n);
+}
+
+// ---- AdamW over the flat LoRA buffer: torch.optim.AdamW single-tensor op order, bf16 state ------------
+__global__ __launch_bounds__(256) void adamw_kernel(const slh_adamw_desc d, float decay, float bc2_sqrt,
+                                                    float step_size, float w1, float beta2, float w2, float eps) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= d.n) return;
+    __bf16* P = (__bf16*)d.param; __bf16* M1 = (__bf16*)d.exp_avg; __bf16* M2 = (__bf16*)d.exp_avg_sq;
+    const float g = round_bf16(d.grad[i] * d.grad_scale);     // param.grad is bf16 in the reference
+    float p = round_bf16((float)P[i] * decay);                  // param.mul_(1 - lr * wd)
+    float m = (float)M1[i];
+    m = round_bf16(m + w1 * (g - m));                           // exp_avg.lerp_(grad, 1 - beta1)
+    float v = round_bf16((float)M2[i] * beta2);                 // exp_avg_sq.mul_(beta2)
+    v = round_bf16(v + w2 * (g * g));                           // .addcmul_(grad, grad, value = 1 - beta2)
+    float den = round_bf16(sqrtf(v));                           // exp_avg_sq.sqrt()
+    den = round_bf16(den / bc2_sqrt);                           //   / bias_correction2_sqrt
+    den = round_bf16(den + eps);                                //   .add_(eps)
+    p = round_bf16(p + (-step_size) * (m / den));               // param.addcdiv_(exp_avg, denom, value = -step_size)
+    P[i] = (__bf16)p; M1[i] = (__bf16)m; M2[i] = (__bf16)v;
+}
+
+}  // namespace
+
+extern "C" int slh_timestep_embed(const slh_tembed_desc* d, slh_stream_t stream) {
+    SLH_CHECK(d && d->vals && d->out && d->dim % 2 == 0 && d->nb > 0 && d->n_vals > 0, "slh_timestep_embed: bad desc");
+    const int total = d->nb * d->n_vals * d->dim;
+    hipLaunchKernelGGL(tembed_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, *d);
+    SLH_LAUNCH_CHECK("slh_timestep_embed");
+    return 0;
+}
+
+extern "C" int slh_conv_in(const slh_convin_desc* d, slh_stream_t stream) {
+    SLH_CHECK(d && d->x && d->w && d->y, "slh_conv_in: null pointer");
+    SLH_CHECK(d->cout % 8 == 0 && d->ldy % 8 == 0 && d->cin > 0 && d->cin <= 16, "slh_conv_in: bad shape");
+    const long total = (long)d->batch * d->h * d->wd * (d->cout / 8);
+    hipLaunchKernelGGL(conv_in_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, *d);
+    SLH_LAUNCH_CHECK("slh_conv_in");
+    return 0;
+}
+
+extern "C" int slh_elementwise(const slh_ew_desc* d, slh_stream_t stream) {
+    SLH_CHECK(d && d->a && d->out, "slh_elementwise: null pointer");
+    SLH_CHECK(d->C % 8 == 0 && d->lda % 8 == 0 && d->ldo % 4 == 0, "slh_elementwise: alignment");
+    hipStream_t s = (hipStream_t)stream;
+    if (d->op == SLH_EW_COLSUM) {
+        SLH_CHECK(d->iarg2 > 0 && d->M % d->iarg2 == 0, "slh_elementwise: colsum rows per sample");
+        dim3 grid((d->C / 8 + 31) / 32, (d->iarg2 + 511) / 512, d->M / d->iarg2);
+        hipLaunchKernelGGL(colsum_kernel, grid, dim3(256), 0, s, *d);
+    } else {
+        if (d->op == SLH_EW_ADD || d->op == SLH_EW_GEGLU_BWD) SLH_CHECK(d->b && d->ldb % 8 == 0, "slh_elementwise: operand b");
+        if (d->op == SLH_EW_GEGLU_FWD || d->op == SLH_EW_GEGLU_BWD) SLH_CHECK(d->C % 32 == 0, "slh_elementwise: geglu C");
+        if (d->op == SLH_EW_UPSAMPLE_BWD) SLH_CHECK(d->iarg > 0 && d->iarg2 > 0, "slh_elementwise: upsample dims");
+        const long total = (long)d->M * (d->C / 8);
+        hipLaunchKernelGGL(ew_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, *d);
+    }
+    SLH_LAUNCH_CHECK("slh_elementwise");
+    return 0;
+}
+
+extern "C" int slh_cfg_ddim(const slh_cfg_ddim_desc* d, slh_stream_t stream) {
+    SLH_CHECK(d && d->eps && d->out && (d->x || !d->do_step), "slh_cfg_ddim: null pointer");
+    const long n = (long)d->nb * d->chw;
+    hipLaunchKernelGGL(cfg_ddim_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, *d);
+    SLH_LAUNCH_CHECK("slh_cfg_ddim");
+    return 0;
+}
+
+extern "C" int slh_guidance_loss(const slh_loss_desc* d, slh_stream_t stream) {
+    SLH_CHECK(d && d->target && d->positive && d->neutral && d->uncond && d->loss, "slh_guidance_loss: null pointer");
+    hipLaunchKernelGGL(loss_kernel, dim3((d->n + 255) / 256), dim3(256), 0, (hipStream_t)stream, *d);
+    SLH_LAUNCH_CHECK("slh_guidance_loss");
+    return 0;
+}
+
+extern "C" int slh_adamw(const slh_adamw_desc* d, slh_stream_t stream) {
+    SLH_CHECK(d && d->param && d->exp_avg && d->exp_avg_sq && d->grad && d->step >= 1, "slh_adamw: bad desc");
+    // scalar prep in double like torch's python-side math, then cast to the fp32 opmath type
+    const double bc1 = 1.0 - pow(d->beta1, (double)d->step);
+    const double bc2 = 1.0 - pow(d->beta2, (double)d->step);
+    const float step_size = (float)(d->lr / bc1);
+    const float bc2_sqrt = (float)sqrt(bc2);
+    const float decay = (float)(1.0 - d->lr * d->weight_decay);
+    hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)((d->n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, *d,
+                       decay, bc2_sqrt, step_size, (float)(1.0 - d->beta1), (float)d->beta2, (float)(1.0 - d->beta2),
+                       (float)d->eps);
+    SLH_LAUNCH_CHECK("slh_adamw");
+    return 0;
+}

@@ -1,0 +1,93 @@
+// Command-buffer executor: the host planner (sliders_amd/plan.py) flattens one UNet forward / backward /
+// optimizer step into a byte buffer of {opcode, nbytes, descriptor} records; this walks it and launches every
+// kernel on the caller's stream with no per-op host<->Python round trip (the reference pays one Python
+// dispatch per torch op: ~1.2k per UNet forward).  The launches are plain stream work, so the
+// caller may also capture a whole program into a hipGraph.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string.h>
+#include "../../include/sliders_hip.h"
+
+void slh_set_error(const char* fmt, ...);
+
+namespace {
+template <typename T>
+inline int run_desc(const unsigned char* p, int32_t nbytes, int (*fn)(const T*, slh_stream_t), slh_stream_t s,
+                    const char* name) {
+    if (nbytes != (int32_t)sizeof(T)) {
+        slh_set_error("slh_run_program: %s descriptor is %d bytes, library expects %d", name, nbytes, (int)sizeof(T));
+        return -3;
+    }
+    T d;
+    memcpy(&d, p, sizeof(T));
+    return fn(&d, s);
+}
+}  // namespace
+
+extern "C" int slh_run_program(const void* program, int64_t nbytes, slh_stream_t stream) {
+    const unsigned char* p = (const unsigned char*)program;
+    const unsigned char* end = p + nbytes;
+    int idx = 0;
+    while (p < end) {
+        if (end - p < 8) { slh_set_error("slh_run_program: truncated record header at op %d", idx); return -3; }
+        int32_t hdr[2];
+        memcpy(hdr, p, 8);
+        p += 8;
+        const int32_t op = hdr[0], sz = hdr[1];
+        if (sz < 0 || end - p < sz) { slh_set_error("slh_run_program: truncated record at op %d", idx); return -3; }
+        int rc = 0;
+        switch (op) {
+            case SLH_OP_GEMM: rc = run_desc<slh_gemm_desc>(p, sz, slh_gemm, stream, "gemm"); break;
+            case SLH_OP_SKINNY: rc = run_desc<slh_skinny_desc>(p, sz, slh_skinny, stream, "skinny"); break;
+            case SLH_OP_GEMV: rc = run_desc<slh_gemv_desc>(p, sz, slh_gemv, stream, "gemv"); break;
+            case SLH_OP_GN_STATS: rc = run_desc<slh_gn_desc>(p, sz, slh_gn_stats, stream, "gn_stats"); break;
+            case SLH_OP_GN_APPLY: rc = run_desc<slh_gn_desc>(p, sz, slh_gn_apply, stream, "gn_apply"); break;
+            case SLH_OP_LAYERNORM: rc = run_desc<slh_ln_desc>(p, sz, slh_layernorm, stream, "layernorm"); break;
+            case SLH_OP_ATTN_FWD: rc = run_desc<slh_attn_desc>(p, sz, slh_attn_fwd, stream, "attn_fwd"); break;
+            case SLH_OP_TRANSPOSE_HEADS:
+                rc = run_desc<slh_transpose_desc>(p, sz, slh_transpose_heads, stream, "transpose_heads"); break;
+            case SLH_OP_TEMBED: rc = run_desc<slh_tembed_desc>(p, sz, slh_timestep_embed, stream, "tembed"); break;
+            case SLH_OP_CONV_IN: rc = run_desc<slh_convin_desc>(p, sz, slh_conv_in, stream, "conv_in"); break;
+            case SLH_OP_ELEMENTWISE: rc = run_desc<slh_ew_desc>(p, sz, slh_elementwise, stream, "elementwise"); break;
+            case SLH_OP_CFG_DDIM: rc = run_desc<slh_cfg_ddim_desc>(p, sz, slh_cfg_ddim, stream, "cfg_ddim"); break;
+            case SLH_OP_LOSS: rc = run_desc<slh_loss_desc>(p, sz, slh_guidance_loss, stream, "loss"); break;
+            case SLH_OP_WGRAD: rc = run_desc<slh_wgrad_desc>(p, sz, slh_lora_wgrad, stream, "wgrad"); break;
+            case SLH_OP_ADAMW: rc = run_desc<slh_adamw_desc>(p, sz, slh_adamw, stream, "adamw"); break;
+            case SLH_OP_GN_BWD_STATS:
+                rc = run_desc<slh_gn_bwd_desc>(p, sz, slh_gn_bwd_stats, stream, "gn_bwd_stats"); break;
+            case SLH_OP_GN_BWD_APPLY:
+                rc = run_desc<slh_gn_bwd_desc>(p, sz, slh_gn_bwd_apply, stream, "gn_bwd_apply"); break;
+            case SLH_OP_LAYERNORM_BWD:
+                rc = run_desc<slh_ln_bwd_desc>(p, sz, slh_layernorm_bwd, stream, "layernorm_bwd"); break;
+            case SLH_OP_ATTN_BWD: rc = run_desc<slh_attn_bwd_desc>(p, sz, slh_attn_bwd, stream, "attn_bwd"); break;
+            case SLH_OP_MEMSET: {
+                if (sz != (int32_t)sizeof(slh_memset_desc)) { slh_set_error("slh_run_program: memset desc size"); return -3; }
+                slh_memset_desc d;
+                memcpy(&d, p, sizeof(d));
+                hipError_t e = hipMemsetAsync(d.ptr, d.value, (size_t)d.nbytes, (hipStream_t)stream);
+                if (e != hipSuccess) { slh_set_error("slh_run_program: memset failed: %s", hipGetErrorString(e)); rc = -2; }
+                break;
+            }
+            default:
+                slh_set_error("slh_run_program: unknown opcode %d at op %d", op, idx);
+                return -3;
+        }
+        if (rc != 0) return rc;
+        p += (sz + 7) & ~7;
+        ++idx;
+    }
+    return 0;
+}
+
+extern "C" int slh_desc_sizes(int32_t* out, int32_t cap) {
+    const int32_t sizes[] = {
+        (int32_t)sizeof(slh_gemm_desc),     (int32_t)sizeof(slh_skinny_desc),   (int32_t)sizeof(slh_gemv_desc),
+        (int32_t)sizeof(slh_gn_desc),       (int32_t)sizeof(slh_gn_bwd_desc),   (int32_t)sizeof(slh_ln_desc),
+        (int32_t)sizeof(slh_ln_bwd_desc),   (int32_t)sizeof(slh_attn_desc),     (int32_t)sizeof(slh_transpose_desc),
+        (int32_t)sizeof(slh_attn_bwd_desc), (int32_t)sizeof(slh_tembed_desc),   (int32_t)sizeof(slh_convin_desc),
+        (int32_t)sizeof(slh_ew_desc),       (int32_t)sizeof(slh_cfg_ddim_desc), (int32_t)sizeof(slh_loss_desc),
+        (int32_t)sizeof(slh_wgrad_desc),    (int32_t)sizeof(slh_adamw_desc),    (int32_t)sizeof(slh_memset_desc)};
+    const int n = (int)(sizeof(sizes) / sizeof(sizes[0]));
+    for (int i = 0; i < n && i < cap; ++i) out[i] = sizes[i];
+    return n;
+}

@@ -1,0 +1,188 @@
+"""ctypes binding of libsliders_hip.so (include/sliders_hip.h).
+
+The product path has NO fallback: if the shared library is missing or a descriptor size disagrees
+with the header the import of this module raises, and every op raises RuntimeError with the
+library's slh_last_error() text on a non-zero status.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsliders_hip.so")
+
+c_i32, c_i64, c_f32, c_f64, c_vp = C.c_int32, C.c_int64, C.c_float, C.c_double, C.c_void_p
+
+
+def _struct(name, fields):
+    return type(name, (C.Structure,), {"_fields_": fields})
+
+
+def _ptrs(*names):
+    return [(n, c_vp) for n in names]
+
+
+def _ints(*names):
+    return [(n, c_i32) for n in names]
+
+
+GemmDesc = _struct("GemmDesc", _ptrs("a0", "a1", "w", "bias", "rowbias", "lora_t", "lora_up", "lora_scale",
+                                     "residual", "c")
+                   + _ints("lda0", "lda1", "ca0", "ca1", "mode", "batch", "hs", "ws", "src_xform", "stride",
+                           "ho", "wo", "ldw", "M", "N", "K", "ld_rowbias", "rows_per_sample", "ld_t",
+                           "lora_groups", "ld_res", "ldc", "geglu", "tile"))
+SkinnyDesc = _struct("SkinnyDesc", _ptrs("a0", "a1", "w", "bias", "out")
+                     + _ints("lda0", "lda1", "ca0", "ca1", "mode", "batch", "hs", "ws", "src_xform", "stride",
+                             "ho", "wo", "M", "R", "K", "ldo", "out_kind"))
+GemvDesc = _struct("GemvDesc", _ptrs("x", "w", "bias", "addend", "lora_t", "lora_tcol", "lora_up", "lora_scale", "y")
+                   + _ints("nb", "N", "K", "ldx", "ld_add", "ld_t", "ldy", "in_act", "out_f32"))
+GnDesc = _struct("GnDesc", _ptrs("x0", "x1", "gamma", "beta", "stats", "y")
+                 + _ints("ldx0", "ldx1", "c0", "c1", "batch", "hw", "groups", "ldy") + [("eps", c_f32)]
+                 + _ints("act"))
+GnBwdDesc = _struct("GnBwdDesc", _ptrs("x0", "x1", "gamma", "beta", "stats", "bstats", "dy", "dx0", "dx1")
+                    + _ints("ldx0", "ldx1", "c0", "c1", "batch", "hw", "groups", "lddy", "lddx0", "lddx1")
+                    + [("eps", c_f32)] + _ints("act", "accumulate0", "accumulate1"))
+LnDesc = _struct("LnDesc", _ptrs("x", "gamma", "beta", "y", "mean_rstd") + _ints("M", "C", "ldx", "ldy")
+                 + [("eps", c_f32)])
+LnBwdDesc = _struct("LnBwdDesc", _ptrs("x", "gamma", "dy", "mean_rstd", "dx")
+                    + _ints("M", "C", "ldx", "lddy", "lddx", "accumulate"))
+AttnDesc = _struct("AttnDesc", _ptrs("q", "k", "vt", "o", "lse")
+                   + _ints("B", "H", "Tq", "Tk", "ldq", "ldk", "ldvt", "ldo") + [("scale", c_f32)])
+TransposeDesc = _struct("TransposeDesc", _ptrs("src", "dst") + _ints("B", "H", "T", "ld", "ldt"))
+AttnBwdDesc = _struct("AttnBwdDesc", _ptrs("q", "k", "v", "o", "d_o", "lse", "dq", "dk", "dv", "delta")
+                      + _ints("B", "H", "Tq", "Tk", "ldq", "ldk", "ldv", "ldo", "lddo", "lddq", "lddk", "lddv")
+                      + [("scale", c_f32)] + _ints("need_dkv"))
+TembedDesc = _struct("TembedDesc", _ptrs("vals", "out") + _ints("nb", "n_vals", "dim", "ldo", "col0"))
+ConvInDesc = _struct("ConvInDesc", _ptrs("x", "w", "bias", "y") + _ints("batch", "cin", "h", "wd", "cout", "ldy"))
+EwDesc = _struct("EwDesc", _ptrs("a", "b", "out") + _ints("M", "C", "lda", "ldb", "ldo", "op", "iarg", "iarg2")
+                 + [("alpha", c_f32)] + _ints("pad_"))
+CfgDdimDesc = _struct("CfgDdimDesc", _ptrs("eps", "x", "out") + _ints("nb", "chw")
+                      + [("guidance", c_f32), ("c_sqrt_beta_t", c_f32), ("c_sqrt_alpha_t", c_f32),
+                         ("c_sqrt_alpha_prev", c_f32), ("c_dir", c_f32)] + _ints("do_step"))
+LossDesc = _struct("LossDesc", _ptrs("target", "positive", "neutral", "uncond", "loss", "dtarget")
+                   + _ints("n") + [("guidance", c_f32)] + _ints("erase"))
+WgradDesc = _struct("WgradDesc", _ptrs("z0", "z1", "v", "out", "scale")
+                    + _ints("ldz0", "ldz1", "c0", "c1", "mode", "batch", "hs", "ws", "src_xform", "stride", "ho",
+                            "wo", "M", "R", "ldv", "ldo", "out_rmajor", "vgroup_cols"))
+AdamwDesc = _struct("AdamwDesc", _ptrs("param", "exp_avg", "exp_avg_sq", "grad") + [("n", c_i64)]
+                    + [(n, c_f64) for n in ("lr", "beta1", "beta2", "eps", "weight_decay")]
+                    + _ints("step") + [("grad_scale", c_f32)])
+MemsetDesc = _struct("MemsetDesc", _ptrs("ptr") + [("nbytes", c_i64)] + _ints("value", "pad"))
+
+# order of slh_desc_sizes()
+_SIZE_ORDER = [GemmDesc, SkinnyDesc, GemvDesc, GnDesc, GnBwdDesc, LnDesc, LnBwdDesc, AttnDesc, TransposeDesc,
+               AttnBwdDesc, TembedDesc, ConvInDesc, EwDesc, CfgDdimDesc, LossDesc, WgradDesc, AdamwDesc, MemsetDesc]
+
+# opcodes (enum in sliders_hip.h)
+OP_GEMM, OP_SKINNY, OP_GEMV, OP_GN_STATS, OP_GN_APPLY, OP_LAYERNORM, OP_ATTN_FWD, OP_TRANSPOSE_HEADS = range(1, 9)
+OP_TEMBED, OP_CONV_IN, OP_ELEMENTWISE, OP_CFG_DDIM, OP_LOSS, OP_WGRAD, OP_ADAMW = range(9, 16)
+OP_GN_BWD_STATS, OP_GN_BWD_APPLY, OP_LAYERNORM_BWD, OP_ATTN_BWD, OP_MEMSET = range(16, 21)
+
+EW_COPY, EW_ADD, EW_GEGLU_FWD, EW_GEGLU_BWD, EW_UPSAMPLE_BWD, EW_COLSUM = range(6)
+
+# C entry point per opcode, for direct (non-program) calls
+_ENTRY = {
+    OP_GEMM: ("slh_gemm", GemmDesc), OP_SKINNY: ("slh_skinny", SkinnyDesc), OP_GEMV: ("slh_gemv", GemvDesc),
+    OP_GN_STATS: ("slh_gn_stats", GnDesc), OP_GN_APPLY: ("slh_gn_apply", GnDesc),
+    OP_LAYERNORM: ("slh_layernorm", LnDesc), OP_ATTN_FWD: ("slh_attn_fwd", AttnDesc),
+    OP_TRANSPOSE_HEADS: ("slh_transpose_heads", TransposeDesc), OP_TEMBED: ("slh_timestep_embed", TembedDesc),
+    OP_CONV_IN: ("slh_conv_in", ConvInDesc), OP_ELEMENTWISE: ("slh_elementwise", EwDesc),
+    OP_CFG_DDIM: ("slh_cfg_ddim", CfgDdimDesc), OP_LOSS: ("slh_guidance_loss", LossDesc),
+    OP_WGRAD: ("slh_lora_wgrad", WgradDesc), OP_ADAMW: ("slh_adamw", AdamwDesc),
+    OP_GN_BWD_STATS: ("slh_gn_bwd_stats", GnBwdDesc), OP_GN_BWD_APPLY: ("slh_gn_bwd_apply", GnBwdDesc),
+    OP_LAYERNORM_BWD: ("slh_layernorm_bwd", LnBwdDesc), OP_ATTN_BWD: ("slh_attn_bwd", AttnBwdDesc),
+}
+
+EXPORTS = ["slh_version", "slh_last_error", "slh_run_program", "slh_desc_sizes"] + [v[0] for v in _ENTRY.values()]
+
+
+class SlidersHipError(RuntimeError):
+    pass
+
+
+_lib: Optional[C.CDLL] = None
+
+
+def load() -> C.CDLL:
+    """Load libsliders_hip.so; raises if it has not been built (python -c 'import __graft_entry__ as g; g.build()')."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise SlidersHipError(
+            f"{LIB_PATH} not found: the HIP extension is not built. There is no CPU fallback; run "
+            f"`make -C {os.path.join(_HERE, 'csrc')}` (or __graft_entry__.build()).")
+    lib = C.CDLL(LIB_PATH)
+    lib.slh_last_error.restype = C.c_char_p
+    lib.slh_run_program.argtypes = [c_vp, c_i64, c_vp]
+    lib.slh_run_program.restype = c_i32
+    lib.slh_desc_sizes.argtypes = [C.POINTER(c_i32), c_i32]
+    for name, desc in _ENTRY.values():
+        fn = getattr(lib, name)
+        fn.argtypes = [C.POINTER(desc), c_vp]
+        fn.restype = c_i32
+    sizes = (c_i32 * 32)()
+    n = lib.slh_desc_sizes(sizes, 32)
+    if n != len(_SIZE_ORDER):
+        raise SlidersHipError(f"binding/library mismatch: library reports {n} descriptors, binding has {len(_SIZE_ORDER)}")
+    for i, d in enumerate(_SIZE_ORDER):
+        if C.sizeof(d) != sizes[i]:
+            raise SlidersHipError(f"binding/library mismatch: sizeof({d.__name__}) = {C.sizeof(d)} vs {sizes[i]}")
+    _lib = lib
+    return lib
+
+
+def last_error() -> str:
+    return load().slh_last_error().decode()
+
+
+def check(rc: int, what: str = ""):
+    if rc != 0:
+        raise SlidersHipError(f"{what} failed (rc={rc}): {last_error()}")
+
+
+def call(opcode: int, desc, stream: int):
+    """Launch one op directly (used by the per-kernel parity tests)."""
+    lib = load()
+    name, _ = _ENTRY[opcode]
+    check(getattr(lib, name)(C.byref(desc), c_vp(stream)), name)
+
+
+class Program:
+    """Flat command buffer replayed by slh_run_program with one C call."""
+
+    def __init__(self):
+        self._chunks = []
+        self.n_ops = 0
+        self._buf = None
+        self.op_names = []
+
+    def add(self, opcode: int, desc, name: str = ""):
+        raw = bytes(desc)
+        pad = (-len(raw)) % 8
+        hdr = C.c_int32 * 2
+        self._chunks.append(bytes(hdr(opcode, len(raw))) + raw + b"\0" * pad)
+        self.n_ops += 1
+        self.op_names.append(name)
+        self._buf = None
+
+    def memset(self, ptr: int, nbytes: int, value: int = 0, name: str = "memset"):
+        self.add(OP_MEMSET, MemsetDesc(ptr=ptr, nbytes=nbytes, value=value, pad=0), name)
+
+    def extend(self, other: "Program"):
+        self._chunks.extend(other._chunks)
+        self.n_ops += other.n_ops
+        self.op_names.extend(other.op_names)
+        self._buf = None
+
+    def finalize(self):
+        if self._buf is None:
+            data = b"".join(self._chunks)
+            self._buf = C.create_string_buffer(data, len(data))
+        return self._buf
+
+    def run(self, stream: int):
+        buf = self.finalize()
+        check(load().slh_run_program(C.cast(buf, c_vp), len(buf), c_vp(stream)), "slh_run_program")

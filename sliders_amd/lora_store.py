@@ -1,0 +1,229 @@
+"""Packed storage of the LoRA adapter parameters (the only trainable state of the hot path).
+
+Reference: `LoRAModule` keeps `lora_down` / `lora_up` as separate nn.Linear / nn.Conv2d per target
+(trainscripts/textsliders/lora.py:55-101), 346 modules = 692 tiny bf16 tensors for SDXL.  Here all of them
+live in ONE flat bf16 buffer (plus one flat fp32 gradient buffer and two flat bf16 AdamW moment buffers), so
+the optimizer step is one launch and the data-parallel exchange is one RCCL all-reduce of one buffer.
+
+Kernel-side layouts inside the flat buffer
+  down, Linear : [r][in]                 (= lora_down.weight)
+  down, Conv3x3: [r][tap][Cin]           (lora_down.weight (r,Cin,3,3) permuted; implicit-GEMM K order)
+  up           : [out][r]                (= lora_up.weight, conv (out,r,1,1) flattened)
+Modules that the planner fuses into one GEMM are adjacent: attn1 (to_q,to_k,to_v) downs form [3r][C] and
+their ups [3C][r]; attn2 (to_k,to_v) likewise; every ResnetBlock2D.time_emb_proj down/up is concatenated
+into one [r*L][temb] / [sum(Cout)][r] pair (one GEMV per UNet pass).
+
+`state_dict()` / `load_state_dict()` convert to / from the reference checkpoint layout (key names and shapes
+of lora.py:231-248) so files are interchangeable with the reference's inference notebooks.
+"""
+from __future__ import annotations
+
+import math
+from collections import OrderedDict
+from dataclasses import dataclass
+from typing import Dict, List, Optional
+
+import torch
+import torch.nn as nn
+
+from .config import UNetConfig
+from .modules import LoraTarget, lora_targets
+
+
+@dataclass
+class LoraEntry:
+    target: LoraTarget
+    down_off: int = -1
+    up_off: int = -1
+    trainable: bool = True
+
+    @property
+    def name(self) -> str:
+        return self.target.lora_name
+
+    @property
+    def k_dim(self) -> int:  # contraction length of the down projection
+        t = self.target
+        return t.in_dim * (9 if t.kind == "conv3" else 1)
+
+    @property
+    def down_numel(self) -> int:
+        return self.target.rank * self.k_dim
+
+    @property
+    def up_numel(self) -> int:
+        return self.target.out_dim * self.target.rank
+
+
+class LoraStore:
+    def __init__(self, cfg: UNetConfig, rank: int = 4, alpha: float = 1.0, train_method: str = "noxattn",
+                 network_type: str = "c3lier", device="cpu", init: str = "reference", kaiming_a: float = 1.0):
+        self.cfg = cfg
+        self.rank = rank
+        self.alpha = rank if alpha is None or alpha == 0 else alpha
+        self.train_method = train_method
+        self.device = device
+        targets = lora_targets(cfg, train_method, rank, network_type)
+        for t in targets:
+            if t.rank != rank:
+                raise NotImplementedError(f"{t.lora_name}: rank clipped to {t.rank}; uniform rank required")
+        self.entries: List[LoraEntry] = [LoraEntry(t) for t in targets]
+        self.by_path: Dict[str, LoraEntry] = {e.target.module_path: e for e in self.entries}
+        self.by_name: Dict[str, LoraEntry] = {e.name: e for e in self.entries}
+        self.scale = self.alpha / self.rank
+        self._layout()
+        n = self.numel
+        self.params = torch.zeros(n, dtype=torch.bfloat16, device=device)
+        self.grads = torch.zeros(n, dtype=torch.float32, device=device)
+        self.exp_avg = torch.zeros(n, dtype=torch.bfloat16, device=device)
+        self.exp_avg_sq = torch.zeros(n, dtype=torch.bfloat16, device=device)
+        self.opt_step = 0
+        if init == "reference":
+            self.init_reference(kaiming_a)
+
+    # ---- layout -------------------------------------------------------------------------------------
+    def _layout(self):
+        off = 0
+        placed = set()
+        self.temb_entries: List[LoraEntry] = [e for e in self.entries if e.target.module_path.endswith("time_emb_proj")]
+        by_path = self.by_path
+
+        def place_group(group: List[LoraEntry]):
+            nonlocal off
+            for e in group:  # downs first (contiguous), then ups
+                e.down_off = off
+                off += e.down_numel
+            for e in group:
+                e.up_off = off
+                off += e.up_numel
+            for e in group:
+                placed.add(e.name)
+
+        for e in self.entries:
+            if e.name in placed or e in self.temb_entries:
+                continue
+            p = e.target.module_path
+            if p.endswith(".to_q") and ".attn1." in p + ".":
+                base = p[: -len(".to_q")]
+                grp = [by_path.get(base + s) for s in (".to_q", ".to_k", ".to_v")]
+                if all(g is not None for g in grp):
+                    place_group(grp)
+                    continue
+            if p.endswith(".to_k") and ".attn2." in p + ".":
+                base = p[: -len(".to_k")]
+                grp = [by_path.get(base + s) for s in (".to_k", ".to_v")]
+                if all(g is not None for g in grp):
+                    place_group(grp)
+                    continue
+            place_group([e])
+        # all time_emb_proj adapters: one contiguous [r*L][temb] down block and one [sum Cout][r] up block
+        self.temb_down_off = off
+        for e in self.temb_entries:
+            e.down_off = off
+            off += e.down_numel
+        self.temb_up_off = off
+        for e in self.temb_entries:
+            e.up_off = off
+            off += e.up_numel
+        # keep every block 16-byte aligned: all numels are multiples of 8 bf16 here (rank 4 * dims % 2 == 0)
+        for e in self.entries:
+            assert e.down_off % 8 == 0 and e.up_off % 4 == 0, e.name
+        self.numel = off
+
+    def fused_group(self, paths: List[str]) -> Optional[List[LoraEntry]]:
+        """Entries for `paths` if they are all adapted AND stored adjacently (downs then ups), else None."""
+        grp = [self.by_path.get(p) for p in paths]
+        if any(g is None for g in grp):
+            return None
+        for a, b in zip(grp, grp[1:]):
+            if b.down_off != a.down_off + a.down_numel or b.up_off != a.up_off + a.up_numel:
+                return None
+        return grp
+
+    # ---- pointers ------------------------------------------------------------------------------------
+    def down_ptr(self, e: LoraEntry) -> int:
+        return self.params.data_ptr() + 2 * e.down_off
+
+    def up_ptr(self, e: LoraEntry) -> int:
+        return self.params.data_ptr() + 2 * e.up_off
+
+    def gdown_ptr(self, e: LoraEntry) -> int:
+        return self.grads.data_ptr() + 4 * e.down_off
+
+    def gup_ptr(self, e: LoraEntry) -> int:
+        return self.grads.data_ptr() + 4 * e.up_off
+
+    # ---- init / (de)serialisation ------------------------------------------------------------------
+    def _down_to_kernel(self, e: LoraEntry, w: torch.Tensor) -> torch.Tensor:
+        if e.target.kind == "conv3":
+            return w.permute(0, 2, 3, 1).reshape(-1)
+        return w.reshape(-1)
+
+    def _down_from_kernel(self, e: LoraEntry, flat: torch.Tensor) -> torch.Tensor:
+        t = e.target
+        if t.kind == "conv3":
+            return flat.view(t.rank, 3, 3, t.in_dim).permute(0, 3, 1, 2).contiguous()
+        if t.kind == "conv1":
+            return flat.view(t.rank, t.in_dim, 1, 1).contiguous()
+        return flat.view(t.rank, t.in_dim).contiguous()
+
+    def _up_shape(self, e: LoraEntry):
+        t = e.target
+        return (t.out_dim, t.rank) if t.kind == "linear" else (t.out_dim, t.rank, 1, 1)
+
+    def init_reference(self, kaiming_a: float = 1.0):
+        """Same RNG draws, in the same order, as LoRAModule.__init__ (lora.py:68-97) so that
+        torch.manual_seed(s) gives the reference's initial adapter weights: the nn.Linear / nn.Conv2d
+        constructors draw their default init first, then kaiming_uniform_(down, a=1) and zeros_(up)."""
+        host = torch.zeros(self.numel, dtype=torch.float32)
+        for e in self.entries:
+            t = e.target
+            if t.kind == "linear":
+                down = nn.Linear(t.in_dim, t.rank, bias=False)
+                up = nn.Linear(t.rank, t.out_dim, bias=False)
+            else:
+                k = 3 if t.kind == "conv3" else 1
+                down = nn.Conv2d(t.in_dim, t.rank, (k, k), (t.stride, t.stride), (k // 2, k // 2), bias=False)
+                up = nn.Conv2d(t.rank, t.out_dim, (1, 1), (1, 1), bias=False)
+            nn.init.kaiming_uniform_(down.weight, a=kaiming_a)
+            nn.init.zeros_(up.weight)
+            host[e.down_off:e.down_off + e.down_numel] = self._down_to_kernel(e, down.weight.detach())
+        self.params.copy_(host.to(torch.bfloat16))
+
+    def state_dict(self, dtype: Optional[torch.dtype] = None) -> "OrderedDict[str, torch.Tensor]":
+        """Reference key order per module: `<name>.alpha`, `<name>.lora_down.weight`, `<name>.lora_up.weight`."""
+        host = self.params.detach().to("cpu")
+        sd = OrderedDict()
+        for e in self.entries:
+            if not e.trainable:
+                continue
+            down = self._down_from_kernel(e, host[e.down_off:e.down_off + e.down_numel].clone())
+            up = host[e.up_off:e.up_off + e.up_numel].clone().view(self._up_shape(e))
+            alpha = torch.tensor(self.alpha)
+            if dtype is not None:
+                down, up, alpha = down.to(dtype), up.to(dtype), alpha.to(dtype)
+            sd[f"{e.name}.alpha"] = alpha
+            sd[f"{e.name}.lora_down.weight"] = down
+            sd[f"{e.name}.lora_up.weight"] = up
+        return sd
+
+    def load_state_dict(self, sd: Dict[str, torch.Tensor], strict: bool = True):
+        host = self.params.detach().to("cpu").to(torch.float32)
+        seen = set()
+        for e in self.entries:
+            kd, ku = f"{e.name}.lora_down.weight", f"{e.name}.lora_up.weight"
+            if kd not in sd or ku not in sd:
+                if strict:
+                    raise KeyError(f"missing key(s) for {e.name}")
+                continue
+            host[e.down_off:e.down_off + e.down_numel] = self._down_to_kernel(e, sd[kd].to(torch.float32))
+            host[e.up_off:e.up_off + e.up_numel] = sd[ku].to(torch.float32).reshape(-1)
+            seen.update((kd, ku, f"{e.name}.alpha"))
+        if strict:
+            extra = set(sd.keys()) - seen
+            if extra:
+                raise KeyError(f"unexpected key(s): {sorted(extra)[:4]} ...")
+        self.params.copy_(host.to(torch.bfloat16))
+
+    def n_trainable(self) -> int:
+        return sum(e.down_numel + e.up_numel for e in self.entries if e.trainable)

@@ -1,0 +1,410 @@
+"""Static planner: turns one UNet2DConditionModel forward (and, for the training pass, its backward through
+the frozen net into the LoRA adapters) into a flat command buffer for libsliders_hip.so.
+
+Op order follows diffusers-0.20.2 UNet2DConditionModel.forward as called by the reference at
+trainscripts/textsliders/train_util.py:159-163 / 242-247, re-expressed on pixel-major
+activations [B*H*W][C]:
+  * every Linear / 1x1 conv / 3x3 conv is slh_gemm (implicit GEMM for 3x3, channel concat and nearest-2x
+    upsample folded into the A-operand addressing),
+  * the LoRA branch of lora.py:108-112 is slh_skinny (down) + a rank-4 epilogue term (up) - skipped entirely
+    when the adapters are switched off (multiplier 0 adds an exact 0 in the reference),
+  * q/k/v (and cross k/v) projections are fused into one GEMM, all time_emb_proj layers into one GEMV.
+Modes: "off" (LoRA disabled), "on" (LoRA enabled, no grad), "train" (LoRA enabled, activations kept, GEGLU
+unfused so its pre-activation is available; `build_backward()` then emits the backward program).
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Tuple, Union
+
+import torch
+
+from . import lib
+from .arena import Arena, Buf
+from .config import UNetConfig
+from .lora_store import LoraEntry, LoraStore
+from .weights import WeightStore
+
+
+@dataclass
+class Act:
+    """Pixel-major activation view: rows = B*H*W pixels, C channels, row stride ld (elements)."""
+    ptr: int
+    B: int
+    H: int
+    W: int
+    C: int
+    ld: int
+    buf: Optional[Buf] = None
+    name: str = ""
+
+    @property
+    def HW(self) -> int:
+        return self.H * self.W
+
+    @property
+    def M(self) -> int:
+        return self.B * self.H * self.W
+
+    def cols(self, c0: int, c: int) -> "Act":
+        return Act(self.ptr + 2 * c0, self.B, self.H, self.W, c, self.ld, self.buf, self.name + f"[:,{c0}:{c0 + c}]")
+
+    def sample(self, b: int, nb: int = 1) -> "Act":
+        return Act(self.ptr + 2 * b * self.HW * self.ld, nb, self.H, self.W, self.C, self.ld, self.buf,
+                   self.name + f"[b{b}]")
+
+    def tensor(self) -> torch.Tensor:
+        """Debug view (real arenas only): [M][C] strided tensor."""
+        base = self.buf.tensor.view(-1)
+        off = (self.ptr - self.buf.ptr) // 2
+        return base.as_strided((self.M, self.C), (self.ld, 1), off)
+
+
+Src = Union[Act, Tuple[Act, Act]]
+
+
+def _src_parts(x: Src):
+    if isinstance(x, tuple):
+        return x[0], x[1]
+    return x, None
+
+
+class UNetPlan:
+    def __init__(self, cfg: UNetConfig, weights: WeightStore, arena: Arena, zarena: Arena, B: int, H: int, W: int,
+                 ctx_len: int = 77, lora: Optional[LoraStore] = None, mode: str = "off",
+                 lora_scale_ptr: int = 0, io: Optional[dict] = None):
+        assert mode in ("off", "on", "train")
+        assert mode == "off" or lora is not None
+        self.cfg, self.w, self.arena, self.zarena = cfg, weights, arena, zarena
+        self.B, self.H, self.W, self.ctx_len = B, H, W, ctx_len
+        self.lora = lora if mode != "off" else None
+        self.mode = mode
+        self.train = mode == "train"
+        self.lora_scale_ptr = lora_scale_ptr
+        self.prog = lib.Program()
+        self.tape: List[dict] = []
+        self.zmark = zarena.mark()
+        self._build_io(io)
+        self._forward()
+        self.zend = zarena.mark()
+        # zero the fp32 accumulators (GroupNorm statistics ...) used by this program first
+        head = lib.Program()
+        if self.zend > self.zmark:
+            p, n = zarena.region(self.zmark, self.zend)
+            head.memset(p, n, 0, "zero_stats")
+        head.extend(self.prog)
+        self.prog = head
+
+    # ------------------------------------------------------------------------------------------------
+    # buffers
+    # ------------------------------------------------------------------------------------------------
+    def _build_io(self, io):
+        cfg, B = self.cfg, self.B
+        if io is not None:
+            self.io = io
+            return
+        a = self.arena
+        self.io = {
+            "sample": a.alloc((B, cfg.in_channels, self.H, self.W), torch.bfloat16, "in.sample"),
+            "t": a.alloc((B, 1), torch.float32, "in.t"),
+            "ctx": a.alloc((B, self.ctx_len, cfg.cross_attention_dim), torch.bfloat16, "in.ctx"),
+            "eps": a.alloc((B, cfg.out_channels, self.H, self.W), torch.bfloat16, "out.eps"),
+        }
+        if cfg.is_xl:
+            self.io["time_ids"] = a.alloc((B, 6), torch.float32, "in.time_ids")
+            self.io["add_in"] = a.alloc((B, cfg.projection_class_embeddings_input_dim), torch.bfloat16, "in.add_in")
+
+    def act(self, B, H, W, C, name="") -> Act:
+        buf = self.arena.alloc((B * H * W, C), torch.bfloat16, name)
+        return Act(buf.ptr, B, H, W, C, C, buf, name)
+
+    def f32(self, shape, name="", zero=False) -> Buf:
+        return (self.zarena if zero else self.arena).alloc(shape, torch.float32, name)
+
+    # ------------------------------------------------------------------------------------------------
+    # op emitters
+    # ------------------------------------------------------------------------------------------------
+    def _lora_group(self, paths: List[str]) -> Optional[List[LoraEntry]]:
+        if self.lora is None:
+            return None
+        return self.lora.fused_group(paths)
+
+    def _conv_fields(self, d, src: Act, conv: dict, Ho: int, Wo: int):
+        d.mode = 1
+        d.batch, d.hs, d.ws = src.B, src.H, src.W
+        d.src_xform = conv.get("xform", 0)
+        d.stride = conv.get("stride", 1)
+        d.ho, d.wo = Ho, Wo
+
+    def skinny(self, x: Src, w_ptr: int, R: int, K: int, conv: Optional[dict], Mout: int, Ho: int, Wo: int,
+               name: str, out: Optional[Buf] = None, bias_ptr: int = 0, out_kind: int = 0) -> Buf:
+        x0, x1 = _src_parts(x)
+        if out is None:
+            out = self.f32((Mout, R), name + ".T")
+        d = lib.SkinnyDesc(a0=x0.ptr, a1=x1.ptr if x1 else 0, w=w_ptr, bias=bias_ptr, out=out.ptr,
+                           lda0=x0.ld, lda1=x1.ld if x1 else 0, ca0=x0.C, ca1=x1.C if x1 else 0,
+                           M=Mout, R=R, K=K, ldo=R, out_kind=out_kind)
+        if conv is not None:
+            self._conv_fields(d, x0, conv, Ho, Wo)
+        else:
+            d.stride = 1
+        self.prog.add(lib.OP_SKINNY, d, name)
+        return out
+
+    def gemm(self, x: Src, wname: str, N: int, name: str, bias: bool = True, conv: Optional[dict] = None,
+             rowbias: Optional[Tuple[int, int]] = None, residual: Optional[Act] = None,
+             lora_paths: Optional[List[str]] = None, geglu: bool = False, out: Optional[Act] = None,
+             w_ptr: Optional[int] = None, bias_ptr: Optional[int] = None) -> Act:
+        """y = x . W^T (+bias)(+rowbias per sample)(+LoRA)(+residual).  conv: {'stride','xform'} for 3x3."""
+        x0, x1 = _src_parts(x)
+        cin = x0.C + (x1.C if x1 else 0)
+        B = x0.B
+        if conv is not None:
+            sh = 1 if conv.get("xform", 0) else 0
+            HL, WL = x0.H << sh, x0.W << sh
+            st = conv.get("stride", 1)
+            Ho, Wo = (HL - 1) // st + 1, (WL - 1) // st + 1   # 3x3, pad 1
+            K = 9 * cin
+        else:
+            Ho, Wo, K = x0.H, x0.W, cin
+        M = B * Ho * Wo
+        Nout = N // 2 if geglu else N
+        if out is None:
+            out = self.act(B, Ho, Wo, Nout, name)
+        grp = self._lora_group(lora_paths) if lora_paths else None
+        T = None
+        if grp is not None:
+            R = sum(e.target.rank for e in grp)
+            T = self.skinny(x, self.lora.down_ptr(grp[0]), R, K, conv, M, Ho, Wo, name + ".lora_down")
+        d = lib.GemmDesc(a0=x0.ptr, a1=x1.ptr if x1 else 0,
+                         w=w_ptr if w_ptr is not None else self.w.ptr(wname + ".w"),
+                         bias=(bias_ptr if bias_ptr is not None else (self.w.ptr(wname + ".b") if bias else 0)),
+                         rowbias=rowbias[0] if rowbias else 0,
+                         lora_t=T.ptr if T else 0, lora_up=self.lora.up_ptr(grp[0]) if grp else 0,
+                         lora_scale=self.lora_scale_ptr if grp else 0,
+                         residual=residual.ptr if residual else 0, c=out.ptr,
+                         lda0=x0.ld, lda1=x1.ld if x1 else 0, ca0=x0.C, ca1=x1.C if x1 else 0,
+                         mode=0, stride=1, ldw=K, M=M, N=N, K=K,
+                         ld_rowbias=rowbias[1] if rowbias else 0, rows_per_sample=Ho * Wo,
+                         ld_t=(4 * len(grp)) if grp else 0, lora_groups=len(grp) if grp else 0,
+                         ld_res=residual.ld if residual else 0, ldc=out.ld, geglu=1 if geglu else 0, tile=0)
+        if conv is not None:
+            self._conv_fields(d, x0, conv, Ho, Wo)
+        self.prog.add(lib.OP_GEMM, d, name)
+        if self.train:
+            self.tape.append(dict(op="gemm", x=x, out=out, wname=wname, N=N, K=K, conv=conv, grp=grp, T=T,
+                                  residual=residual, rowbias=rowbias, name=name, Ho=Ho, Wo=Wo))
+        return out
+
+    def groupnorm(self, x: Src, wname: str, eps: float, act: int, name: str) -> Act:
+        x0, x1 = _src_parts(x)
+        C = x0.C + (x1.C if x1 else 0)
+        B, H, W = x0.B, x0.H, x0.W
+        G = self.cfg.norm_num_groups
+        stats = self.f32((B, G, 2), name + ".stats", zero=True)
+        y = self.act(B, H, W, C, name)
+        d = lib.GnDesc(x0=x0.ptr, x1=x1.ptr if x1 else 0, gamma=self.w.ptr(wname + ".g"), beta=self.w.ptr(wname + ".b"),
+                       stats=stats.ptr, y=y.ptr, ldx0=x0.ld, ldx1=x1.ld if x1 else 0, c0=x0.C, c1=x1.C if x1 else 0,
+                       batch=B, hw=H * W, groups=G, ldy=y.ld, eps=eps, act=act)
+        self.prog.add(lib.OP_GN_STATS, d, name + ".stats")
+        self.prog.add(lib.OP_GN_APPLY, d, name + ".apply")
+        if self.train:
+            self.tape.append(dict(op="gn", x=x, out=y, wname=wname, eps=eps, act=act, stats=stats, name=name))
+        return y
+
+    def layernorm(self, x: Act, wname: str, name: str) -> Act:
+        y = self.act(x.B, x.H, x.W, x.C, name)
+        mr = self.f32((x.M, 2), name + ".mean_rstd") if self.train else None
+        d = lib.LnDesc(x=x.ptr, gamma=self.w.ptr(wname + ".g"), beta=self.w.ptr(wname + ".b"), y=y.ptr,
+                       mean_rstd=mr.ptr if mr else 0, M=x.M, C=x.C, ldx=x.ld, ldy=y.ld, eps=1e-5)
+        self.prog.add(lib.OP_LAYERNORM, d, name)
+        if self.train:
+            self.tape.append(dict(op="ln", x=x, out=y, wname=wname, mr=mr, name=name))
+        return y
+
+    def attention(self, q: Act, k: Act, v: Act, Tk: int, heads: int, name: str) -> Act:
+        """q [B*Tq][C] view, k/v [B*Tk][C] views (any ld); returns [B*Tq][C]."""
+        B, Tq, C = q.B, q.HW, q.C
+        assert C == heads * 64, "only head_dim 64 is implemented"
+        ldt = (Tk + 63) // 64 * 64
+        vt = self.arena.alloc((B, heads, 64, ldt), torch.bfloat16, name + ".vt")
+        self.prog.add(lib.OP_TRANSPOSE_HEADS, lib.TransposeDesc(src=v.ptr, dst=vt.ptr, B=B, H=heads, T=Tk, ld=v.ld, ldt=ldt),
+                      name + ".vt")
+        o = self.act(q.B, q.H, q.W, C, name)
+        lse = self.f32((B, heads, Tq), name + ".lse") if self.train else None
+        d = lib.AttnDesc(q=q.ptr, k=k.ptr, vt=vt.ptr, o=o.ptr, lse=lse.ptr if lse else 0, B=B, H=heads, Tq=Tq, Tk=Tk,
+                         ldq=q.ld, ldk=k.ld, ldvt=ldt, ldo=o.ld, scale=64 ** -0.5)
+        self.prog.add(lib.OP_ATTN_FWD, d, name)
+        if self.train:
+            self.tape.append(dict(op="attn", q=q, k=k, v=v, o=o, lse=lse, Tk=Tk, heads=heads, name=name))
+        return o
+
+    # ------------------------------------------------------------------------------------------------
+    # network pieces
+    # ------------------------------------------------------------------------------------------------
+    def _embeddings(self):
+        cfg, B, w = self.cfg, self.B, self.w
+        ted = cfg.time_embed_dim
+        c0 = cfg.block_out_channels[0]
+        a = self.arena
+        t_in = a.alloc((B, c0), torch.bfloat16, "temb.sin")
+        self.prog.add(lib.OP_TEMBED, lib.TembedDesc(vals=self.io["t"].ptr, out=t_in.ptr, nb=B, n_vals=1, dim=c0,
+                                                    ldo=c0, col0=0), "time_proj")
+        h1 = a.alloc((B, ted), torch.bfloat16, "temb.h1")
+        self._gemv(t_in.ptr, c0, "time_embedding.linear_1", ted, c0, h1.ptr, ted, 0, name="time_embedding.linear_1")
+        emb = a.alloc((B, ted), torch.bfloat16, "temb.emb")
+        self._gemv(h1.ptr, ted, "time_embedding.linear_2", ted, ted, emb.ptr, ted, 1, name="time_embedding.linear_2")
+        if cfg.is_xl:
+            add_in = self.io["add_in"]
+            pin = cfg.projection_class_embeddings_input_dim
+            self.prog.add(lib.OP_TEMBED, lib.TembedDesc(vals=self.io["time_ids"].ptr, out=add_in.ptr, nb=B, n_vals=6,
+                                                        dim=cfg.addition_time_embed_dim, ldo=pin,
+                                                        col0=cfg.pooled_dim), "add_time_proj")
+            g1 = a.alloc((B, ted), torch.bfloat16, "aemb.h1")
+            self._gemv(add_in.ptr, pin, "add_embedding.linear_1", ted, pin, g1.ptr, ted, 0, name="add_embedding.linear_1")
+            emb2 = a.alloc((B, ted), torch.bfloat16, "temb.emb_sum")
+            self._gemv(g1.ptr, ted, "add_embedding.linear_2", ted, ted, emb2.ptr, ted, 1, addend=(emb.ptr, ted),
+                       name="add_embedding.linear_2")
+            emb = emb2
+        self.emb = emb
+        # every ResnetBlock2D.time_emb_proj(silu(emb)) in one launch
+        tot = w.temb_total
+        self.temb_all = a.alloc((B, tot), torch.bfloat16, "temb.proj_all")
+        lt = None
+        if self.lora is not None and self.lora.temb_entries:
+            L = len(self.lora.temb_entries)
+            if L != len(w.resnet_paths):
+                raise NotImplementedError("time_emb_proj adapters must cover every resnet or none")
+            lt = self.f32((B, 4 * L), "temb.lora_T")
+            d = lib.GemvDesc(x=emb.ptr, w=self.lora.params.data_ptr() + 2 * self.lora.temb_down_off, y=lt.ptr,
+                             nb=B, N=4 * L, K=ted, ldx=ted, ldy=4 * L, in_act=1, out_f32=1)
+            self.prog.add(lib.OP_GEMV, d, "temb.lora_down")
+            if not hasattr(self.lora, "temb_tcol"):
+                tcol = torch.empty(tot, dtype=torch.int32)
+                for i, p in enumerate(w.resnet_paths):
+                    e = self.lora.temb_entries[i]
+                    assert e.target.module_path == p + ".time_emb_proj"
+                    o = w.temb_offsets[p]
+                    tcol[o:o + e.target.out_dim] = 4 * i
+                self.lora.temb_tcol = tcol.to(self.lora.params.device)
+        d = lib.GemvDesc(x=emb.ptr, w=w.ptr("temb_proj.w"), bias=w.ptr("temb_proj.b"), y=self.temb_all.ptr,
+                         nb=B, N=tot, K=ted, ldx=ted, ldy=tot, in_act=1, out_f32=0)
+        if lt is not None:
+            d.lora_t = lt.ptr
+            d.ld_t = lt.shape[1]
+            d.lora_tcol = self.lora.temb_tcol.data_ptr()
+            d.lora_up = self.lora.params.data_ptr() + 2 * self.lora.temb_up_off
+            d.lora_scale = self.lora_scale_ptr
+        self.prog.add(lib.OP_GEMV, d, "time_emb_proj_all")
+        self.temb_lora_T = lt
+
+    def _gemv(self, x_ptr, ldx, wname, N, K, y_ptr, ldy, in_act, addend=None, name=""):
+        d = lib.GemvDesc(x=x_ptr, w=self.w.ptr(wname + ".w"), bias=self.w.ptr(wname + ".b"), y=y_ptr,
+                         addend=addend[0] if addend else 0, ld_add=addend[1] if addend else 0,
+                         nb=self.B, N=N, K=K, ldx=ldx, ldy=ldy, in_act=in_act, out_f32=0)
+        self.prog.add(lib.OP_GEMV, d, name)
+
+    def _resnet(self, x: Src, path: str, cout: int) -> Act:
+        x0, x1 = _src_parts(x)
+        cin = x0.C + (x1.C if x1 else 0)
+        eps = self.cfg.norm_eps
+        a1 = self.groupnorm(x, path + ".norm1", eps, 1, path + ".norm1")
+        rb = (self.temb_all.ptr + 2 * self.w.temb_offsets[path], self.w.temb_total)
+        h = self.gemm(a1, path + ".conv1", cout, path + ".conv1", conv={}, rowbias=rb, lora_paths=[path + ".conv1"])
+        if self.train:
+            self.tape[-1]["temb_path"] = path
+        a2 = self.groupnorm(h, path + ".norm2", eps, 1, path + ".norm2")
+        if cin != cout:
+            sc = self.gemm(x, path + ".conv_shortcut", cout, path + ".conv_shortcut",
+                           lora_paths=[path + ".conv_shortcut"])
+        else:
+            assert x1 is None
+            sc = x0
+        return self.gemm(a2, path + ".conv2", cout, path + ".conv2", conv={}, residual=sc,
+                         lora_paths=[path + ".conv2"])
+
+    def _tblock(self, h: Act, path: str, heads: int, ctx: Act) -> Act:
+        C = h.C
+        a1, a2 = path + ".attn1", path + ".attn2"
+        n1 = self.layernorm(h, path + ".norm1", path + ".norm1")
+        qkv = self.gemm(n1, a1 + ".qkv", 3 * C, a1 + ".qkv", bias=False,
+                        lora_paths=[a1 + ".to_q", a1 + ".to_k", a1 + ".to_v"])
+        T = h.HW
+        o1 = self.attention(qkv.cols(0, C), qkv.cols(C, C), qkv.cols(2 * C, C), T, heads, a1 + ".sdpa")
+        h1 = self.gemm(o1, a1 + ".out", C, a1 + ".out", residual=h, lora_paths=[a1 + ".to_out.0"])
+        n2 = self.layernorm(h1, path + ".norm2", path + ".norm2")
+        q2 = self.gemm(n2, a2 + ".q", C, a2 + ".q", bias=False, lora_paths=[a2 + ".to_q"])
+        kv = self.gemm(ctx, a2 + ".kv", 2 * C, a2 + ".kv", bias=False, lora_paths=[a2 + ".to_k", a2 + ".to_v"])
+        o2 = self.attention(q2, kv.cols(0, C), kv.cols(C, C), self.ctx_len, heads, a2 + ".sdpa")
+        h2 = self.gemm(o2, a2 + ".out", C, a2 + ".out", residual=h1, lora_paths=[a2 + ".to_out.0"])
+        n3 = self.layernorm(h2, path + ".norm3", path + ".norm3")
+        if self.train:
+            pre = self.gemm(n3, path + ".ff1", 8 * C, path + ".ff1", lora_paths=[path + ".ff.net.0.proj"])
+            ff = self.act(h.B, h.H, h.W, 4 * C, path + ".geglu")
+            self.prog.add(lib.OP_ELEMENTWISE, lib.EwDesc(a=pre.ptr, out=ff.ptr, M=pre.M, C=4 * C, lda=pre.ld, ldo=ff.ld,
+                                                         op=lib.EW_GEGLU_FWD), path + ".geglu")
+            self.tape.append(dict(op="geglu", pre=pre, out=ff, name=path + ".geglu"))
+        else:
+            grp = self._lora_group([path + ".ff.net.0.proj"])
+            if grp is not None:
+                raise NotImplementedError("LoRA on GEGLU.proj is not a reference target")
+            ff = self.gemm(n3, path + ".ff1", 8 * C, path + ".ff1", geglu=True)
+        return self.gemm(ff, path + ".ff2", C, path + ".ff2", residual=h2, lora_paths=[path + ".ff.net.2"])
+
+    def _transformer(self, x: Act, path: str, layers: int, heads: int) -> Act:
+        g = self.groupnorm(x, path + ".norm", 1e-6, 0, path + ".norm")
+        h = self.gemm(g, path + ".proj_in", x.C, path + ".proj_in", lora_paths=[path + ".proj_in"])
+        for k in range(layers):
+            h = self._tblock(h, f"{path}.transformer_blocks.{k}", heads, self.ctx)
+        return self.gemm(h, path + ".proj_out", x.C, path + ".proj_out", residual=x, lora_paths=[path + ".proj_out"])
+
+    def _forward(self):
+        cfg, B, H, W = self.cfg, self.B, self.H, self.W
+        boc = cfg.block_out_channels
+        self._embeddings()
+        ctxb = self.io["ctx"]
+        self.ctx = Act(ctxb.ptr, B, 1, self.ctx_len, cfg.cross_attention_dim, cfg.cross_attention_dim, ctxb, "ctx")
+        h = self.act(B, H, W, boc[0], "conv_in")
+        self.prog.add(lib.OP_CONV_IN, lib.ConvInDesc(x=self.io["sample"].ptr, w=self.w.ptr("conv_in.w"),
+                                                     bias=self.w.ptr("conv_in.b"), y=h.ptr, batch=B,
+                                                     cin=cfg.in_channels, h=H, wd=W, cout=boc[0], ldy=h.ld), "conv_in")
+        skips = [h]
+        for i, t in enumerate(cfg.down_block_types):
+            path = f"down_blocks.{i}"
+            cout = boc[i]
+            final = i == len(boc) - 1
+            for j in range(cfg.layers_per_block):
+                h = self._resnet(h, f"{path}.resnets.{j}", cout)
+                if t != "DownBlock2D":
+                    h = self._transformer(h, f"{path}.attentions.{j}", cfg.transformer_layers_per_block[i],
+                                          cfg.attention_head_dim[i])
+                skips.append(h)
+            if not final:
+                p = f"{path}.downsamplers.0.conv"
+                h = self.gemm(h, p, cout, p, conv={"stride": 2}, lora_paths=[p])
+                skips.append(h)
+        mp = "mid_block"
+        h = self._resnet(h, mp + ".resnets.0", boc[-1])
+        h = self._transformer(h, mp + ".attentions.0", cfg.transformer_layers_per_block[-1], cfg.attention_head_dim[-1])
+        h = self._resnet(h, mp + ".resnets.1", boc[-1])
+        rboc = tuple(reversed(boc))
+        rheads = tuple(reversed(cfg.attention_head_dim))
+        rtl = tuple(reversed(cfg.transformer_layers_per_block))
+        for i, t in enumerate(cfg.up_block_types):
+            path = f"up_blocks.{i}"
+            cout = rboc[i]
+            final = i == len(boc) - 1
+            for j in range(cfg.layers_per_block + 1):
+                skip = skips.pop()
+                h = self._resnet((h, skip), f"{path}.resnets.{j}", cout)
+                if t != "UpBlock2D":
+                    h = self._transformer(h, f"{path}.attentions.{j}", rtl[i], rheads[i])
+            if not final:
+                p = f"{path}.upsamplers.0.conv"
+                h = self.gemm(h, p, cout, p, conv={"xform": 1}, lora_paths=[p])
+        assert not skips
+        g = self.groupnorm(h, "conv_norm_out", cfg.norm_eps, 1, "conv_norm_out")
+        self.skinny(g, self.w.ptr("conv_out.w"), cfg.out_channels, 9 * g.C, {}, g.M, g.H, g.W, "conv_out",
+                    out=self.io["eps"], bias_ptr=self.w.ptr("conv_out.b"), out_kind=1)
+        if self.train:
+            self.tape.append(dict(op="conv_out", x=g, name="conv_out"))

@@ -1,0 +1,197 @@
+"""UNetEngine: the drop-in for the `unet` object the reference passes to predict_noise[_xl]
+(trainscripts/textsliders/train_util.py:145-171, 220-260):
+
+    unet(latent_model_input, timestep, encoder_hidden_states=E[, added_cond_kwargs={...}]).sample
+
+Same call signature, same (B,4,H,W) latent layout at the boundary, same attributes the reference's callers
+touch (.to/.eval/.requires_grad_/.enable_xformers_memory_efficient_attention/.config.in_channels/.in_channels/
+.dtype).  Everything between the input copy and the output tensor is ONE slh_run_program call on the current
+PyTorch-ROCm stream; PyTorch only owns the memory.
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional, Tuple
+
+import torch
+
+from . import lib
+from .arena import Arena
+from .config import UNetConfig
+from .lora_store import LoraStore
+from .planner import UNetPlan
+from .weights import WeightStore
+
+
+class UNetOutput:
+    def __init__(self, sample: torch.Tensor):
+        self.sample = sample
+
+    def __getitem__(self, i):
+        return (self.sample,)[i]
+
+
+class _Cfg(dict):
+    __getattr__ = dict.__getitem__
+
+
+class UNetEngine:
+    def __init__(self, cfg: UNetConfig, state_dict: Dict[str, torch.Tensor], device="cuda:0",
+                 arena_bytes: Optional[int] = None, ctx_len: int = 77):
+        self.cfg = cfg
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError("UNetEngine needs a ROCm GPU (there is no CPU fallback for the hot path)")
+        lib.load()
+        self.weights = WeightStore(cfg, state_dict, self.device)
+        self.ctx_len = ctx_len
+        self.config = _Cfg(in_channels=cfg.in_channels, sample_size=cfg.sample_size)
+        self.in_channels = cfg.in_channels
+        self.dtype = torch.bfloat16
+        self.lora: Optional[LoraStore] = None
+        self.lora_active = False
+        self.lora_scale = torch.zeros(1, dtype=torch.float32, device=self.device)
+        self._plans: Dict[Tuple, UNetPlan] = {}
+        self._arena_bytes = arena_bytes
+        self.arena: Optional[Arena] = None
+        self.zarena = Arena(64 << 20, self.device, "zero-init accumulators")
+        self.train_plan: Optional[UNetPlan] = None
+
+    # ---- reference-facing no-ops ----------------------------------------------------------------
+    def to(self, *a, **k):
+        return self
+
+    def eval(self):
+        return self
+
+    def requires_grad_(self, flag=False):
+        return self
+
+    def enable_xformers_memory_efficient_attention(self):
+        return None
+
+    # ---- LoRA switch (driven by sliders_amd.lora.LoRANetwork) ------------------------------------
+    def attach_lora(self, store: LoraStore):
+        self.lora = store
+        self._plans = {k: v for k, v in self._plans.items() if k[3] == "off"}
+
+    def set_lora(self, active: bool, multiplier: float = 1.0):
+        self.lora_active = bool(active) and self.lora is not None
+        if self.lora is not None:
+            self.lora_scale.fill_(float(multiplier) * self.lora.scale if active else 0.0)
+
+    # ---- planning ---------------------------------------------------------------------------------
+    def _virtual_size(self, B, H, W, mode) -> int:
+        va = Arena(1 << 50, None, "virtual")
+        vz = Arena(1 << 40, None, "virtualz")
+        UNetPlan(self.cfg, _VirtualWeights(self.weights), va, vz, B, H, W, self.ctx_len,
+                 _VirtualLora(self.lora) if mode != "off" else None, mode, 0)
+        return va.high_water
+
+    def _ensure_arena(self, need: int):
+        if self.arena is not None and self.arena.capacity >= need:
+            return
+        if self.arena is not None and self._plans:
+            raise MemoryError("activation arena too small for a new plan; construct the engine with arena_bytes")
+        cap = max(need, self._arena_bytes or 0)
+        self.arena = Arena(cap + (1 << 20), self.device, "activations")
+
+    def plan(self, B: int, H: int, W: int, mode: str) -> UNetPlan:
+        key = (B, H, W, mode)
+        p = self._plans.get(key)
+        if p is not None:
+            return p
+        need = self._virtual_size(B, H, W, mode)
+        self._ensure_arena(need)
+        if mode == "train":
+            self.weights.ensure_dgrad()
+        # all plans share the activation arena from offset 0: they never run concurrently
+        self.arena.reset(0)
+        zmark = self.zarena.mark()
+        p = UNetPlan(self.cfg, self.weights, self.arena, self.zarena, B, H, W, self.ctx_len,
+                     self.lora if mode != "off" else None, mode, self.lora_scale.data_ptr())
+        p.arena_end = self.arena.mark()
+        del zmark
+        self._plans[key] = p
+        return p
+
+    # ---- the model call ---------------------------------------------------------------------------
+    def _mode(self) -> str:
+        if not self.lora_active:
+            return "off"
+        return "train" if torch.is_grad_enabled() else "on"
+
+    def load_inputs(self, p: UNetPlan, sample, timestep, encoder_hidden_states, added_cond_kwargs):
+        B = p.B
+        io = p.io
+        io["sample"].tensor.copy_(sample.to(torch.bfloat16))
+        t = timestep
+        if not torch.is_tensor(t):
+            t = torch.tensor(float(t))
+        io["t"].tensor.copy_(t.to(device=self.device, dtype=torch.float32).reshape(-1, 1).expand(B, 1))
+        io["ctx"].tensor.copy_(encoder_hidden_states.to(torch.bfloat16))
+        if self.cfg.is_xl:
+            te = added_cond_kwargs["text_embeds"]
+            ti = added_cond_kwargs["time_ids"]
+            io["time_ids"].tensor.copy_(ti.to(torch.float32).reshape(B, 6))
+            io["add_in"].tensor[:, : self.cfg.pooled_dim].copy_(te.to(torch.bfloat16))
+
+    def forward_plan(self, p: UNetPlan):
+        p.prog.run(torch.cuda.current_stream().cuda_stream)
+
+    def __call__(self, sample, timestep, encoder_hidden_states=None, added_cond_kwargs=None,
+                 return_dict: bool = True, mode: Optional[str] = None):
+        B, _, H, W = sample.shape
+        mode = mode or self._mode()
+        p = self.plan(B, H, W, mode)
+        self.load_inputs(p, sample, timestep, encoder_hidden_states, added_cond_kwargs)
+        self.forward_plan(p)
+        if mode == "train":
+            self.train_plan = p
+        out = p.io["eps"].tensor.clone()
+        if not return_dict:
+            return (out,)
+        return UNetOutput(out)
+
+    forward = __call__
+
+
+class _VirtualWeights:
+    """Pointer-less stand-in so the planner can be dry-run for sizing."""
+
+    def __init__(self, w: WeightStore):
+        self._w = w
+        self.temb_offsets = w.temb_offsets
+        self.temb_total = w.temb_total
+        self.resnet_paths = w.resnet_paths
+
+    def ptr(self, name):
+        return 0x1000
+
+    def has(self, name):
+        return self._w.has(name)
+
+
+class _VirtualLora:
+    def __init__(self, s: LoraStore):
+        self._s = s
+        self.temb_entries = s.temb_entries
+        self.temb_down_off = s.temb_down_off
+        self.temb_up_off = s.temb_up_off
+        self.temb_tcol = _FakeTensor()
+        self.params = _FakeTensor()
+
+    def fused_group(self, paths):
+        return self._s.fused_group(paths)
+
+    def down_ptr(self, e):
+        return 0x2000
+
+    def up_ptr(self, e):
+        return 0x2000
+
+
+class _FakeTensor:
+    device = "cpu"
+
+    def data_ptr(self):
+        return 0x3000

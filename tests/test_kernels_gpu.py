@@ -1,0 +1,437 @@
+"""Per-kernel parity: every HIP entry point of include/sliders_hip.h, called through the C ABI, against a
+plain PyTorch fp32 restatement of the same op on the same seeded inputs.
+
+Tolerances (floating point, bf16 I/O, fp32 accumulate): relative L2 error of the bf16 output against the fp32
+reference computed from the SAME bf16-rounded inputs must be < 6e-3 (= 1.5 bf16 ulps, i.e. output rounding
+plus accumulation-order noise).  Elementwise kernels whose rounding points are restated exactly (CFG+DDIM,
+loss gradient, AdamW) must be BIT-EXACT against the torch bf16 ops.
+"""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from sliders_amd import lib
+from tests.util import bf, p, report, stream
+
+pytestmark = pytest.mark.gpu
+TOL = 6e-3
+
+
+def _conv_ref(x_img, w, stride=1, up=False, dilate=False):
+    """x_img [B,C,H,W] fp32, w [Co,Ci,3,3]"""
+    if up:
+        x_img = F.interpolate(x_img, scale_factor=2.0, mode="nearest")
+    if dilate:
+        B, C, H, W = x_img.shape
+        z = torch.zeros(B, C, 2 * H, 2 * W, device=x_img.device)
+        z[:, :, ::2, ::2] = x_img
+        x_img = z
+    return F.conv2d(x_img, w, None, stride=stride, padding=1)
+
+
+def _to_pix(x_img):
+    B, C, H, W = x_img.shape
+    return x_img.permute(0, 2, 3, 1).reshape(B * H * W, C).contiguous()
+
+
+def _pack_conv(w):
+    return w.permute(0, 2, 3, 1).reshape(w.shape[0], -1).contiguous()
+
+
+@pytest.mark.parametrize("tile", [0x22, 0x21, 0x12, 0x11])
+@pytest.mark.parametrize("M,N,K", [(256, 128, 64), (300, 320, 320), (1024, 640, 1280), (154, 256, 2048)])
+def test_gemm_dense(dev, M, N, K, tile):
+    torch.manual_seed(M + N + K)
+    x = bf(torch.randn(M, K, device=dev))
+    w = bf(torch.randn(N, K, device=dev) / math.sqrt(K))
+    bias = bf(torch.randn(N, device=dev))
+    res = bf(torch.randn(M, N, device=dev))
+    c = torch.zeros(M, N, device=dev, dtype=torch.bfloat16)
+    d = lib.GemmDesc(a0=p(x), w=p(w), bias=p(bias), residual=p(res), c=p(c), lda0=K, ca0=K, mode=0, stride=1, ldw=K,
+                     M=M, N=N, K=K, ld_res=N, ldc=N, rows_per_sample=M, tile=tile)
+    lib.call(lib.OP_GEMM, d, stream())
+    torch.cuda.synchronize()
+    ref = x.float() @ w.float().t() + bias.float() + res.float()
+    report(f"gemm_dense M{M} N{N} K{K} tile{tile:x}", c, ref, TOL)
+
+
+def test_gemm_two_source_rowbias_lora(dev):
+    torch.manual_seed(1)
+    B, HW, C0, C1, N = 2, 160, 128, 64, 320
+    M, K = B * HW, C0 + C1
+    x0 = bf(torch.randn(M, C0, device=dev))
+    x1big = bf(torch.randn(M, 2 * C1, device=dev))      # second source is a column slice (ld != C)
+    x1 = x1big[:, C1:]
+    w = bf(torch.randn(N, K, device=dev) / math.sqrt(K))
+    rb = bf(torch.randn(B, 512, device=dev))
+    for groups in (1, 2):
+        T = torch.randn(M, 4 * groups, device=dev)
+        up = bf(torch.randn(N, 4, device=dev))
+        scale = torch.tensor([0.25], device=dev)
+        c = torch.zeros(M, N, device=dev, dtype=torch.bfloat16)
+        d = lib.GemmDesc(a0=p(x0), a1=x1.data_ptr(), w=p(w), rowbias=rb.data_ptr() + 2 * 64, lora_t=p(T),
+                         lora_up=p(up), lora_scale=p(scale), c=p(c), lda0=C0, lda1=2 * C1, ca0=C0, ca1=C1, mode=0,
+                         stride=1, ldw=K, M=M, N=N, K=K, ld_rowbias=512, rows_per_sample=HW, ld_t=4 * groups,
+                         lora_groups=groups, ldc=N, tile=0)
+        lib.call(lib.OP_GEMM, d, stream())
+        torch.cuda.synchronize()
+        xcat = torch.cat([x0.float(), x1.float()], 1)
+        ref = xcat @ w.float().t() + rb.float()[:, 64:64 + N].repeat_interleave(HW, 0)
+        ng = N // groups
+        for g in range(groups):
+            ref[:, g * ng:(g + 1) * ng] += 0.25 * T[:, 4 * g:4 * g + 4] @ up.float()[g * ng:(g + 1) * ng].t()
+        report(f"gemm_2src_rowbias_lora g{groups}", c, ref, TOL)
+
+
+def test_gemm_geglu(dev):
+    torch.manual_seed(2)
+    M, d_, K = 512, 128, 256      # proj: K -> 8*d_/... here N = 2*n_out
+    n_out = 4 * d_
+    N = 2 * n_out
+    x = bf(torch.randn(M, K, device=dev))
+    w = bf(torch.randn(N, K, device=dev) / math.sqrt(K))
+    b = bf(torch.randn(N, device=dev))
+    from sliders_amd.weights import _geglu_perm
+    wp, bp = _geglu_perm(w), _geglu_perm(b)
+    for tile in (0x22, 0x12):
+        c = torch.zeros(M, n_out, device=dev, dtype=torch.bfloat16)
+        d = lib.GemmDesc(a0=p(x), w=p(wp), bias=p(bp), c=p(c), lda0=K, ca0=K, mode=0, stride=1, ldw=K, M=M, N=N, K=K,
+                         ldc=n_out, geglu=1, rows_per_sample=M, tile=tile)
+        lib.call(lib.OP_GEMM, d, stream())
+        torch.cuda.synchronize()
+        proj = bf(x.float() @ w.float().t() + b.float()).float()
+        ref = proj[:, :n_out] * bf(F.gelu(proj[:, n_out:])).float()
+        report(f"gemm_geglu tile{tile:x}", c, ref, TOL)
+    # unfused training path: blocked pre-activation + elementwise GEGLU fwd / bwd
+    pre = torch.zeros(M, N, device=dev, dtype=torch.bfloat16)
+    d = lib.GemmDesc(a0=p(x), w=p(wp), bias=p(bp), c=p(pre), lda0=K, ca0=K, mode=0, stride=1, ldw=K, M=M, N=N, K=K,
+                     ldc=N, rows_per_sample=M)
+    lib.call(lib.OP_GEMM, d, stream())
+    out = torch.zeros(M, n_out, device=dev, dtype=torch.bfloat16)
+    lib.call(lib.OP_ELEMENTWISE, lib.EwDesc(a=p(pre), out=p(out), M=M, C=n_out, lda=N, ldo=n_out, op=lib.EW_GEGLU_FWD), stream())
+    torch.cuda.synchronize()
+    report("geglu_unfused_fwd", out, ref, TOL)
+    dy = bf(torch.randn(M, n_out, device=dev))
+    dpre = torch.zeros(M, N, device=dev, dtype=torch.bfloat16)
+    lib.call(lib.OP_ELEMENTWISE, lib.EwDesc(a=p(pre), b=p(dy), out=p(dpre), M=M, C=n_out, lda=N, ldb=n_out, ldo=N,
+                                            op=lib.EW_GEGLU_BWD), stream())
+    torch.cuda.synchronize()
+    pr = proj.clone().requires_grad_(True)
+    (pr[:, :n_out] * F.gelu(pr[:, n_out:])).backward(dy.float())
+    report("geglu_bwd", dpre, _perm_cols(pr.grad), 1.5e-2)
+
+
+def _perm_cols(g):
+    from sliders_amd.weights import _geglu_perm
+    return _geglu_perm(g.t().contiguous()).t().contiguous()
+
+
+@pytest.mark.parametrize("stride,xform", [(1, 0), (2, 0), (1, 1), (1, 2)])
+@pytest.mark.parametrize("tile", [0x22, 0x11])
+def test_gemm_conv3x3(dev, stride, xform, tile):
+    torch.manual_seed(3 + stride + xform)
+    B, H, W, Ci, Co = 2, 12, 20, 128, 192
+    img = bf(torch.randn(B, Ci, H, W, device=dev))
+    w4 = bf(torch.randn(Co, Ci, 3, 3, device=dev) / math.sqrt(9 * Ci))
+    bias = bf(torch.randn(Co, device=dev))
+    ref_img = _conv_ref(img.float(), w4.float(), stride, up=(xform == 1), dilate=(xform == 2)) + bias.float()[None, :, None, None]
+    Ho, Wo = ref_img.shape[2:]
+    x = bf(_to_pix(img.float()))
+    wp = _pack_conv(w4)
+    M = B * Ho * Wo
+    c = torch.zeros(M, Co, device=dev, dtype=torch.bfloat16)
+    d = lib.GemmDesc(a0=p(x), w=p(wp), bias=p(bias), c=p(c), lda0=Ci, ca0=Ci, mode=1, batch=B, hs=H, ws=W,
+                     src_xform=xform, stride=stride, ho=Ho, wo=Wo, ldw=9 * Ci, M=M, N=Co, K=9 * Ci, ldc=Co,
+                     rows_per_sample=Ho * Wo, tile=tile)
+    lib.call(lib.OP_GEMM, d, stream())
+    torch.cuda.synchronize()
+    report(f"gemm_conv s{stride} x{xform} tile{tile:x}", c, _to_pix(ref_img), TOL)
+
+
+def test_gemm_conv_two_source_and_skinny(dev):
+    torch.manual_seed(5)
+    B, H, W, C0, C1, Co = 2, 16, 16, 128, 64, 128
+    i0 = bf(torch.randn(B, C0, H, W, device=dev))
+    i1 = bf(torch.randn(B, C1, H, W, device=dev))
+    w4 = bf(torch.randn(Co, C0 + C1, 3, 3, device=dev) / math.sqrt(9 * (C0 + C1)))
+    ref = _to_pix(_conv_ref(torch.cat([i0, i1], 1).float(), w4.float()))
+    x0, x1 = bf(_to_pix(i0.float())), bf(_to_pix(i1.float()))
+    M = B * H * W
+    c = torch.zeros(M, Co, device=dev, dtype=torch.bfloat16)
+    d = lib.GemmDesc(a0=p(x0), a1=p(x1), w=p(_pack_conv(w4)), c=p(c), lda0=C0, lda1=C1, ca0=C0, ca1=C1, mode=1,
+                     batch=B, hs=H, ws=W, stride=1, ho=H, wo=W, ldw=9 * (C0 + C1), M=M, N=Co, K=9 * (C0 + C1),
+                     ldc=Co, rows_per_sample=H * W)
+    lib.call(lib.OP_GEMM, d, stream())
+    torch.cuda.synchronize()
+    report("gemm_conv_2src", c, ref, TOL)
+    # skinny: LoRA down conv (R=4), stride 2, and the NCHW conv_out form
+    for stride, R, kind in ((1, 4, 0), (2, 4, 0), (1, 12, 0), (1, 4, 1)):
+        wd = bf(torch.randn(R, C0 + C1, 3, 3, device=dev) / math.sqrt(9 * (C0 + C1)))
+        bias = bf(torch.randn(R, device=dev))
+        r_img = _conv_ref(torch.cat([i0, i1], 1).float(), wd.float(), stride) + bias.float()[None, :, None, None]
+        Ho, Wo = r_img.shape[2:]
+        Mo = B * Ho * Wo
+        out = torch.zeros(Mo, R, device=dev) if kind == 0 else torch.zeros(B, R, Ho, Wo, device=dev, dtype=torch.bfloat16)
+        sd = lib.SkinnyDesc(a0=p(x0), a1=p(x1), w=p(_pack_conv(wd)), bias=p(bias), out=p(out), lda0=C0, lda1=C1,
+                            ca0=C0, ca1=C1, mode=1, batch=B, hs=H, ws=W, stride=stride, ho=Ho, wo=Wo, M=Mo, R=R,
+                            K=9 * (C0 + C1), ldo=R, out_kind=kind)
+        lib.call(lib.OP_SKINNY, sd, stream())
+        torch.cuda.synchronize()
+        report(f"skinny_conv s{stride} R{R} kind{kind}", out, _to_pix(r_img) if kind == 0 else r_img, 2e-5 if kind == 0 else TOL)
+    # dense skinny
+    xd = bf(torch.randn(333, 640, device=dev))
+    wd = bf(torch.randn(12, 640, device=dev))
+    out = torch.zeros(333, 12, device=dev)
+    sd = lib.SkinnyDesc(a0=p(xd), w=p(wd), out=p(out), lda0=640, ca0=640, mode=0, stride=1, M=333, R=12, K=640, ldo=12)
+    lib.call(lib.OP_SKINNY, sd, stream())
+    torch.cuda.synchronize()
+    report("skinny_dense", out, xd.float() @ wd.float().t(), 2e-5)
+
+
+def test_gemv(dev):
+    torch.manual_seed(6)
+    nb, N, K = 2, 1000, 1280
+    x = bf(torch.randn(nb, K, device=dev))
+    w = bf(torch.randn(N, K, device=dev) / math.sqrt(K))
+    b = bf(torch.randn(N, device=dev))
+    add = bf(torch.randn(nb, N, device=dev))
+    T = torch.randn(nb, 16, device=dev)
+    tcol = torch.randint(0, 4, (N,), device=dev, dtype=torch.int32) * 4
+    up = bf(torch.randn(N, 4, device=dev))
+    scale = torch.tensor([0.25], device=dev)
+    y = torch.zeros(nb, N, device=dev, dtype=torch.bfloat16)
+    d = lib.GemvDesc(x=p(x), w=p(w), bias=p(b), addend=p(add), lora_t=p(T), lora_tcol=p(tcol), lora_up=p(up),
+                     lora_scale=p(scale), y=p(y), nb=nb, N=N, K=K, ldx=K, ld_add=N, ld_t=16, ldy=N, in_act=1, out_f32=0)
+    lib.call(lib.OP_GEMV, d, stream())
+    torch.cuda.synchronize()
+    xs = bf(F.silu(x.float())).float()
+    ref = xs @ w.float().t() + b.float()
+    idx = tcol.long()[None, :, None] + torch.arange(4, device=dev)[None, None, :]
+    tsel = torch.gather(T[:, None, :].expand(nb, N, 16), 2, idx.expand(nb, N, 4))
+    ref = ref + 0.25 * (tsel * up.float()[None]).sum(-1)
+    ref = bf(ref).float() + add.float()
+    report("gemv", y, ref, TOL)
+
+
+@pytest.mark.parametrize("C0,C1,act", [(320, 0, 1), (64, 0, 0), (1280, 640, 1), (2560, 0, 1), (960, 0, 1)])
+def test_groupnorm(dev, C0, C1, act):
+    torch.manual_seed(7)
+    B, HW = 2, 300
+    C = C0 + C1
+    x0 = bf(torch.randn(B * HW, C0, device=dev) * 2 + 0.5)
+    x1 = bf(torch.randn(B * HW, C1, device=dev)) if C1 else None
+    g, bta = bf(torch.randn(C, device=dev)), bf(torch.randn(C, device=dev))
+    stats = torch.zeros(B, 32, 2, device=dev)
+    y = torch.zeros(B * HW, C, device=dev, dtype=torch.bfloat16)
+    d = lib.GnDesc(x0=p(x0), x1=p(x1), gamma=p(g), beta=p(bta), stats=p(stats), y=p(y), ldx0=C0, ldx1=C1, c0=C0, c1=C1,
+                   batch=B, hw=HW, groups=32, ldy=C, eps=1e-5, act=act)
+    lib.call(lib.OP_GN_STATS, d, stream())
+    lib.call(lib.OP_GN_APPLY, d, stream())
+    torch.cuda.synchronize()
+    xc = torch.cat([x0, x1], 1) if C1 else x0
+    ximg = xc.float().view(B, HW, C).permute(0, 2, 1)
+    ref = F.group_norm(ximg, 32, g.float(), bta.float(), 1e-5)
+    if act:
+        ref = F.silu(bf(ref).float())
+    ref = ref.permute(0, 2, 1).reshape(B * HW, C)
+    report(f"groupnorm C{C0}+{C1} act{act}", y, ref, TOL)
+    # backward (dx only)
+    dy = bf(torch.randn(B * HW, C, device=dev))
+    bst = torch.zeros(B, 32, 2, device=dev)
+    dx0 = torch.zeros(B * HW, C0, device=dev, dtype=torch.bfloat16)
+    dx1 = torch.zeros(B * HW, max(C1, 8), device=dev, dtype=torch.bfloat16)
+    bd = lib.GnBwdDesc(x0=p(x0), x1=p(x1), gamma=p(g), beta=p(bta), stats=p(stats), bstats=p(bst), dy=p(dy),
+                       dx0=p(dx0), dx1=p(dx1) if C1 else 0, ldx0=C0, ldx1=C1, c0=C0, c1=C1, batch=B, hw=HW, groups=32,
+                       lddy=C, lddx0=C0, lddx1=max(C1, 8), eps=1e-5, act=act)
+    lib.call(lib.OP_GN_BWD_STATS, bd, stream())
+    lib.call(lib.OP_GN_BWD_APPLY, bd, stream())
+    torch.cuda.synchronize()
+    xi = ximg.clone().requires_grad_(True)
+    o = F.group_norm(xi, 32, g.float(), bta.float(), 1e-5)
+    if act:
+        o = F.silu(o)
+    o.backward(dy.float().view(B, HW, C).permute(0, 2, 1))
+    gref = xi.grad.permute(0, 2, 1).reshape(B * HW, C)
+    got = torch.cat([dx0, dx1[:, :C1]], 1) if C1 else dx0
+    report(f"groupnorm_bwd C{C0}+{C1} act{act}", got, gref, 1.5e-2)
+
+
+@pytest.mark.parametrize("C", [64, 320, 640, 1280])
+def test_layernorm(dev, C):
+    torch.manual_seed(8)
+    M = 777
+    x = bf(torch.randn(M, C, device=dev) * 3 + 1)
+    g, b = bf(torch.randn(C, device=dev)), bf(torch.randn(C, device=dev))
+    y = torch.zeros(M, C, device=dev, dtype=torch.bfloat16)
+    mr = torch.zeros(M, 2, device=dev)
+    lib.call(lib.OP_LAYERNORM, lib.LnDesc(x=p(x), gamma=p(g), beta=p(b), y=p(y), mean_rstd=p(mr), M=M, C=C, ldx=C,
+                                          ldy=C, eps=1e-5), stream())
+    torch.cuda.synchronize()
+    report(f"layernorm C{C}", y, F.layer_norm(x.float(), (C,), g.float(), b.float(), 1e-5), TOL)
+    dy = bf(torch.randn(M, C, device=dev))
+    dx = bf(torch.randn(M, C, device=dev))
+    dx_init = dx.clone()
+    lib.call(lib.OP_LAYERNORM_BWD, lib.LnBwdDesc(x=p(x), gamma=p(g), dy=p(dy), mean_rstd=p(mr), dx=p(dx), M=M, C=C,
+                                                 ldx=C, lddy=C, lddx=C, accumulate=1), stream())
+    torch.cuda.synchronize()
+    xi = x.float().clone().requires_grad_(True)
+    F.layer_norm(xi, (C,), g.float(), b.float(), 1e-5).backward(dy.float())
+    report(f"layernorm_bwd C{C}", dx, xi.grad + dx_init.float(), 1.5e-2)
+
+
+@pytest.mark.parametrize("B,H,Tq,Tk", [(2, 5, 1024, 1024), (1, 3, 192, 192), (2, 4, 256, 77), (1, 2, 100, 333)])
+def test_attention_fwd(dev, B, H, Tq, Tk):
+    torch.manual_seed(9)
+    C = H * 64
+    self_attn = Tq == Tk
+    if self_attn:
+        qkv = bf(torch.randn(B * Tq, 3 * C, device=dev))
+        q, k, v = qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:]
+        ldq = ldk = ldv = 3 * C
+    else:
+        qb = bf(torch.randn(B * Tq, C, device=dev))
+        kvb = bf(torch.randn(B * Tk, 2 * C, device=dev))
+        q, k, v = qb, kvb[:, :C], kvb[:, C:]
+        ldq, ldk, ldv = C, 2 * C, 2 * C
+    ldt = (Tk + 63) // 64 * 64
+    vt = torch.full((B, H, 64, ldt), float("nan"), device=dev, dtype=torch.bfloat16)
+    lib.call(lib.OP_TRANSPOSE_HEADS, lib.TransposeDesc(src=v.data_ptr(), dst=p(vt), B=B, H=H, T=Tk, ld=ldv, ldt=ldt), stream())
+    torch.cuda.synchronize()
+    vref = v.reshape(B, Tk, H, 64).permute(0, 2, 3, 1)
+    assert torch.equal(vt[..., :Tk], vref), "transpose_heads mismatch"
+    assert (vt[..., Tk:] == 0).all(), "transpose_heads padding must be zero"
+    o = torch.zeros(B * Tq, C, device=dev, dtype=torch.bfloat16)
+    lse = torch.zeros(B, H, Tq, device=dev)
+    d = lib.AttnDesc(q=q.data_ptr(), k=k.data_ptr(), vt=p(vt), o=p(o), lse=p(lse), B=B, H=H, Tq=Tq, Tk=Tk, ldq=ldq,
+                     ldk=ldk, ldvt=ldt, ldo=C, scale=0.125)
+    lib.call(lib.OP_ATTN_FWD, d, stream())
+    torch.cuda.synchronize()
+    qf = q.float().reshape(B, Tq, H, 64).transpose(1, 2)
+    kf = k.float().reshape(B, Tk, H, 64).transpose(1, 2)
+    vf = v.float().reshape(B, Tk, H, 64).transpose(1, 2)
+    s = qf @ kf.transpose(-1, -2) * 0.125
+    ref = (torch.softmax(s, -1) @ vf).transpose(1, 2).reshape(B * Tq, C)
+    report(f"attn_fwd B{B} H{H} Tq{Tq} Tk{Tk}", o, ref, 8e-3)
+    report("attn_lse", lse, torch.logsumexp(s, -1) * 1.4426950408889634, 1e-4)
+
+
+def test_timestep_embed_and_conv_in(dev):
+    torch.manual_seed(10)
+    vals = torch.tensor([[999.0, 1024.0, 0.0], [20.0, 512.0, 3.0]], device=dev)
+    out = torch.zeros(2, 16 + 3 * 256, device=dev, dtype=torch.bfloat16)
+    lib.call(lib.OP_TEMBED, lib.TembedDesc(vals=p(vals), out=p(out), nb=2, n_vals=3, dim=256, ldo=out.shape[1], col0=16), stream())
+    torch.cuda.synchronize()
+    half = 128
+    fr = torch.exp(-math.log(10000) * torch.arange(half, dtype=torch.float32, device=dev) / half)
+    arg = vals[:, :, None] * fr
+    ref = torch.cat([torch.cos(arg), torch.sin(arg)], -1).reshape(2, -1)
+    report("timestep_embed", out[:, 16:], ref, 4e-3)
+    B, H, W, Co = 2, 24, 16, 320
+    x = bf(torch.randn(B, 4, H, W, device=dev))
+    w4 = bf(torch.randn(Co, 4, 3, 3, device=dev) / 6)
+    bias = bf(torch.randn(Co, device=dev))
+    y = torch.zeros(B * H * W, Co, device=dev, dtype=torch.bfloat16)
+    lib.call(lib.OP_CONV_IN, lib.ConvInDesc(x=p(x), w=p(_pack_conv(w4)), bias=p(bias), y=p(y), batch=B, cin=4, h=H, wd=W,
+                                            cout=Co, ldy=Co), stream())
+    torch.cuda.synchronize()
+    report("conv_in", y, _to_pix(F.conv2d(x.float(), w4.float(), bias.float(), padding=1)), TOL)
+
+
+def test_cfg_ddim_bit_exact(dev):
+    torch.manual_seed(11)
+    from oracle.ddim_oracle import DDIMScheduler
+    sch = DDIMScheduler()
+    sch.set_timesteps(50)
+    nb, chw = 1, 4 * 32 * 32
+    eps = bf(torch.randn(2 * nb, chw, device=dev))
+    x = bf(torch.randn(nb, chw, device=dev))
+    for t in (980, 500, 0):
+        cb, ca, cp, cd = sch.step_coefficients(t)
+        out = torch.zeros(nb, chw, device=dev, dtype=torch.bfloat16)
+        d = lib.CfgDdimDesc(eps=p(eps), x=p(x), out=p(out), nb=nb, chw=chw, guidance=3.0, c_sqrt_beta_t=cb,
+                            c_sqrt_alpha_t=ca, c_sqrt_alpha_prev=cp, c_dir=cd, do_step=1)
+        lib.call(lib.OP_CFG_DDIM, d, stream())
+        torch.cuda.synchronize()
+        e_c, x_c = eps.cpu(), x.cpu()
+        u, tt = e_c.chunk(2)
+        guided = u + 3 * (tt - u)                       # train_util.py:166-169 in bf16
+        ref = sch.step(guided, t, x_c).prev_sample      # oracle DDIM, bf16 tensors x fp32 0-dim scalars
+        assert ref.dtype == torch.bfloat16
+        assert torch.equal(out.cpu(), ref), f"cfg+ddim not bit-exact at t={t}: max diff {(out.cpu().float() - ref.float()).abs().max()}"
+    print("[parity] cfg_ddim: bit-exact at t=980,500,0")
+
+
+def test_loss_and_grad(dev):
+    torch.manual_seed(12)
+    n = 4 * 64 * 64
+    tg, po, ne, un = [bf(torch.randn(n, device=dev)) for _ in range(4)]
+    for erase in (0, 1):
+        loss = torch.zeros(1, device=dev)
+        dt = torch.zeros(n, device=dev, dtype=torch.bfloat16)
+        lib.call(lib.OP_LOSS, lib.LossDesc(target=p(tg), positive=p(po), neutral=p(ne), uncond=p(un), loss=p(loss),
+                                           dtarget=p(dt), n=n, guidance=4.0, erase=erase), stream())
+        torch.cuda.synchronize()
+        t_c = tg.cpu().clone().requires_grad_(True)
+        y = ne.cpu() - 4.0 * (po.cpu() - un.cpu()) if erase else ne.cpu() + 4.0 * (po.cpu() - un.cpu())
+        l = F.mse_loss(t_c, y)
+        l.backward()
+        assert torch.equal(dt.cpu(), t_c.grad), "loss gradient not bit-exact vs torch bf16 autograd"
+        assert abs(loss.item() - l.float().item()) <= 4e-3 * abs(l.float().item()) + 1e-6
+    print("[parity] guidance loss: gradient bit-exact, value within bf16 rounding")
+
+
+def test_adamw_bit_exact(dev):
+    torch.manual_seed(13)
+    n = 10007
+    p0 = bf(torch.randn(n) * 0.05)
+    param = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.AdamW([param], lr=2e-4)
+    dp = p0.clone().to(dev)
+    m = torch.zeros(n, device=dev, dtype=torch.bfloat16)
+    v = torch.zeros(n, device=dev, dtype=torch.bfloat16)
+    mism = 0
+    for step in range(1, 6):
+        g = torch.randn(n) * 1e-3
+        param.grad = bf(g)
+        opt.step()
+        gd = bf(g).float().to(dev)
+        d = lib.AdamwDesc(param=p(dp), exp_avg=p(m), exp_avg_sq=p(v), grad=p(gd), n=n, lr=2e-4, beta1=0.9, beta2=0.999,
+                          eps=1e-8, weight_decay=0.01, step=step, grad_scale=1.0)
+        lib.call(lib.OP_ADAMW, d, stream())
+        torch.cuda.synchronize()
+        mism = (dp.cpu().view(torch.int16) != param.data.view(torch.int16)).sum().item()
+        print(f"[parity] adamw step {step}: {mism}/{n} params differ from torch.optim.AdamW(bf16, CPU)")
+    assert mism == 0, "AdamW not bit-exact"
+
+
+def test_lora_wgrad(dev):
+    torch.manual_seed(14)
+    M, C, R = 1500, 320, 4
+    z = bf(torch.randn(M, C, device=dev))
+    v = torch.randn(M, 12, device=dev)
+    scale = torch.tensor([0.25], device=dev)
+    out = torch.zeros(C, 4, device=dev)
+    lib.call(lib.OP_WGRAD, lib.WgradDesc(z0=p(z), v=p(v), out=p(out), scale=p(scale), ldz0=C, c0=C, mode=0, stride=1,
+                                         M=M, R=4, ldv=12, ldo=4, out_rmajor=0, vgroup_cols=0), stream())
+    torch.cuda.synchronize()
+    report("wgrad_up_layout", out, 0.25 * z.float().t() @ v[:, :4], 1e-4)
+    out = torch.zeros(12, C, device=dev)
+    lib.call(lib.OP_WGRAD, lib.WgradDesc(z0=p(z), v=p(v), out=p(out), scale=p(scale), ldz0=C, c0=C, mode=0, stride=1,
+                                         M=M, R=12, ldv=12, ldo=C, out_rmajor=1, vgroup_cols=0), stream())
+    torch.cuda.synchronize()
+    report("wgrad_down_layout_R12", out, 0.25 * v.t() @ z.float(), 1e-4)
+    # conv-mode: dA[r][tap][ci] = sum_m im2col(x)[m][tap,ci] * U[m][r]
+    B, H, W, Ci = 2, 10, 12, 64
+    img = bf(torch.randn(B, Ci, H, W, device=dev))
+    U = torch.randn(B * H * W, 4, device=dev)
+    out = torch.zeros(4, 9 * Ci, device=dev)
+    lib.call(lib.OP_WGRAD, lib.WgradDesc(z0=p(bf(_to_pix(img.float()))), v=p(U), out=p(out), scale=p(scale), ldz0=Ci,
+                                         c0=Ci, mode=1, batch=B, hs=H, ws=W, stride=1, ho=H, wo=W, M=B * H * W, R=4,
+                                         ldv=4, ldo=9 * Ci, out_rmajor=1, vgroup_cols=0), stream())
+    torch.cuda.synchronize()
+    wd = torch.zeros(4, Ci, 3, 3, device=dev, requires_grad=True)
+    yy = F.conv2d(img.float(), wd, padding=1)
+    yy.backward(U.view(B, H, W, 4).permute(0, 3, 1, 2))
+    report("wgrad_conv", out, 0.25 * wd.grad.permute(0, 2, 3, 1).reshape(4, -1), 1e-4)
