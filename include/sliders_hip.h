@@ -68,6 +68,8 @@ typedef struct slh_gemm_desc {
     int32_t ld_res, ldc;
     int32_t geglu;           /* 1: out[:, j] = a_j * gelu(g_j); W rows pre-permuted in 64-row blocks [32 a | 32 g] */
     int32_t tile;            /* 0 auto; else (MI<<4)|NI with MI,NI in {1,2}: block tile (64*MI) x (64*NI) */
+    int32_t lora_rank;       /* 0 = 4.  With lora_up_rmajor: total rank 4 | 8 | 12 (T has that many columns) */
+    int32_t lora_up_rmajor;  /* 1: lora_up is [rank][N] (= lora_down as stored): backward-data LoRA term */
 } slh_gemm_desc;
 int slh_gemm(const slh_gemm_desc* d, slh_stream_t stream);
 
@@ -86,6 +88,7 @@ typedef struct slh_skinny_desc {
     int32_t M, R, K;
     int32_t ldo;
     int32_t out_kind;        /* 0: fp32 [M][ldo]; 1: bf16 NCHW [batch][R][ho][wo] */
+    int32_t w_kmajor;        /* 1: w is [K][4] (R must be 4): U = dY . B with B = lora_up [out][r] as stored */
 } slh_skinny_desc;
 int slh_skinny(const slh_skinny_desc* d, slh_stream_t stream);
 
@@ -193,10 +196,13 @@ int slh_transpose_heads(const slh_transpose_desc* d, slh_stream_t stream);
  * in the caller-provided workspace.  need_dkv = 0 for cross-attention (text K/V carry no gradient). */
 typedef struct slh_attn_bwd_desc {
     const void* q; const void* k; const void* v; const void* o; const void* d_o;
-    const float* lse;
+    const void* kt;          /* [B][H][64][ldkt] K transposed (slh_transpose_heads) */
+    const void* qt;          /* [B][H][64][ldqt] Q transposed   (need_dkv only) */
+    const void* dot;         /* [B][H][64][ldqt] dO transposed  (need_dkv only) */
+    const float* lse;        /* [B][H][Tq] from the forward, padded by 64 floats */
+    float* delta;            /* [B][H][Tq] fp32 workspace, padded by 64 floats */
     void* dq; void* dk; void* dv;
-    float* delta;            /* [B][H][Tq] fp32 workspace */
-    int32_t B, H, Tq, Tk, ldq, ldk, ldv, ldo, lddo, lddq, lddk, lddv;
+    int32_t B, H, Tq, Tk, ldq, ldk, ldv, ldo, lddo, ldkt, ldqt, lddq, lddk, lddv;
     float scale;
     int32_t need_dkv;
 } slh_attn_bwd_desc;
@@ -245,9 +251,10 @@ int slh_elementwise(const slh_ew_desc* d, slh_stream_t stream);
  * do_step = 0 to produce only the guided epsilon (predict_noise). */
 typedef struct slh_cfg_ddim_desc {
     const void* eps; const void* x; void* out;
+    void* out2;              /* optional second copy of the result (the CFG pair's duplicated latent input) */
     int32_t nb, chw;
     float guidance;
-    float c_sqrt_beta_t, c_sqrt_alpha_t, c_sqrt_alpha_prev, c_dir;
+    float c_sqrt_beta_t, c_inv_sqrt_alpha_t, c_sqrt_alpha_prev, c_dir;
     int32_t do_step;
 } slh_cfg_ddim_desc;
 int slh_cfg_ddim(const slh_cfg_ddim_desc* d, slh_stream_t stream);
@@ -257,7 +264,9 @@ int slh_cfg_ddim(const slh_cfg_ddim_desc* d, slh_stream_t stream);
 typedef struct slh_loss_desc {
     const void* target; const void* positive; const void* neutral; const void* uncond;
     float* loss; void* dtarget;
+    float* dtarget_pix;      /* optional: the same gradient as fp32 pixel-major [nb*hw][nch] (backward input) */
     int32_t n; float guidance; int32_t erase;
+    int32_t hw, nch;         /* n = nb * nch * hw, NCHW order */
 } slh_loss_desc;
 int slh_guidance_loss(const slh_loss_desc* d, slh_stream_t stream);
 
@@ -275,6 +284,25 @@ typedef struct slh_wgrad_desc {
     int32_t vgroup_cols;     /* >0: channel c uses V columns 4*(c/vgroup_cols).. (fused q/k/v up grads) */
 } slh_wgrad_desc;
 int slh_lora_wgrad(const slh_wgrad_desc* d, slh_stream_t stream);
+
+/* Backward-data term of a 3x3 LoRA down conv (lora.py:82-87): gx[i][c] (+)= scale * sum_{tap,r} U[o][r] *
+ * A[r][tap][c] for the output pixels o with o*stride + tap - 1 = i.  U fp32 [batch*ho*wo][ldu], A = lora_down
+ * as stored [4][9*cin], gx bf16 pixel-major image of hl x wl. */
+typedef struct slh_lora_cdgrad_desc {
+    const float* u; const void* a_down; const float* scale; void* gx;
+    int32_t batch, hl, wl, ho, wo, stride, cin, ldu, ldgx, accumulate;
+} slh_lora_cdgrad_desc;
+int slh_lora_conv_dgrad(const slh_lora_cdgrad_desc* d, slh_stream_t stream);
+
+/* LoRA gradients of one ResnetBlock2D.time_emb_proj for one sample: g = d(loss)/d(temb projection) [C] fp32
+ * (column sums of the conv1 output gradient), t = that layer's lora_down(silu(emb)) [4], up [C][4], emb [ted]
+ * bf16; accumulates d_up [C][4] and d_down [4][ted] (fp32). */
+typedef struct slh_temb_lora_bwd_desc {
+    const float* g; const float* t; const void* up; const void* emb; float* d_up; float* d_down;
+    const float* scale;
+    int32_t C, ted;
+} slh_temb_lora_bwd_desc;
+int slh_temb_lora_bwd(const slh_temb_lora_bwd_desc* d, slh_stream_t stream);
 
 /* flat AdamW over the packed LoRA parameter buffer (bf16 params and moments, torch.optim.AdamW op order
  * and bf16 rounding points; train_util.py:362-363, train_lora_xl.py:346). grads fp32. */
@@ -297,7 +325,8 @@ enum {
     SLH_OP_LAYERNORM = 6, SLH_OP_ATTN_FWD = 7, SLH_OP_TRANSPOSE_HEADS = 8, SLH_OP_TEMBED = 9,
     SLH_OP_CONV_IN = 10, SLH_OP_ELEMENTWISE = 11, SLH_OP_CFG_DDIM = 12, SLH_OP_LOSS = 13,
     SLH_OP_WGRAD = 14, SLH_OP_ADAMW = 15, SLH_OP_GN_BWD_STATS = 16, SLH_OP_GN_BWD_APPLY = 17,
-    SLH_OP_LAYERNORM_BWD = 18, SLH_OP_ATTN_BWD = 19, SLH_OP_MEMSET = 20
+    SLH_OP_LAYERNORM_BWD = 18, SLH_OP_ATTN_BWD = 19, SLH_OP_MEMSET = 20, SLH_OP_LORA_CONV_DGRAD = 21,
+    SLH_OP_TEMB_LORA_BWD = 22
 };
 typedef struct slh_memset_desc { void* ptr; int64_t nbytes; int32_t value; int32_t pad; } slh_memset_desc;
 int slh_run_program(const void* program, int64_t nbytes, slh_stream_t stream);

@@ -56,13 +56,29 @@ class DDIMScheduler:
         alpha_prod_t = self.alphas_cumprod[t]
         alpha_prod_t_prev = self.alphas_cumprod[prev_t] if prev_t >= 0 else self.final_alpha_cumprod
         beta_prod_t = 1 - alpha_prod_t
-        # epsilon prediction; 0-dim fp32 scalars times (possibly bf16) tensors keep the tensor dtype
-        pred_original_sample = (sample - beta_prod_t ** 0.5 * model_output) / alpha_prod_t ** 0.5
-        pred_epsilon = model_output
         variance = (1 - alpha_prod_t_prev) / (1 - alpha_prod_t) * (1 - alpha_prod_t / alpha_prod_t_prev)
         std_dev_t = eta * variance ** 0.5
-        pred_sample_direction = (1 - alpha_prod_t_prev - std_dev_t ** 2) ** 0.5 * pred_epsilon
-        prev_sample = alpha_prod_t_prev ** 0.5 * pred_original_sample + pred_sample_direction
+        # diffusers writes (epsilon prediction, no clipping):
+        #   pred_original_sample = (sample - beta_prod_t ** 0.5 * model_output) / alpha_prod_t ** 0.5
+        #   pred_sample_direction = (1 - alpha_prod_t_prev - std_dev_t ** 2) ** 0.5 * model_output
+        #   prev_sample = alpha_prod_t_prev ** 0.5 * pred_original_sample + pred_sample_direction
+        # where the coefficients are 0-dim fp32 CPU tensors and the operands bf16 tensors ON THE GPU (the
+        # reference trains on cuda, train_lora_xl.py:414).  torch's CUDA binary kernels keep a CPU scalar in
+        # fp32 opmath (no rounding of the coefficient to bf16) and divide by a CPU scalar as a * (1 / b);
+        # every op rounds its result once to the tensor dtype.  _smul restates exactly that, so this oracle
+        # gives the same bits on CPU as the reference's ops give on a GPU.
+        dt = sample.dtype
+
+        def _smul(scalar, tensor):
+            return (tensor.float() * scalar.float()).to(dt)
+
+        c_sqrt_beta = beta_prod_t ** 0.5
+        c_inv_sqrt_alpha = torch.tensor(1.0) / (alpha_prod_t ** 0.5)
+        c_dir = (1 - alpha_prod_t_prev - std_dev_t ** 2) ** 0.5
+        c_sqrt_alpha_prev = alpha_prod_t_prev ** 0.5
+        pred_original_sample = _smul(c_inv_sqrt_alpha, sample - _smul(c_sqrt_beta, model_output))
+        pred_sample_direction = _smul(c_dir, model_output)
+        prev_sample = _smul(c_sqrt_alpha_prev, pred_original_sample) + pred_sample_direction
         return _StepOutput(prev_sample, pred_original_sample)
 
     def add_noise(self, original_samples, noise, timesteps):
@@ -76,10 +92,10 @@ class DDIMScheduler:
         return a * original_samples + s * noise
 
     def step_coefficients(self, timestep):
-        """(sqrt(1-a_t), sqrt(a_t), sqrt(a_prev), sqrt(1-a_prev)) as python floats of fp32 values."""
+        """(sqrt(1-a_t), 1/sqrt(a_t), sqrt(a_prev), sqrt(1-a_prev)) as python floats of fp32 values."""
         t = int(timestep)
         prev_t = t - self.num_train_timesteps // self.num_inference_steps
         a_t = self.alphas_cumprod[t]
         a_p = self.alphas_cumprod[prev_t] if prev_t >= 0 else self.final_alpha_cumprod
-        return (float((1 - a_t) ** 0.5), float(a_t ** 0.5), float(a_p ** 0.5),
+        return (float((1 - a_t) ** 0.5), float(torch.tensor(1.0) / (a_t ** 0.5)), float(a_p ** 0.5),
                 float((1 - a_p - (0.0 * a_p) ** 2) ** 0.5))

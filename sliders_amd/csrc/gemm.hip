@@ -29,6 +29,7 @@ struct GemmArgs {
     int hs, ws, src_xform, stride, ho, wo;
     int ldw, M, N, K;
     int ld_rowbias, rows_per_sample, ld_t, lora_cols_per_group, ld_res, ldc, geglu;
+    int lora_rank, lora_up_rmajor;
     int tiles_m, tiles_n;
 };
 
@@ -210,7 +211,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) v[e] += (float)b4[e];
                     }
-                    if (p.lora_t) {
+                    if (p.lora_t && !p.lora_up_rmajor) {
                         const int g = n / p.lora_cols_per_group;
                         const f32x4 t = g == 0 ? tv[0] : (g == 1 ? tv[1] : tv[2]);
 #pragma unroll
@@ -219,6 +220,22 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
                             v[e] += lscale * (t[0] * (float)u[0] + t[1] * (float)u[1] +
                                               t[2] * (float)u[2] + t[3] * (float)u[3]);
                         }
+                    } else if (p.lora_t) {
+                        // backward-data form: the "up" matrix is lora_down as stored, [rank][N], rank 4..12
+                        float s4[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                        for (int g = 0; g < 3; ++g) {
+                            if (g * 4 < p.lora_rank) {
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) {
+                                    const bf16x4 u = *(const bf16x4*)(p.lora_up + (long)(g * 4 + r) * p.N + n);
+#pragma unroll
+                                    for (int e = 0; e < 4; ++e) s4[e] += tv[g][r] * (float)u[e];
+                                }
+                            }
+                        }
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] += lscale * s4[e];
                     }
                     if (p.residual) {
                         const bf16x4 r4 = *(const bf16x4*)(p.residual + (long)m * p.ld_res + n);
@@ -298,6 +315,10 @@ extern "C" int slh_gemm(const slh_gemm_desc* d, slh_stream_t stream) {
         SLH_CHECK(d->lora_groups >= 1 && d->lora_groups <= 3 && d->N % d->lora_groups == 0 &&
                       d->ld_t >= 4 * d->lora_groups && d->ld_t % 4 == 0,
                   "slh_gemm: bad lora grouping");
+        if (d->lora_up_rmajor)
+            SLH_CHECK(d->lora_groups == 1 && (d->lora_rank == 4 || d->lora_rank == 8 || d->lora_rank == 12) &&
+                          d->ld_t >= d->lora_rank,
+                      "slh_gemm: r-major lora_up needs groups=1 and rank in {4,8,12}");
         SLH_CHECK((d->N / d->lora_groups) % 4 == 0, "slh_gemm: lora group width");
     }
     if (d->rowbias) SLH_CHECK(d->rows_per_sample > 0 && d->ld_rowbias % 4 == 0, "slh_gemm: rowbias");
@@ -328,6 +349,7 @@ extern "C" int slh_gemm(const slh_gemm_desc* d, slh_stream_t stream) {
     a.ld_rowbias = d->ld_rowbias; a.rows_per_sample = d->rows_per_sample > 0 ? d->rows_per_sample : 1;
     a.ld_t = d->ld_t; a.lora_cols_per_group = d->lora_t ? d->N / d->lora_groups : 1;
     a.ld_res = d->ld_res; a.ldc = d->ldc; a.geglu = d->geglu;
+    a.lora_rank = d->lora_rank > 0 ? d->lora_rank : 4; a.lora_up_rmajor = d->lora_up_rmajor;
     a.tiles_m = (d->M + 64 * MI - 1) / (64 * MI);
     a.tiles_n = (d->N + 64 * NI - 1) / (64 * NI);
     hipStream_t s = (hipStream_t)stream;

@@ -22,7 +22,7 @@ struct AddrArgs {  // shared A-operand addressing (same meaning as slh_gemm_desc
 template <int RMAX>
 __global__ __launch_bounds__(256) void skinny_kernel(AddrArgs A, const __bf16* __restrict__ w,
                                                      const __bf16* __restrict__ bias, void* out,
-                                                     int M, int R, int K, int ldo, int out_kind) {
+                                                     int M, int R, int K, int ldo, int out_kind, int kmajor) {
     const int tid = threadIdx.x;
     const int sub = tid & 15;
     const int m = blockIdx.x * 16 + (tid >> 4);
@@ -38,6 +38,21 @@ __global__ __launch_bounds__(256) void skinny_kernel(AddrArgs A, const __bf16* _
         float xf[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) xf[e] = (float)x[e];
+        if (kmajor) {
+            // W given as [K][4] (the lora_up layout [out][r] read as a down-projection of the output gradient)
+            if (RMAX == 4) {
+#pragma unroll
+                for (int h = 0; h < 4; ++h) {
+                    const bf16x8 wv = *(const bf16x8*)(w + (long)k * 4 + h * 8);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        acc[r] += xf[2 * h] * (float)wv[r];
+                        acc[r] += xf[2 * h + 1] * (float)wv[4 + r];
+                    }
+                }
+            }
+            return;
+        }
 #pragma unroll
         for (int r = 0; r < RMAX; ++r) {
             if (r < R) {
@@ -264,6 +279,7 @@ extern "C" int slh_skinny(const slh_skinny_desc* d, slh_stream_t stream) {
         SLH_CHECK(d->stride == 1 || d->stride == 2, "slh_skinny: stride");
     }
     if (d->out_kind == 1) SLH_CHECK(d->mode == 1, "slh_skinny: NCHW output needs conv geometry");
+    if (d->w_kmajor) SLH_CHECK(d->R == 4 && d->mode == 0 && !d->bias, "slh_skinny: w_kmajor needs dense R=4");
     AddrArgs A;
     fill_addr(A, d->a0, d->a1, d->lda0, d->lda1, d->ca0, d->ca1, d->mode, d->hs, d->ws, d->src_xform, d->stride,
               d->ho, d->wo);
@@ -271,13 +287,13 @@ extern "C" int slh_skinny(const slh_skinny_desc* d, slh_stream_t stream) {
     hipStream_t s = (hipStream_t)stream;
     if (d->R <= 4)
         hipLaunchKernelGGL(skinny_kernel<4>, dim3(grid), dim3(256), 0, s, A, (const __bf16*)d->w,
-                           (const __bf16*)d->bias, d->out, d->M, d->R, d->K, d->ldo, d->out_kind);
+                           (const __bf16*)d->bias, d->out, d->M, d->R, d->K, d->ldo, d->out_kind, d->w_kmajor);
     else if (d->R <= 12)
         hipLaunchKernelGGL(skinny_kernel<12>, dim3(grid), dim3(256), 0, s, A, (const __bf16*)d->w,
-                           (const __bf16*)d->bias, d->out, d->M, d->R, d->K, d->ldo, d->out_kind);
+                           (const __bf16*)d->bias, d->out, d->M, d->R, d->K, d->ldo, d->out_kind, d->w_kmajor);
     else
         hipLaunchKernelGGL(skinny_kernel<16>, dim3(grid), dim3(256), 0, s, A, (const __bf16*)d->w,
-                           (const __bf16*)d->bias, d->out, d->M, d->R, d->K, d->ldo, d->out_kind);
+                           (const __bf16*)d->bias, d->out, d->M, d->R, d->K, d->ldo, d->out_kind, d->w_kmajor);
     SLH_LAUNCH_CHECK("slh_skinny");
     return 0;
 }
@@ -315,5 +331,104 @@ extern "C" int slh_lora_wgrad(const slh_wgrad_desc* d, slh_stream_t stream) {
     if (d->R == 4) hipLaunchKernelGGL(wgrad_kernel<4>, grid, dim3(256), 0, s, p);
     else hipLaunchKernelGGL(wgrad_kernel<12>, grid, dim3(256), 0, s, p);
     SLH_LAUNCH_CHECK("slh_lora_wgrad");
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Backward-data contribution of a 3x3 LoRA down conv:  gx[i][c] (+)= s * sum_{tap,r} U[o(i,tap)][r] * A[r][tap][c]
+// with o*stride + tap - 1 = i.  Thread = (input pixel, 8-channel chunk).  HBM-bound on gx.
+// ------------------------------------------------------------------------------------------------
+namespace {
+__global__ __launch_bounds__(256) void lora_conv_dgrad_kernel(const slh_lora_cdgrad_desc d) {
+    const int nchunk = d.cin / 8;
+    const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long total = (long)d.batch * d.hl * d.wl * nchunk;
+    if (gid >= total) return;
+    const int chunk = (int)(gid % nchunk);
+    const long pix = gid / nchunk;
+    const int hw = d.hl * d.wl;
+    const int b = (int)(pix / hw);
+    const int rem = (int)(pix - (long)b * hw);
+    const int iy = rem / d.wl, ix = rem - iy * d.wl;
+    const int c = chunk * 8;
+    const __bf16* A = (const __bf16*)d.a_down;
+    const int K = 9 * d.cin;
+    float acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+    for (int tap = 0; tap < 9; ++tap) {
+        const int ky = tap / 3, kx = tap - ky * 3;
+        const int ty = iy + 1 - ky, tx = ix + 1 - kx;
+        if (ty < 0 || tx < 0) continue;
+        if (d.stride == 2 && ((ty | tx) & 1)) continue;
+        const int oy = ty / d.stride, ox = tx / d.stride;
+        if (oy >= d.ho || ox >= d.wo) continue;
+        const f32x4 u = *(const f32x4*)(d.u + ((long)b * d.ho * d.wo + (long)oy * d.wo + ox) * d.ldu);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const bf16x8 a = *(const bf16x8*)(A + (long)r * K + tap * d.cin + c);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] += u[r] * (float)a[e];
+        }
+    }
+    const float s = *d.scale;
+    __bf16* g = (__bf16*)d.gx + pix * d.ldgx + c;
+    bf16x8 o;
+    if (d.accumulate) o = *(const bf16x8*)g;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (__bf16)(s * acc[e] + (d.accumulate ? (float)o[e] : 0.f));
+    *(bf16x8*)g = o;
+}
+
+// LoRA gradients of one ResnetBlock2D.time_emb_proj (a [1 x ted] x [ted x C] linear applied to silu(emb)):
+//   d_up[c][r] += s * g[c] * T[r];  U[r] = sum_c g[c] * up[c][r];  d_down[r][k] += s * U[r] * silu(emb[k])
+__global__ __launch_bounds__(256) void temb_lora_bwd_kernel(const slh_temb_lora_bwd_desc d) {
+    __shared__ float red[4][4];
+    __shared__ float U[4];
+    const int tid = threadIdx.x;
+    const float s = *d.scale;
+    float t[4], part[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int r = 0; r < 4; ++r) t[r] = d.t[r];
+    for (int c = tid; c < d.C; c += 256) {
+        const float g = d.g[c];
+        const bf16x4 u = *(const bf16x4*)((const __bf16*)d.up + (long)c * 4);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            part[r] += g * (float)u[r];
+            d.d_up[(long)c * 4 + r] += s * g * t[r];
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) part[r] = wave_sum(part[r]);
+    if ((tid & 63) == 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[tid >> 6][r] = part[r];
+    }
+    __syncthreads();
+    if (tid < 4) U[tid] = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
+    __syncthreads();
+    for (int k = tid; k < d.ted; k += 256) {
+        const float x = round_bf16(silu_f((float)((const __bf16*)d.emb)[k]));
+#pragma unroll
+        for (int r = 0; r < 4; ++r) d.d_down[(long)r * d.ted + k] += s * U[r] * x;
+    }
+}
+}  // namespace
+
+extern "C" int slh_lora_conv_dgrad(const slh_lora_cdgrad_desc* d, slh_stream_t stream) {
+    SLH_CHECK(d && d->u && d->a_down && d->scale && d->gx, "slh_lora_conv_dgrad: null pointer");
+    SLH_CHECK(d->cin % 8 == 0 && d->ldgx % 8 == 0 && d->ldu % 4 == 0 && (d->stride == 1 || d->stride == 2),
+              "slh_lora_conv_dgrad: bad shape");
+    const long total = (long)d->batch * d->hl * d->wl * (d->cin / 8);
+    hipLaunchKernelGGL(lora_conv_dgrad_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, *d);
+    SLH_LAUNCH_CHECK("slh_lora_conv_dgrad");
+    return 0;
+}
+
+extern "C" int slh_temb_lora_bwd(const slh_temb_lora_bwd_desc* d, slh_stream_t stream) {
+    SLH_CHECK(d && d->g && d->t && d->up && d->emb && d->d_up && d->d_down && d->scale, "slh_temb_lora_bwd: null pointer");
+    hipLaunchKernelGGL(temb_lora_bwd_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, *d);
+    SLH_LAUNCH_CHECK("slh_temb_lora_bwd");
     return 0;
 }

@@ -174,10 +174,12 @@ __global__ __launch_bounds__(256) void cfg_ddim_kernel(const slh_cfg_ddim_desc d
     // DDIMScheduler.step, eta = 0, epsilon prediction, fp32 0-dim scalars times bf16 tensors
     const float r1 = round_bf16(d.c_sqrt_beta_t * e);
     const float r2 = round_bf16(x - r1);
-    const float x0 = round_bf16(r2 / d.c_sqrt_alpha_t);
+    const float x0 = round_bf16(r2 * d.c_inv_sqrt_alpha_t);  // torch CUDA divides by a CPU scalar as a * (1/b)
     const float dir = round_bf16(d.c_dir * e);
     const float r3 = round_bf16(d.c_sqrt_alpha_prev * x0);
-    ((__bf16*)d.out)[i] = (__bf16)(r3 + dir);
+    const __bf16 res = (__bf16)(r3 + dir);
+    ((__bf16*)d.out)[i] = res;
+    if (d.out2) ((__bf16*)d.out2)[i] = res;
 }
 
 // ---- guidance loss (prompt_util.py:108-148) --------------------------------------------------------------
@@ -194,7 +196,14 @@ __global__ __launch_bounds__(256) void loss_kernel(const slh_loss_desc d) {
         const float y = round_bf16(d.erase ? ne - d2 : ne + d2);
         const float diff = tg - y;
         sq = diff * diff;
-        if (d.dtarget) ((__bf16*)d.dtarget)[i] = (__bf16)((2.0f / (float)d.n) * diff);
+        const __bf16 gq = (__bf16)((2.0f / (float)d.n) * diff);
+        if (d.dtarget) ((__bf16*)d.dtarget)[i] = gq;
+        if (d.dtarget_pix) {
+            const int per = d.nch * d.hw;
+            const int b = i / per, rem = i - b * per;
+            const int ch = rem / d.hw, px = rem - ch * d.hw;
+            d.dtarget_pix[((long)b * d.hw + px) * d.nch + ch] = (float)gq;
+        }
     }
     sq = wave_sum(sq);
     __shared__ float part[4];

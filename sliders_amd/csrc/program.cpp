@@ -60,6 +60,10 @@ extern "C" int slh_run_program(const void* program, int64_t nbytes, slh_stream_t
             case SLH_OP_LAYERNORM_BWD:
                 rc = run_desc<slh_ln_bwd_desc>(p, sz, slh_layernorm_bwd, stream, "layernorm_bwd"); break;
             case SLH_OP_ATTN_BWD: rc = run_desc<slh_attn_bwd_desc>(p, sz, slh_attn_bwd, stream, "attn_bwd"); break;
+            case SLH_OP_LORA_CONV_DGRAD:
+                rc = run_desc<slh_lora_cdgrad_desc>(p, sz, slh_lora_conv_dgrad, stream, "lora_conv_dgrad"); break;
+            case SLH_OP_TEMB_LORA_BWD:
+                rc = run_desc<slh_temb_lora_bwd_desc>(p, sz, slh_temb_lora_bwd, stream, "temb_lora_bwd"); break;
             case SLH_OP_MEMSET: {
                 if (sz != (int32_t)sizeof(slh_memset_desc)) { slh_set_error("slh_run_program: memset desc size"); return -3; }
                 slh_memset_desc d;
@@ -86,7 +90,8 @@ extern "C" int slh_desc_sizes(int32_t* out, int32_t cap) {
         (int32_t)sizeof(slh_ln_bwd_desc),   (int32_t)sizeof(slh_attn_desc),     (int32_t)sizeof(slh_transpose_desc),
         (int32_t)sizeof(slh_attn_bwd_desc), (int32_t)sizeof(slh_tembed_desc),   (int32_t)sizeof(slh_convin_desc),
         (int32_t)sizeof(slh_ew_desc),       (int32_t)sizeof(slh_cfg_ddim_desc), (int32_t)sizeof(slh_loss_desc),
-        (int32_t)sizeof(slh_wgrad_desc),    (int32_t)sizeof(slh_adamw_desc),    (int32_t)sizeof(slh_memset_desc)};
+        (int32_t)sizeof(slh_wgrad_desc),    (int32_t)sizeof(slh_adamw_desc),    (int32_t)sizeof(slh_memset_desc),
+        (int32_t)sizeof(slh_lora_cdgrad_desc), (int32_t)sizeof(slh_temb_lora_bwd_desc)};
     const int n = (int)(sizeof(sizes) / sizeof(sizes[0]));
     for (int i = 0; i < n && i < cap; ++i) out[i] = sizes[i];
     return n;

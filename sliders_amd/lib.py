@@ -32,10 +32,10 @@ GemmDesc = _struct("GemmDesc", _ptrs("a0", "a1", "w", "bias", "rowbias", "lora_t
                                      "residual", "c")
                    + _ints("lda0", "lda1", "ca0", "ca1", "mode", "batch", "hs", "ws", "src_xform", "stride",
                            "ho", "wo", "ldw", "M", "N", "K", "ld_rowbias", "rows_per_sample", "ld_t",
-                           "lora_groups", "ld_res", "ldc", "geglu", "tile"))
+                           "lora_groups", "ld_res", "ldc", "geglu", "tile", "lora_rank", "lora_up_rmajor"))
 SkinnyDesc = _struct("SkinnyDesc", _ptrs("a0", "a1", "w", "bias", "out")
                      + _ints("lda0", "lda1", "ca0", "ca1", "mode", "batch", "hs", "ws", "src_xform", "stride",
-                             "ho", "wo", "M", "R", "K", "ldo", "out_kind"))
+                             "ho", "wo", "M", "R", "K", "ldo", "out_kind", "w_kmajor"))
 GemvDesc = _struct("GemvDesc", _ptrs("x", "w", "bias", "addend", "lora_t", "lora_tcol", "lora_up", "lora_scale", "y")
                    + _ints("nb", "N", "K", "ldx", "ld_add", "ld_t", "ldy", "in_act", "out_f32"))
 GnDesc = _struct("GnDesc", _ptrs("x0", "x1", "gamma", "beta", "stats", "y")
@@ -51,18 +51,19 @@ LnBwdDesc = _struct("LnBwdDesc", _ptrs("x", "gamma", "dy", "mean_rstd", "dx")
 AttnDesc = _struct("AttnDesc", _ptrs("q", "k", "vt", "o", "lse")
                    + _ints("B", "H", "Tq", "Tk", "ldq", "ldk", "ldvt", "ldo") + [("scale", c_f32)])
 TransposeDesc = _struct("TransposeDesc", _ptrs("src", "dst") + _ints("B", "H", "T", "ld", "ldt"))
-AttnBwdDesc = _struct("AttnBwdDesc", _ptrs("q", "k", "v", "o", "d_o", "lse", "dq", "dk", "dv", "delta")
-                      + _ints("B", "H", "Tq", "Tk", "ldq", "ldk", "ldv", "ldo", "lddo", "lddq", "lddk", "lddv")
+AttnBwdDesc = _struct("AttnBwdDesc", _ptrs("q", "k", "v", "o", "d_o", "kt", "qt", "dot", "lse", "delta", "dq", "dk", "dv")
+                      + _ints("B", "H", "Tq", "Tk", "ldq", "ldk", "ldv", "ldo", "lddo", "ldkt", "ldqt", "lddq", "lddk",
+                              "lddv")
                       + [("scale", c_f32)] + _ints("need_dkv"))
 TembedDesc = _struct("TembedDesc", _ptrs("vals", "out") + _ints("nb", "n_vals", "dim", "ldo", "col0"))
 ConvInDesc = _struct("ConvInDesc", _ptrs("x", "w", "bias", "y") + _ints("batch", "cin", "h", "wd", "cout", "ldy"))
 EwDesc = _struct("EwDesc", _ptrs("a", "b", "out") + _ints("M", "C", "lda", "ldb", "ldo", "op", "iarg", "iarg2")
                  + [("alpha", c_f32)] + _ints("pad_"))
-CfgDdimDesc = _struct("CfgDdimDesc", _ptrs("eps", "x", "out") + _ints("nb", "chw")
-                      + [("guidance", c_f32), ("c_sqrt_beta_t", c_f32), ("c_sqrt_alpha_t", c_f32),
+CfgDdimDesc = _struct("CfgDdimDesc", _ptrs("eps", "x", "out", "out2") + _ints("nb", "chw")
+                      + [("guidance", c_f32), ("c_sqrt_beta_t", c_f32), ("c_inv_sqrt_alpha_t", c_f32),
                          ("c_sqrt_alpha_prev", c_f32), ("c_dir", c_f32)] + _ints("do_step"))
-LossDesc = _struct("LossDesc", _ptrs("target", "positive", "neutral", "uncond", "loss", "dtarget")
-                   + _ints("n") + [("guidance", c_f32)] + _ints("erase"))
+LossDesc = _struct("LossDesc", _ptrs("target", "positive", "neutral", "uncond", "loss", "dtarget", "dtarget_pix")
+                   + _ints("n") + [("guidance", c_f32)] + _ints("erase", "hw", "nch"))
 WgradDesc = _struct("WgradDesc", _ptrs("z0", "z1", "v", "out", "scale")
                     + _ints("ldz0", "ldz1", "c0", "c1", "mode", "batch", "hs", "ws", "src_xform", "stride", "ho",
                             "wo", "M", "R", "ldv", "ldo", "out_rmajor", "vgroup_cols"))
@@ -70,15 +71,20 @@ AdamwDesc = _struct("AdamwDesc", _ptrs("param", "exp_avg", "exp_avg_sq", "grad")
                     + [(n, c_f64) for n in ("lr", "beta1", "beta2", "eps", "weight_decay")]
                     + _ints("step") + [("grad_scale", c_f32)])
 MemsetDesc = _struct("MemsetDesc", _ptrs("ptr") + [("nbytes", c_i64)] + _ints("value", "pad"))
+LoraCdgradDesc = _struct("LoraCdgradDesc", _ptrs("u", "a_down", "scale", "gx")
+                         + _ints("batch", "hl", "wl", "ho", "wo", "stride", "cin", "ldu", "ldgx", "accumulate"))
+TembLoraBwdDesc = _struct("TembLoraBwdDesc", _ptrs("g", "t", "up", "emb", "d_up", "d_down", "scale") + _ints("C", "ted"))
 
 # order of slh_desc_sizes()
 _SIZE_ORDER = [GemmDesc, SkinnyDesc, GemvDesc, GnDesc, GnBwdDesc, LnDesc, LnBwdDesc, AttnDesc, TransposeDesc,
-               AttnBwdDesc, TembedDesc, ConvInDesc, EwDesc, CfgDdimDesc, LossDesc, WgradDesc, AdamwDesc, MemsetDesc]
+               AttnBwdDesc, TembedDesc, ConvInDesc, EwDesc, CfgDdimDesc, LossDesc, WgradDesc, AdamwDesc, MemsetDesc,
+               LoraCdgradDesc, TembLoraBwdDesc]
 
 # opcodes (enum in sliders_hip.h)
 OP_GEMM, OP_SKINNY, OP_GEMV, OP_GN_STATS, OP_GN_APPLY, OP_LAYERNORM, OP_ATTN_FWD, OP_TRANSPOSE_HEADS = range(1, 9)
 OP_TEMBED, OP_CONV_IN, OP_ELEMENTWISE, OP_CFG_DDIM, OP_LOSS, OP_WGRAD, OP_ADAMW = range(9, 16)
 OP_GN_BWD_STATS, OP_GN_BWD_APPLY, OP_LAYERNORM_BWD, OP_ATTN_BWD, OP_MEMSET = range(16, 21)
+OP_LORA_CONV_DGRAD, OP_TEMB_LORA_BWD = 21, 22
 
 EW_COPY, EW_ADD, EW_GEGLU_FWD, EW_GEGLU_BWD, EW_UPSAMPLE_BWD, EW_COLSUM = range(6)
 
@@ -93,6 +99,7 @@ _ENTRY = {
     OP_WGRAD: ("slh_lora_wgrad", WgradDesc), OP_ADAMW: ("slh_adamw", AdamwDesc),
     OP_GN_BWD_STATS: ("slh_gn_bwd_stats", GnBwdDesc), OP_GN_BWD_APPLY: ("slh_gn_bwd_apply", GnBwdDesc),
     OP_LAYERNORM_BWD: ("slh_layernorm_bwd", LnBwdDesc), OP_ATTN_BWD: ("slh_attn_bwd", AttnBwdDesc),
+    OP_LORA_CONV_DGRAD: ("slh_lora_conv_dgrad", LoraCdgradDesc), OP_TEMB_LORA_BWD: ("slh_temb_lora_bwd", TembLoraBwdDesc),
 }
 
 EXPORTS = ["slh_version", "slh_last_error", "slh_run_program", "slh_desc_sizes"] + [v[0] for v in _ENTRY.values()]

@@ -231,7 +231,7 @@ class UNetPlan:
         self.prog.add(lib.OP_TRANSPOSE_HEADS, lib.TransposeDesc(src=v.ptr, dst=vt.ptr, B=B, H=heads, T=Tk, ld=v.ld, ldt=ldt),
                       name + ".vt")
         o = self.act(q.B, q.H, q.W, C, name)
-        lse = self.f32((B, heads, Tq), name + ".lse") if self.train else None
+        lse = self.f32((B * heads * Tq + 64,), name + ".lse") if self.train else None   # padded: bwd reads by 64s
         d = lib.AttnDesc(q=q.ptr, k=k.ptr, vt=vt.ptr, o=o.ptr, lse=lse.ptr if lse else 0, B=B, H=heads, Tq=Tq, Tk=Tk,
                          ldq=q.ld, ldk=k.ld, ldvt=ldt, ldo=o.ld, scale=64 ** -0.5)
         self.prog.add(lib.OP_ATTN_FWD, d, name)
@@ -335,6 +335,8 @@ class UNetPlan:
         n2 = self.layernorm(h1, path + ".norm2", path + ".norm2")
         q2 = self.gemm(n2, a2 + ".q", C, a2 + ".q", bias=False, lora_paths=[a2 + ".to_q"])
         kv = self.gemm(ctx, a2 + ".kv", 2 * C, a2 + ".kv", bias=False, lora_paths=[a2 + ".to_k", a2 + ".to_v"])
+        if self._lora_group([a2 + ".to_k", a2 + ".to_v"]) is None:
+            self.nograd_kv.add(kv.buf.ptr)      # text K/V carry no gradient unless they are adapted
         o2 = self.attention(q2, kv.cols(0, C), kv.cols(C, C), self.ctx_len, heads, a2 + ".sdpa")
         h2 = self.gemm(o2, a2 + ".out", C, a2 + ".out", residual=h1, lora_paths=[a2 + ".to_out.0"])
         n3 = self.layernorm(h2, path + ".norm3", path + ".norm3")
@@ -365,6 +367,8 @@ class UNetPlan:
         ctxb = self.io["ctx"]
         self.ctx = Act(ctxb.ptr, B, 1, self.ctx_len, cfg.cross_attention_dim, cfg.cross_attention_dim, ctxb, "ctx")
         h = self.act(B, H, W, boc[0], "conv_in")
+        self.nograd = {ctxb.ptr, h.buf.ptr}     # nothing trainable upstream of these
+        self.nograd_kv = set()
         self.prog.add(lib.OP_CONV_IN, lib.ConvInDesc(x=self.io["sample"].ptr, w=self.w.ptr("conv_in.w"),
                                                      bias=self.w.ptr("conv_in.b"), y=h.ptr, batch=B,
                                                      cin=cfg.in_channels, h=H, wd=W, cout=boc[0], ldy=h.ld), "conv_in")
@@ -408,3 +412,288 @@ class UNetPlan:
                     out=self.io["eps"], bias_ptr=self.w.ptr("conv_out.b"), out_kind=1)
         if self.train:
             self.tape.append(dict(op="conv_out", x=g, name="conv_out"))
+
+
+# ======================================================================================================
+# backward through the frozen net into the LoRA adapters (loss.backward(), train_lora_xl.py:345)
+# ======================================================================================================
+class BackwardPlan:
+    """Reverse walk over a train-mode UNetPlan's tape.  Gradients flow only for samples [b0, b0+nb): in the
+    reference's CFG pair the unconditional half receives an exactly-zero gradient (d/du of u + 1*(t-u) is
+    1 - 1 = 0 in bf16, train_util.py:250-253 with guidance_scale=1), so its backward is skipped.
+
+    Every backward-data product reuses slh_gemm with the pre-transposed frozen weights; LoRA gradients are
+    skinny reductions (slh_skinny with the up matrix as a [K][4] down-projection of dY, slh_lora_wgrad)."""
+
+    def __init__(self, fwd: UNetPlan, b0: int, nb: int, one_ptr: int):
+        assert fwd.train and fwd.lora is not None
+        self.f = fwd
+        self.cfg, self.w, self.arena, self.zarena, self.lora = fwd.cfg, fwd.w, fwd.arena, fwd.zarena, fwd.lora
+        self.b0, self.nb = b0, nb
+        self.one_ptr = one_ptr
+        self.scale_ptr = fwd.lora_scale_ptr
+        self.prog = lib.Program()
+        self._g: Dict[int, Act] = {}          # base buffer ptr -> full-width gradient buffer (nb samples)
+        self._written = set()
+        zmark = self.zarena.mark()
+        H, W = fwd.H, fwd.W
+        self.deps_pix = self.arena.alloc((nb * H * W, 4), torch.float32, "bwd.deps_pix")
+        self._walk()
+        zend = self.zarena.mark()
+        head = lib.Program()
+        if zend > zmark:
+            p, n = self.zarena.region(zmark, zend)
+            head.memset(p, n, 0, "zero_bwd_stats")
+        head.extend(self.prog)
+        self.prog = head
+
+    # ---- gradient buffers ------------------------------------------------------------------------
+    def _sl(self, a: Act) -> Act:
+        return a.sample(self.b0, self.nb)
+
+    def grad(self, a: Act, write: bool = True):
+        """(gradient view matching `a` for the selected samples, accumulate?)"""
+        base = a.buf.ptr
+        g = self._g.get(base)
+        if g is None:
+            rows = self.nb * a.HW
+            buf = self.arena.alloc((rows, a.ld), torch.bfloat16, "g:" + a.name)
+            g = Act(buf.ptr, self.nb, a.H, a.W, a.ld, a.ld, buf, "g:" + a.name)
+            self._g[base] = g
+        c0 = ((a.ptr - a.buf.ptr) // 2) % a.ld
+        view = Act(g.ptr + 2 * c0, self.nb, a.H, a.W, a.C, g.ld, g.buf, g.name)
+        key = (base, c0, a.C)
+        acc = key in self._written
+        if write:
+            self._written.add(key)
+        return view, acc
+
+    def has_grad(self, a: Act) -> bool:
+        """True once any column range of a's buffer has received a gradient."""
+        return any(k[0] == a.buf.ptr for k in self._written)
+
+    def alias_grad(self, a: Act, g: Act):
+        self._g[a.buf.ptr] = Act(g.ptr, g.B, g.H, g.W, a.ld, g.ld, g.buf, g.name)
+        self._written.add((a.buf.ptr, 0, a.C))
+
+    # ---- op emitters -----------------------------------------------------------------------------
+    def _ew(self, op, a: Act, out: Act, b: Optional[Act] = None, name="", C=None, iarg=0, iarg2=0, M=None):
+        d = lib.EwDesc(a=a.ptr, b=b.ptr if b else 0, out=out.ptr, M=M if M is not None else a.M, C=C or a.C, lda=a.ld,
+                       ldb=b.ld if b else 0, ldo=out.ld, op=op, iarg=iarg, iarg2=iarg2)
+        self.prog.add(lib.OP_ELEMENTWISE, d, name)
+
+    def add_into(self, dst_fwd: Act, src: Act, name: str):
+        g, acc = self.grad(dst_fwd)
+        if acc:
+            self._ew(lib.EW_ADD, g, g, src, name + ".add")
+        else:
+            self._ew(lib.EW_COPY, src, g, name=name + ".copy")
+
+    def _walk(self):
+        f = self.f
+        for rec in reversed(f.tape):
+            getattr(self, "_b_" + rec["op"])(rec)
+
+    def _b_conv_out(self, rec):
+        x = rec["x"]
+        gx, acc = self.grad(x)
+        d = lib.LoraCdgradDesc(u=self.deps_pix.ptr, a_down=self.w.ptr("conv_out.w"), scale=self.one_ptr, gx=gx.ptr,
+                               batch=self.nb, hl=x.H, wl=x.W, ho=x.H, wo=x.W, stride=1, cin=x.C, ldu=4, ldgx=gx.ld,
+                               accumulate=1 if acc else 0)
+        self.prog.add(lib.OP_LORA_CONV_DGRAD, d, "bwd.conv_out")
+
+    def _b_gn(self, rec):
+        x0, x1 = _src_parts(rec["x"])
+        y = rec["out"]
+        if not self.has_grad(y):
+            return
+        need0 = x0.buf.ptr not in self.f.nograd
+        need1 = x1 is not None and x1.buf.ptr not in self.f.nograd
+        if not (need0 or need1):
+            return
+        gy, _ = self.grad(y, write=False)
+        G = self.cfg.norm_num_groups
+        bst = self.zarena.alloc((self.nb, G, 2), torch.float32, "bwd." + rec["name"] + ".bstats")
+        x0s = self._sl(x0)
+        x1s = self._sl(x1) if x1 is not None else None
+        g0, a0 = self.grad(x0) if need0 else (None, False)
+        g1, a1 = self.grad(x1) if need1 else (None, False)
+        st = rec["stats"].ptr + 4 * self.b0 * G * 2
+        d = lib.GnBwdDesc(x0=x0s.ptr, x1=x1s.ptr if x1s else 0, gamma=self.w.ptr(rec["wname"] + ".g"),
+                          beta=self.w.ptr(rec["wname"] + ".b"), stats=st, bstats=bst.ptr, dy=gy.ptr,
+                          dx0=g0.ptr if g0 else 0, dx1=g1.ptr if g1 else 0, ldx0=x0s.ld, ldx1=x1s.ld if x1s else 0,
+                          c0=x0.C, c1=x1.C if x1 is not None else 0, batch=self.nb, hw=x0.HW, groups=G, lddy=gy.ld,
+                          lddx0=g0.ld if g0 else 0, lddx1=g1.ld if g1 else 0, eps=rec["eps"], act=rec["act"],
+                          accumulate0=1 if a0 else 0, accumulate1=1 if a1 else 0)
+        self.prog.add(lib.OP_GN_BWD_STATS, d, "bwd." + rec["name"] + ".stats")
+        self.prog.add(lib.OP_GN_BWD_APPLY, d, "bwd." + rec["name"] + ".apply")
+
+    def _b_ln(self, rec):
+        x, y = rec["x"], rec["out"]
+        if not self.has_grad(y):
+            return
+        gy, _ = self.grad(y, write=False)
+        gx, acc = self.grad(x)
+        xs = self._sl(x)
+        mr = rec["mr"].ptr + 4 * 2 * self.b0 * x.HW
+        d = lib.LnBwdDesc(x=xs.ptr, gamma=self.w.ptr(rec["wname"] + ".g"), dy=gy.ptr, mean_rstd=mr, dx=gx.ptr,
+                          M=xs.M, C=x.C, ldx=xs.ld, lddy=gy.ld, lddx=gx.ld, accumulate=1 if acc else 0)
+        self.prog.add(lib.OP_LAYERNORM_BWD, d, "bwd." + rec["name"])
+
+    def _b_geglu(self, rec):
+        pre, out = rec["pre"], rec["out"]
+        if not self.has_grad(out):
+            return
+        go, _ = self.grad(out, write=False)
+        gp, acc = self.grad(pre)
+        assert not acc
+        ps = self._sl(pre)
+        self._ew(lib.EW_GEGLU_BWD, ps, gp, go, "bwd." + rec["name"], C=out.C)
+
+    def _transpose(self, src: Act, heads: int, T: int, name: str):
+        ldt = (T + 63) // 64 * 64
+        t = self.arena.alloc((self.nb, heads, 64, ldt), torch.bfloat16, name)
+        self.prog.add(lib.OP_TRANSPOSE_HEADS, lib.TransposeDesc(src=src.ptr, dst=t.ptr, B=self.nb, H=heads, T=T,
+                                                                ld=src.ld, ldt=ldt), name)
+        return t, ldt
+
+    def _b_attn(self, rec):
+        q, k, v, o = rec["q"], rec["k"], rec["v"], rec["o"]
+        if not self.has_grad(o):
+            return
+        heads, Tk, Tq = rec["heads"], rec["Tk"], q.HW
+        go, _ = self.grad(o, write=False)
+        need_dkv = 1 if (k.buf.ptr not in self.f.nograd_kv) else 0
+        qs, ks, vs, os_ = self._sl(q), self._sl(k), self._sl(v), self._sl(o)
+        kt, ldkt = self._transpose(ks, heads, Tk, "bwd." + rec["name"] + ".kt")
+        gq, aq = self.grad(q)
+        assert not aq
+        delta = self.arena.alloc((self.nb * heads * Tq + 64,), torch.float32, "bwd." + rec["name"] + ".delta")
+        d = lib.AttnBwdDesc(q=qs.ptr, k=ks.ptr, v=vs.ptr, o=os_.ptr, d_o=go.ptr, kt=kt.ptr,
+                            lse=rec["lse"].ptr + 4 * self.b0 * heads * Tq, delta=delta.ptr, dq=gq.ptr,
+                            B=self.nb, H=heads, Tq=Tq, Tk=Tk, ldq=qs.ld, ldk=ks.ld, ldv=vs.ld, ldo=os_.ld, lddo=go.ld,
+                            ldkt=ldkt, lddq=gq.ld, scale=64 ** -0.5, need_dkv=need_dkv)
+        if need_dkv:
+            qt, ldqt = self._transpose(qs, heads, Tq, "bwd." + rec["name"] + ".qt")
+            dot, _ = self._transpose(go, heads, Tq, "bwd." + rec["name"] + ".dot")
+            gk, ak = self.grad(k)
+            gv, av = self.grad(v)
+            assert not ak and not av
+            d.qt, d.dot, d.ldqt, d.dk, d.dv, d.lddk, d.lddv = qt.ptr, dot.ptr, ldqt, gk.ptr, gv.ptr, gk.ld, gv.ld
+        self.prog.add(lib.OP_ATTN_BWD, d, "bwd." + rec["name"])
+
+    def _b_gemm(self, rec):
+        y = rec["out"]
+        if not self.has_grad(y):
+            return
+        f = self.f
+        name = "bwd." + rec["name"]
+        gy, _ = self.grad(y, write=False)
+        x0, x1 = _src_parts(rec["x"])
+        conv, grp, N, K = rec["conv"], rec["grp"], rec["N"], rec["K"]
+        Ho, Wo = rec["Ho"], rec["Wo"]
+        Ms = self.nb * Ho * Wo
+        # residual branch: d(out)/d(residual) = identity
+        r = rec["residual"]
+        if r is not None and r.buf.ptr not in f.nograd:
+            if r.buf.ptr not in self._g and r.ld == r.C and gy.ld == gy.C and r.C == gy.C:
+                self.alias_grad(r, gy)
+            else:
+                self.add_into(r, gy, name + ".res")
+        # time-embedding add: gradient w.r.t. the per-sample bias feeds the time_emb_proj adapter
+        if rec.get("temb_path") and self.lora.temb_entries:
+            path = rec["temb_path"]
+            i = f.w.resnet_paths.index(path)
+            e = self.lora.temb_entries[i]
+            gsum = self.zarena.alloc((self.nb, N), torch.float32, name + ".gtemb")
+            self._ew(lib.EW_COLSUM, gy, Act(gsum.ptr, self.nb, 1, 1, N, N, gsum), name=name + ".colsum", iarg2=Ho * Wo)
+            ted = self.cfg.time_embed_dim
+            L4 = f.temb_lora_T.shape[1]
+            for s in range(self.nb):
+                d = lib.TembLoraBwdDesc(g=gsum.ptr + 4 * s * N, t=f.temb_lora_T.ptr + 4 * ((self.b0 + s) * L4 + 4 * i),
+                                        up=self.lora.up_ptr(e), emb=f.emb.ptr + 2 * (self.b0 + s) * ted,
+                                        d_up=self.lora.gup_ptr(e), d_down=self.lora.gdown_ptr(e), scale=self.scale_ptr,
+                                        C=N, ted=ted)
+                self.prog.add(lib.OP_TEMB_LORA_BWD, d, name + ".temb_lora")
+        # LoRA: U = dY . B_up per fused member; dB = s dY^T T ; dA = s U^T X
+        U = None
+        if grp is not None:
+            ng = len(grp)
+            Ng = N // ng
+            U = self.arena.alloc((Ms, 4 * ng), torch.float32, name + ".U")
+            T = rec["T"]
+            Ts = T.ptr + 4 * self.b0 * (Ho * Wo) * 4 * ng
+            for g_i, e in enumerate(grp):
+                d = lib.SkinnyDesc(a0=gy.ptr + 2 * g_i * Ng, w=self.lora.up_ptr(e), out=U.ptr + 4 * 4 * g_i, lda0=gy.ld,
+                                   ca0=Ng, mode=0, stride=1, M=Ms, R=4, K=Ng, ldo=4 * ng, w_kmajor=1)
+                self.prog.add(lib.OP_SKINNY, d, name + f".U{g_i}")
+            d = lib.WgradDesc(z0=gy.ptr, v=Ts, out=self.lora.gup_ptr(grp[0]), scale=self.scale_ptr, ldz0=gy.ld, c0=N,
+                              mode=0, stride=1, M=Ms, R=4, ldv=4 * ng, ldo=4, out_rmajor=0,
+                              vgroup_cols=Ng if ng > 1 else 0)
+            self.prog.add(lib.OP_WGRAD, d, name + ".dB")
+            x0s = self._sl(x0)
+            x1s = self._sl(x1) if x1 is not None else None
+            for g_i, e in enumerate(grp):
+                d = lib.WgradDesc(z0=x0s.ptr, z1=x1s.ptr if x1s else 0, v=U.ptr + 4 * 4 * g_i, out=self.lora.gdown_ptr(e),
+                                  scale=self.scale_ptr, ldz0=x0s.ld, ldz1=x1s.ld if x1s else 0, c0=x0.C,
+                                  c1=x1.C if x1 is not None else 0, mode=0, stride=1, M=Ms, R=4, ldv=4 * ng,
+                                  ldo=K, out_rmajor=1, vgroup_cols=0)
+                if conv is not None:
+                    d.mode, d.batch, d.hs, d.ws = 1, self.nb, x0.H, x0.W
+                    d.src_xform, d.stride, d.ho, d.wo = conv.get("xform", 0), conv.get("stride", 1), Ho, Wo
+                self.prog.add(lib.OP_WGRAD, d, name + f".dA{g_i}")
+        # backward data
+        need0 = x0.buf.ptr not in f.nograd
+        need1 = x1 is not None and x1.buf.ptr not in f.nograd
+        if not (need0 or need1):
+            return
+        cin = x0.C + (x1.C if x1 is not None else 0)
+        wT = self.w.ptr(rec["wname"] + ".wT")
+        gyimg = Act(gy.ptr, self.nb, Ho, Wo, N, gy.ld, gy.buf, gy.name)
+        if conv is None:
+            if x1 is None:
+                gx, acc = self.grad(x0)
+                tgt, tacc = gx, acc
+            else:
+                tb = self.arena.alloc((Ms, cin), torch.bfloat16, name + ".gxcat")
+                tgt, tacc = Act(tb.ptr, self.nb, x0.H, x0.W, cin, cin, tb), False
+            d = lib.GemmDesc(a0=gy.ptr, w=wT, c=tgt.ptr, residual=tgt.ptr if tacc else 0, lda0=gy.ld, ca0=N, mode=0,
+                             stride=1, ldw=N, M=Ms, N=cin, K=N, ld_res=tgt.ld, ldc=tgt.ld, rows_per_sample=Ho * Wo)
+            if grp is not None:
+                d.lora_t, d.ld_t, d.lora_up, d.lora_scale = U.ptr, 4 * len(grp), self.lora.down_ptr(grp[0]), self.scale_ptr
+                d.lora_groups, d.lora_rank, d.lora_up_rmajor = 1, 4 * len(grp), 1
+            self.prog.add(lib.OP_GEMM, d, name + ".dgrad")
+            if x1 is not None:
+                if need0:
+                    self.add_into(x0, tgt.cols(0, x0.C), name + ".gx0")
+                if need1:
+                    self.add_into(x1, tgt.cols(x0.C, x1.C), name + ".gx1")
+        else:
+            assert x1 is None
+            xform, stride = conv.get("xform", 0), conv.get("stride", 1)
+            if xform == 1:     # forward read a nearest-2x upsampled image: dgrad lands on the 2h x 2w grid first
+                HL, WL = 2 * x0.H, 2 * x0.W
+                tb = self.arena.alloc((self.nb * HL * WL, cin), torch.bfloat16, name + ".gx_up")
+                tgt, tacc = Act(tb.ptr, self.nb, HL, WL, cin, cin, tb), False
+            else:
+                HL, WL = x0.H, x0.W
+                tgt, tacc = self.grad(x0)
+            d = lib.GemmDesc(a0=gy.ptr, w=wT, c=tgt.ptr, residual=tgt.ptr if tacc else 0, lda0=gy.ld, ca0=N, mode=1,
+                             batch=self.nb, hs=Ho, ws=Wo, src_xform=2 if stride == 2 else 0, stride=1, ho=HL, wo=WL,
+                             ldw=9 * N, M=self.nb * HL * WL, N=cin, K=9 * N, ld_res=tgt.ld, ldc=tgt.ld,
+                             rows_per_sample=HL * WL)
+            self.prog.add(lib.OP_GEMM, d, name + ".dgrad")
+            if grp is not None:
+                d2 = lib.LoraCdgradDesc(u=U.ptr, a_down=self.lora.down_ptr(grp[0]), scale=self.scale_ptr, gx=tgt.ptr,
+                                        batch=self.nb, hl=HL, wl=WL, ho=Ho, wo=Wo, stride=stride, cin=cin, ldu=4,
+                                        ldgx=tgt.ld, accumulate=1)
+                self.prog.add(lib.OP_LORA_CONV_DGRAD, d2, name + ".lora_dgrad")
+            if xform == 1:
+                gx, acc = self.grad(x0)
+                if acc:
+                    t2b = self.arena.alloc((self.nb * x0.HW, cin), torch.bfloat16, name + ".gx_dn")
+                    t2 = Act(t2b.ptr, self.nb, x0.H, x0.W, cin, cin, t2b)
+                    self._ew(lib.EW_UPSAMPLE_BWD, tgt, t2, name=name + ".upsample_bwd", iarg=x0.W, iarg2=x0.HW, M=t2.M)
+                    self._ew(lib.EW_ADD, gx, gx, t2, name + ".add")
+                else:
+                    self._ew(lib.EW_UPSAMPLE_BWD, tgt, gx, name=name + ".upsample_bwd", iarg=x0.W, iarg2=x0.HW, M=gx.M)

@@ -18,7 +18,7 @@ from . import lib
 from .arena import Arena
 from .config import UNetConfig
 from .lora_store import LoraStore
-from .planner import UNetPlan
+from .planner import BackwardPlan, UNetPlan
 from .weights import WeightStore
 
 
@@ -55,6 +55,8 @@ class UNetEngine:
         self.arena: Optional[Arena] = None
         self.zarena = Arena(64 << 20, self.device, "zero-init accumulators")
         self.train_plan: Optional[UNetPlan] = None
+        self.one = torch.ones(1, dtype=torch.float32, device=self.device)
+        self.grad_all_samples = False
 
     # ---- reference-facing no-ops ----------------------------------------------------------------
     def to(self, *a, **k):
@@ -83,15 +85,27 @@ class UNetEngine:
     def _virtual_size(self, B, H, W, mode) -> int:
         va = Arena(1 << 50, None, "virtual")
         vz = Arena(1 << 40, None, "virtualz")
-        UNetPlan(self.cfg, _VirtualWeights(self.weights), va, vz, B, H, W, self.ctx_len,
-                 _VirtualLora(self.lora) if mode != "off" else None, mode, 0)
+        p = UNetPlan(self.cfg, _VirtualWeights(self.weights), va, vz, B, H, W, self.ctx_len,
+                     _VirtualLora(self.lora) if mode != "off" else None, mode, 0)
+        if mode == "train":
+            b0, nb = self._grad_samples(B)
+            BackwardPlan(p, b0, nb, 0)
         return va.high_water
+
+    def _grad_samples(self, B: int):
+        """Samples that receive a non-zero gradient: the text half of the CFG pair (see BackwardPlan)."""
+        if self.grad_all_samples or B == 1:
+            return 0, B
+        return B // 2, B // 2
 
     def _ensure_arena(self, need: int):
         if self.arena is not None and self.arena.capacity >= need:
             return
-        if self.arena is not None and self._plans:
-            raise MemoryError("activation arena too small for a new plan; construct the engine with arena_bytes")
+        # grow: every cached plan holds raw pointers into the old arena, so they are rebuilt lazily
+        self._plans.clear()
+        self.train_plan = None
+        self.arena = None
+        torch.cuda.synchronize()
         cap = max(need, self._arena_bytes or 0)
         self.arena = Arena(cap + (1 << 20), self.device, "activations")
 
@@ -100,19 +114,32 @@ class UNetEngine:
         p = self._plans.get(key)
         if p is not None:
             return p
-        need = self._virtual_size(B, H, W, mode)
+        modes = ["off"] + (["on", "train"] if self.lora is not None else [])
+        need = max(self._virtual_size(B, H, W, m) for m in modes)
         self._ensure_arena(need)
         if mode == "train":
             self.weights.ensure_dgrad()
         # all plans share the activation arena from offset 0: they never run concurrently
         self.arena.reset(0)
-        zmark = self.zarena.mark()
         p = UNetPlan(self.cfg, self.weights, self.arena, self.zarena, B, H, W, self.ctx_len,
                      self.lora if mode != "off" else None, mode, self.lora_scale.data_ptr())
+        if mode == "train":
+            b0, nb = self._grad_samples(B)
+            p.backward = BackwardPlan(p, b0, nb, self.one.data_ptr())
         p.arena_end = self.arena.mark()
-        del zmark
         self._plans[key] = p
         return p
+
+    def run_backward(self, p: Optional[UNetPlan] = None, d_eps: Optional[torch.Tensor] = None):
+        """Backward of the last train-mode forward.  d_eps: gradient w.r.t. the returned epsilon for the
+        gradient-carrying samples, (nb,4,H,W); None if the caller already filled backward.deps_pix
+        (slh_guidance_loss writes it directly).  Accumulates into lora.grads (fp32)."""
+        p = p or self.train_plan
+        bw = p.backward
+        if d_eps is not None:
+            nb, C, H, W = d_eps.shape
+            bw.deps_pix.tensor.copy_(d_eps.to(torch.bfloat16).float().permute(0, 2, 3, 1).reshape(nb * H * W, C))
+        bw.prog.run(torch.cuda.current_stream().cuda_stream)
 
     # ---- the model call ---------------------------------------------------------------------------
     def _mode(self) -> str:
@@ -187,6 +214,12 @@ class _VirtualLora:
         return 0x2000
 
     def up_ptr(self, e):
+        return 0x2000
+
+    def gdown_ptr(self, e):
+        return 0x2000
+
+    def gup_ptr(self, e):
         return 0x2000
 
 

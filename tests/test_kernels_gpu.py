@@ -351,7 +351,7 @@ def test_cfg_ddim_bit_exact(dev):
         cb, ca, cp, cd = sch.step_coefficients(t)
         out = torch.zeros(nb, chw, device=dev, dtype=torch.bfloat16)
         d = lib.CfgDdimDesc(eps=p(eps), x=p(x), out=p(out), nb=nb, chw=chw, guidance=3.0, c_sqrt_beta_t=cb,
-                            c_sqrt_alpha_t=ca, c_sqrt_alpha_prev=cp, c_dir=cd, do_step=1)
+                            c_inv_sqrt_alpha_t=ca, c_sqrt_alpha_prev=cp, c_dir=cd, do_step=1)
         lib.call(lib.OP_CFG_DDIM, d, stream())
         torch.cuda.synchronize()
         e_c, x_c = eps.cpu(), x.cpu()
