@@ -1,0 +1,166 @@
+"""Fused concept-slider training iteration on one MI355X (and data-parallel across N of them).
+
+One iteration = the body of the reference loop trainscripts/textsliders/train_lora_xl.py:162-356
+(train_lora.py:155-309 for SD-1.x):
+
+    k ~ U{1..max_denoising_steps-1}; latents = randn * init_noise_sigma
+    with LoRA on, no grad:   k x [ predict_noise(uncond|target, guidance 3) -> DDIM step ]      (k UNet passes)
+    t = timesteps_1000[int(k*1000/50)]                                                           (quirk D.1 kept)
+    LoRA off, no grad:       positive / neutral / unconditional predictions, guidance 1         (3 UNet passes)
+    LoRA on, grad:           target prediction, guidance 1                                      (1 UNet pass)
+    loss = MSE(target, neutral +- gs*(positive - unconditional)); backward; AdamW
+
+Every UNet pass is one command-buffer replay (slh_run_program); CFG combine + DDIM step, the guidance loss,
+the backward pass and the flat AdamW are HIP kernels; nothing round-trips through the host inside an
+iteration (the reference syncs on loss.item() and empties the allocator cache every iteration).
+Data parallel: ranks train different prompt pairs / noise with a shared k, then ONE all-reduce of the flat
+fp32 LoRA-gradient buffer (RCCL over xGMI via torch.distributed) before the replicated AdamW step.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import Optional
+
+import torch
+
+from . import lib
+from .ddim import DDIMSchedule
+from .lora_store import LoraStore
+from .unet import UNetEngine
+
+
+@dataclass
+class PairEmbeds:
+    """Device-resident CFG-concatenated embeddings of one PromptEmbedsPair (prompt_util.py:71-106):
+    each ctx tensor is cat([unconditional, X]) as concat_embeddings builds it (train_util.py:136-141)."""
+    ctx_target: torch.Tensor          # (2*bs, 77, D)
+    ctx_positive: torch.Tensor
+    ctx_neutral: torch.Tensor
+    ctx_uncond: torch.Tensor
+    pooled_target: Optional[torch.Tensor] = None   # (2*bs, P)  SDXL only
+    pooled_positive: Optional[torch.Tensor] = None
+    pooled_neutral: Optional[torch.Tensor] = None
+    pooled_uncond: Optional[torch.Tensor] = None
+    guidance_scale: float = 1.0
+    action: str = "enhance"
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+class SliderTrainer:
+    def __init__(self, engine: UNetEngine, store: LoraStore, H: int, W: int, batch_size: int = 1,
+                 lr: float = 2e-4, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.01,
+                 max_denoising_steps: int = 50, denoise_guidance: float = 3.0, process_group=None):
+        self.eng, self.store = engine, store
+        self.H, self.W, self.bs = H, W, batch_size
+        self.lr, self.betas, self.eps, self.wd = lr, betas, eps, weight_decay
+        self.nsteps = max_denoising_steps
+        self.denoise_guidance = denoise_guidance
+        self.sched = DDIMSchedule()
+        self.pg = process_group
+        self.world = 1
+        if process_group is not None or (torch.distributed.is_available() and torch.distributed.is_initialized()):
+            self.world = torch.distributed.get_world_size(process_group)
+        dev = engine.device
+        cfg = engine.cfg
+        engine.attach_lora(store) if engine.lora is not store else None
+        shape = (batch_size, cfg.out_channels, H, W)
+        z = lambda: torch.zeros(shape, dtype=torch.bfloat16, device=dev)
+        self.denoised, self.e_pos, self.e_neu, self.e_unc, self.e_tgt = z(), z(), z(), z(), z()
+        self.loss = torch.zeros(1, dtype=torch.float32, device=dev)
+        self.time_ids = None
+        if cfg.is_xl:
+            self.time_ids = torch.tensor([[H * 8.0, W * 8.0, 0.0, 0.0, H * 8.0, W * 8.0]] * (2 * batch_size),
+                                         dtype=torch.float32, device=dev)
+        self.chw = cfg.out_channels * H * W
+        self.t50 = self.sched.make_timesteps(max_denoising_steps)
+        self.t1000 = self.sched.make_timesteps(1000)
+        self.unet_passes = 0
+
+    # ---- helpers ------------------------------------------------------------------------------------
+    def _load_cond(self, p, ctx, pooled):
+        p.io["ctx"].tensor.copy_(ctx)
+        if self.eng.cfg.is_xl:
+            p.io["time_ids"].tensor.copy_(self.time_ids)
+            p.io["add_in"].tensor[:, : self.eng.cfg.pooled_dim].copy_(pooled)
+
+    def _load_latents(self, p, lat):
+        s = p.io["sample"].tensor
+        s[: self.bs].copy_(lat)
+        s[self.bs:].copy_(lat)
+
+    def _cfg(self, p, out, guidance, coeff=None, out2=None, x=None):
+        d = lib.CfgDdimDesc(eps=p.io["eps"].ptr, x=x or 0, out=out, out2=out2 or 0, nb=self.bs, chw=self.chw,
+                            guidance=guidance, do_step=0)
+        if coeff is not None:
+            d.c_sqrt_beta_t, d.c_inv_sqrt_alpha_t, d.c_sqrt_alpha_prev, d.c_dir = coeff
+            d.do_step = 1
+        lib.call(lib.OP_CFG_DDIM, d, _stream())
+
+    def _predict(self, p, lat, ctx, pooled, t, out):
+        self._load_latents(p, lat)
+        self._load_cond(p, ctx, pooled)
+        p.io["t"].tensor.fill_(float(t))
+        p.prog.run(_stream())
+        self.unet_passes += 1
+        self._cfg(p, out.data_ptr(), 1.0)
+
+    # ---- one iteration ------------------------------------------------------------------------------
+    def iteration(self, pair: PairEmbeds, k: int, noise: torch.Tensor) -> torch.Tensor:
+        """noise: (bs,4,H,W) already scaled by init_noise_sigma (=1).  Returns the device loss scalar."""
+        eng, st, bs = self.eng, self.store, self.bs
+        B = 2 * bs
+        s = _stream()
+        # 1. partial denoise with the adapters on (train_lora_xl.py:205-227)
+        eng.set_lora(True, 1.0)
+        p_on = eng.plan(B, self.H, self.W, "on")
+        self._load_cond(p_on, pair.ctx_target, pair.pooled_target)
+        self._load_latents(p_on, noise.to(torch.bfloat16))
+        smp = p_on.io["sample"]
+        half = bs * self.chw * 2
+        for i in range(k):
+            t = self.t50[i]
+            p_on.io["t"].tensor.fill_(float(t))
+            p_on.prog.run(s)
+            self.unet_passes += 1
+            self._cfg(p_on, smp.ptr, self.denoise_guidance, self.sched.step_coefficients(t, self.nsteps),
+                      out2=smp.ptr + half, x=smp.ptr)
+        self.denoised.copy_(smp.tensor[:bs])
+        t_cur = self.t1000[int(k * 1000 / self.nsteps)]
+        # 2. frozen-model predictions, adapters off (train_lora_xl.py:236-295)
+        eng.set_lora(False)
+        p_off = eng.plan(B, self.H, self.W, "off")
+        self._predict(p_off, self.denoised, pair.ctx_positive, pair.pooled_positive, t_cur, self.e_pos)
+        self._predict(p_off, self.denoised, pair.ctx_neutral, pair.pooled_neutral, t_cur, self.e_neu)
+        self._predict(p_off, self.denoised, pair.ctx_uncond, pair.pooled_uncond, t_cur, self.e_unc)
+        # 3. target prediction with the adapters on, kept for backward (train_lora_xl.py:302-322)
+        eng.set_lora(True, 1.0)
+        p_tr = eng.plan(B, self.H, self.W, "train")
+        self._predict(p_tr, self.denoised, pair.ctx_target, pair.pooled_target, t_cur, self.e_tgt)
+        # 4. loss + its gradient, written straight into the backward plan's input (prompt_util.py:108-148)
+        self.loss.zero_()
+        bw = p_tr.backward
+        n = bs * self.chw
+        d = lib.LossDesc(target=self.e_tgt.data_ptr(), positive=self.e_pos.data_ptr(), neutral=self.e_neu.data_ptr(),
+                         uncond=self.e_unc.data_ptr(), loss=self.loss.data_ptr(), dtarget=0,
+                         dtarget_pix=bw.deps_pix.ptr, n=n, guidance=float(pair.guidance_scale),
+                         erase=1 if pair.action == "erase" else 0, hw=self.H * self.W, nch=eng.cfg.out_channels)
+        lib.call(lib.OP_LOSS, d, s)
+        # 5. backward into the flat fp32 gradient buffer, (all-reduce,) AdamW
+        st.grads.zero_()
+        bw.prog.run(s)
+        if self.world > 1:
+            torch.distributed.all_reduce(st.grads, group=self.pg)
+        self.optimizer_step()
+        return self.loss
+
+    def optimizer_step(self):
+        st = self.store
+        st.opt_step += 1
+        d = lib.AdamwDesc(param=st.params.data_ptr(), exp_avg=st.exp_avg.data_ptr(), exp_avg_sq=st.exp_avg_sq.data_ptr(),
+                          grad=st.grads.data_ptr(), n=st.numel, lr=self.lr, beta1=self.betas[0], beta2=self.betas[1],
+                          eps=self.eps, weight_decay=self.wd, step=st.opt_step, grad_scale=1.0 / self.world)
+        lib.call(lib.OP_ADAMW, d, _stream())

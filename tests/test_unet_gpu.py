@@ -115,4 +115,4 @@ def test_unet_forward_parity_with_lora(dev, name, method):
     with nw32:
         e_on = run_oracle(net32, x, 700, ctx, kw, torch.float32)
     print(f"[parity] adapter effect size rel_l2(on, off) = {rel_err(e_on, e_plain):.3e}")
-    assert rel_err(e_on, e_plain) > 1e-2, "test is vacuous: adapters have no visible effect"
+    assert rel_err(e_on, e_plain) > 1e-3, "test is vacuous: adapters have no visible effect"
