@@ -1,0 +1,222 @@
+#!/usr/bin/env python3
+"""Contract benchmark: concept-slider LoRA training throughput in UNet denoise steps/sec.
+
+  python bench.py --gpus N --steps K --warmup W            (N=1)
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[2]): SDXL-base UNet, rank-4 text slider (noxattn + c3lier, alpha 1), 1024x1024
+(latent 128x128), batch 1 (CFG pair B=2), bf16, DDIM-50, AdamW lr 2e-4.  One bench "step" = ONE TRAINING
+ITERATION of the reference loop (train_lora_xl.py:162-356): k partial-denoise UNet passes with the adapters on
+(k ~ U{1..49}, seeded, shared by all ranks), 3 frozen predictions, 1 target prediction with grad, guidance
+loss, backward into the adapters, (all-reduce,) AdamW.  The metric counts UNet denoise steps
+(= predict_noise calls = UNet forwards on a CFG pair): value = sum_i (k_i + 4) * N / wall.
+Weights are seeded random-init with the real SDXL shapes and text embeddings are seeded randn (no checkpoints
+exist offline) - throughput does not depend on the values.
+
+Extra JSON objects: "roofline" for the dominant kernel (bf16 MFMA GEMM instantiation with the largest share
+of a UNet pass; algorithmic FLOPs / HIP-event time, measured live on the launch stream) and "cpu_baseline"
+(the CPU oracle = PyTorch restatement of the reference's diffusers UNet, bf16 oneDNN, one UNet denoise step of
+the same workload, rank 0 at N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+MFMA_PEAK_TFLOPS = 2500.0     # dense bf16, /opt/skills/guides/MI355X_MICROARCH.md
+HBM_PEAK_GBS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=6)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--model", default="sdxl")
+    ap.add_argument("--res", type=int, default=1024)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--seed", type=int, default=0)
+    return ap.parse_args()
+
+
+def gemm_flops(d):
+    n = d.N
+    return 2.0 * d.M * n * d.K
+
+
+def measure_roofline(eng, plan):
+    """Replay every slh_gemm of one adapters-off UNet pass individually between HIP events on the stream the
+    kernels are launched on, grouped by kernel instantiation."""
+    from sliders_amd import lib
+    stream = torch.cuda.current_stream()
+    s = stream.cuda_stream
+    groups = {}
+    plan.prog.run(s)                      # make every input of every op valid
+    torch.cuda.synchronize()
+    reps = 3
+    for opcode, d in plan.prog.ops:
+        if opcode != lib.OP_GEMM:
+            continue
+        var = lib.gemm_variant(d)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        lib.call(lib.OP_GEMM, d, s)      # warm
+        e0.record(stream)
+        for _ in range(reps):
+            lib.call(lib.OP_GEMM, d, s)
+        e1.record(stream)
+        e1.synchronize()
+        ms = e0.elapsed_time(e1) / reps
+        g = groups.setdefault(var, dict(ms=0.0, flops=0.0, calls=0))
+        g["ms"] += ms
+        g["flops"] += gemm_flops(d)
+        g["calls"] += 1
+    var, g = max(groups.items(), key=lambda kv: kv[1]["ms"])
+    mi, ni, mode = var >> 8, (var >> 4) & 15, var & 15
+    achieved = g["flops"] / (g["ms"] * 1e-3) / 1e12
+    table = {f"gemm_kernel<{v >> 8},{(v >> 4) & 15},{v & 15}>": dict(
+        calls_per_pass=x["calls"], ms_per_pass=round(x["ms"], 3), tflops=round(x["flops"] / (x["ms"] * 1e-3) / 1e12, 1))
+        for v, x in sorted(groups.items())}
+    return {
+        "bound": "mfma", "kernel": f"gemm_kernel<{mi}, {ni}, {mode}>",
+        "achieved": round(achieved, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+        "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": None,
+        "flop_per_launch": g["flops"] / g["calls"], "avg_launch_us": round(1e3 * g["ms"] / g["calls"], 2),
+        "launches_per_unet_pass": g["calls"], "all_gemm_variants": table,
+    }
+
+
+def cpu_baseline(model, hw):
+    """One UNet denoise step of the same workload on the host cores with the CPU oracle (bf16 oneDNN)."""
+    from oracle.unet_oracle import build_unet
+    from sliders_amd.config import CONFIGS
+    torch.set_num_threads(os.cpu_count())
+    cfg = CONFIGS[model]()
+    net = build_unet(model, device="meta")
+    # cheap distinct-memory init: values do not matter for timing, but every weight must own its memory
+    g = torch.Generator().manual_seed(0)
+    block = (torch.rand(1 << 22, generator=g) - 0.5) * 0.05
+    sd = {}
+    for k, v in net.state_dict().items():
+        n = v.numel()
+        t = block.repeat((n + block.numel() - 1) // block.numel())[:n].reshape(v.shape).to(torch.bfloat16)
+        if k.endswith("norm.weight") or ".norm1.weight" in k or ".norm2.weight" in k or ".norm3.weight" in k or k == "conv_norm_out.weight":
+            t = torch.ones_like(t)
+        sd[k] = t
+    net.load_state_dict(sd, assign=True)
+    net.eval()
+    B = 2
+    x = torch.randn(B, 4, hw, hw).bfloat16()
+    ctx = torch.randn(B, 77, cfg.cross_attention_dim).bfloat16()
+    kw = None
+    if cfg.is_xl:
+        kw = {"text_embeds": torch.randn(B, cfg.pooled_dim).bfloat16(),
+              "time_ids": torch.tensor([[hw * 8.0, hw * 8.0, 0, 0, hw * 8.0, hw * 8.0]] * B).bfloat16()}
+    with torch.no_grad():
+        t0 = time.time()
+        out = net(x, torch.tensor(500), ctx, kw).sample
+        dt = time.time() - t0
+    assert torch.isfinite(out.float()).all()
+    return {"value": round(1.0 / dt, 4), "unit": "steps/s", "cores": os.cpu_count(), "kind": "port",
+            "sample": f"1 UNet denoise step (CFG pair B=2, {model} {hw * 8}x{hw * 8}, bf16 torch/oneDNN forward, "
+                      f"{dt:.1f} s) with the CPU oracle (PyTorch restatement of the diffusers UNet)"}
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local)
+        torch.distributed.init_process_group("nccl", device_id=torch.device("cuda", local))
+    dev = torch.device("cuda", local if world > 1 else 0)
+    torch.cuda.set_device(dev)
+
+    from sliders_amd.config import CONFIGS
+    from sliders_amd.lora_store import LoraStore
+    from sliders_amd.random_init import random_state_dict
+    from sliders_amd.trainer import PairEmbeds, SliderTrainer
+    from sliders_amd.unet import UNetEngine
+
+    cfg = CONFIGS[a.model]()
+    hw = a.res // 8
+    eng = UNetEngine(cfg, random_state_dict(cfg, dev, a.seed), dev)
+    torch.manual_seed(a.seed)   # identical adapter init on every rank (replicated parameters)
+    store = LoraStore(cfg, rank=4, alpha=1.0, train_method="noxattn", device=dev)
+    tr = SliderTrainer(eng, store, hw, hw, batch_size=1, lr=2e-4)
+
+    # 4 prompts x 2 attributes = 8 PromptEmbedsPairs (BASELINE configs[2]); synthetic CLIP-shaped embeddings
+    g = torch.Generator(device="cpu").manual_seed(1234)
+    pairs = []
+    for i in range(8):
+        e = [torch.randn(1, 77, cfg.cross_attention_dim, generator=g).to(dev, torch.bfloat16) for _ in range(4)]
+        pl = [torch.randn(1, cfg.pooled_dim, generator=g).to(dev, torch.bfloat16) for _ in range(4)] if cfg.is_xl else [None] * 4
+        tgt, pos, neu, unc = e
+        cat = lambda x: torch.cat([unc, x]).contiguous()
+        pcat = (lambda x: torch.cat([pl[3], x]).contiguous()) if cfg.is_xl else (lambda x: None)
+        pairs.append(PairEmbeds(cat(tgt), cat(pos), cat(neu), cat(unc), pcat(pl[0]), pcat(pl[1]), pcat(pl[2]),
+                                pcat(pl[3]), guidance_scale=4.0, action="enhance"))
+    krng = torch.Generator(device="cpu").manual_seed(4321)           # shared across ranks
+    nrng = torch.Generator(device="cpu").manual_seed(1000 + rank)    # per-rank noise
+
+    def one_step(step_idx):
+        k = int(torch.randint(1, 50, (1,), generator=krng).item())
+        pair = pairs[(step_idx * world + rank) % len(pairs)]
+        noise = torch.randn(1, 4, hw, hw, generator=nrng).to(dev)
+        tr.iteration(pair, k, noise)
+        return k
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(a.warmup):
+        one_step(i)
+    barrier()
+    t0 = time.time()
+    unet_steps = 0
+    for i in range(a.steps):
+        unet_steps += one_step(a.warmup + i) + 4
+    barrier()
+    dt = time.time() - t0
+    if world > 1:
+        tdt = torch.tensor([dt], device=dev)
+        torch.distributed.all_reduce(tdt, op=torch.distributed.ReduceOp.MAX)
+        dt = float(tdt.item())
+    loss = float(tr.loss.item())
+
+    res = {
+        "metric": "UNet denoise steps/sec (SDXL rank-4 text slider)",
+        "value": round(unet_steps * world / dt, 3), "unit": "steps/s", "n_gpus": world, "steps": a.steps,
+        "warmup": a.warmup, "ms_per_step": round(1e3 * dt / a.steps, 2), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
+        "data": "synthetic (seeded random-init weights with the real SDXL shapes, randn text embeddings)",
+        "config": {"workload": f"{a.model} text slider rank=4 alpha=1 noxattn+c3lier, {a.res}x{a.res}, batch 1 "
+                               f"(CFG pair), DDIM-50 partial denoise k~U{{1..49}} + 4 predictions + backward + AdamW",
+                   "bench_step": "one training iteration", "unet_denoise_steps_timed": unet_steps * world,
+                   "iterations_per_s": round(a.steps * world / dt, 4), "prompt_pairs": len(pairs),
+                   "parallelism": f"dp{world}", "final_loss": loss},
+    }
+    if rank == 0 and world == 1:
+        if not a.no_roofline:
+            eng.set_lora(False)
+            res["roofline"] = measure_roofline(eng, eng.plan(2, hw, hw, "off"))
+        if not a.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(a.model, hw)
+    if rank == 0:
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -72,6 +72,9 @@ typedef struct slh_gemm_desc {
     int32_t lora_up_rmajor;  /* 1: lora_up is [rank][N] (= lora_down as stored): backward-data LoRA term */
 } slh_gemm_desc;
 int slh_gemm(const slh_gemm_desc* d, slh_stream_t stream);
+/* (MI<<8)|(NI<<4)|mode of the kernel instantiation gemm_kernel<MI,NI,mode> slh_gemm would launch for d
+ * (used by bench.py to attribute measured time and algorithmic FLOPs to one profiled kernel name). */
+int slh_gemm_variant(const slh_gemm_desc* d);
 
 /* ------------------------------------------------------------------------------------------------
  * slh_skinny: T[M][R] = A[M][K] . Wd[R][K]^T (+bias), R <= 16, same A addressing as slh_gemm.

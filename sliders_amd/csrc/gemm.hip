@@ -291,6 +291,26 @@ int launch_gemm(const GemmArgs& a, int mode, hipStream_t s) {
 
 }  // namespace
 
+// tile choice: explicit (d->tile, set by the planner from the tuned table) or a fill-the-chip heuristic
+static void pick_tile(const slh_gemm_desc* d, int& MI, int& NI) {
+    MI = 2; NI = 2;
+    if (d->tile) {
+        MI = (d->tile >> 4) & 15; NI = d->tile & 15;
+        return;
+    }
+    auto tiles = [&](int mi, int ni) { return ((d->M + 64 * mi - 1) / (64 * mi)) * ((d->N + 64 * ni - 1) / (64 * ni)); };
+    if (tiles(2, 2) < 384) { MI = 2; NI = 1; }
+    if (!d->geglu && tiles(2, 2) < 192) { MI = 1; NI = 1; }
+    if (d->geglu) { NI = 2; if (tiles(2, 2) < 256) MI = 1; }
+}
+
+// (MI<<8)|(NI<<4)|mode of the kernel instantiation slh_gemm would launch: gemm_kernel<MI, NI, mode>
+extern "C" int slh_gemm_variant(const slh_gemm_desc* d) {
+    int MI, NI;
+    pick_tile(d, MI, NI);
+    return (MI << 8) | (NI << 4) | (d->mode & 15);
+}
+
 extern "C" int slh_gemm(const slh_gemm_desc* d, slh_stream_t stream) {
     SLH_CHECK(d && d->a0 && d->w && d->c, "slh_gemm: null pointer");
     SLH_CHECK(d->M > 0 && d->N > 0 && d->K > 0, "slh_gemm: bad shape M=%d N=%d K=%d", d->M, d->N, d->K);
@@ -326,16 +346,8 @@ extern "C" int slh_gemm(const slh_gemm_desc* d, slh_stream_t stream) {
     if (d->geglu) SLH_CHECK(d->N % 64 == 0 && !d->lora_t && !d->residual && !d->rowbias, "slh_gemm: geglu constraints");
 
     int MI = 2, NI = 2;
-    if (d->tile) {
-        MI = (d->tile >> 4) & 15; NI = d->tile & 15;
-        SLH_CHECK((MI == 1 || MI == 2) && (NI == 1 || NI == 2), "slh_gemm: bad tile");
-    } else {
-        // heuristic: keep at least ~1.5 workgroups per CU when the problem allows it
-        auto tiles = [&](int mi, int ni) { return ((d->M + 64 * mi - 1) / (64 * mi)) * ((d->N + 64 * ni - 1) / (64 * ni)); };
-        if (tiles(2, 2) < 384) { MI = 2; NI = 1; }
-        if (!d->geglu && tiles(2, 2) < 192) { MI = 1; NI = 1; }
-        if (d->geglu) { NI = 2; if (tiles(2, 2) < 256) MI = 1; }
-    }
+    pick_tile(d, MI, NI);
+    SLH_CHECK((MI == 1 || MI == 2) && (NI == 1 || NI == 2), "slh_gemm: bad tile");
     if (d->geglu) SLH_CHECK(NI == 2, "slh_gemm: geglu needs NI=2");
 
     GemmArgs a;

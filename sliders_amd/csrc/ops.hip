@@ -24,35 +24,49 @@ __global__ void tembed_kernel(const slh_tembed_desc d) {
 }
 
 // ---- conv_in: NCHW (B,cin,H,W) -> pixel-major [B*H*W][cout], 3x3 pad 1 --------------------------------
-__global__ __launch_bounds__(256) void conv_in_kernel(const slh_convin_desc d) {
-    const int nchunk = d.cout / 8;
-    const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    const long total = (long)d.batch * d.h * d.wd * nchunk;
-    if (gid >= total) return;
-    const int chunk = (int)(gid % nchunk);
-    const long pix = gid / nchunk;
-    const int hw = d.h * d.wd;
-    const int b = (int)(pix / hw);
-    const int rem = (int)(pix - (long)b * hw);
-    const int oy = rem / d.wd, ox = rem - oy * d.wd;
-    const __bf16* x = (const __bf16*)d.x + (long)b * d.cin * hw;
-    const __bf16* w = (const __bf16*)d.w + (long)chunk * 8 * 9 * d.cin;
-    float acc[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) acc[e] = d.bias ? (float)((const __bf16*)d.bias)[chunk * 8 + e] : 0.f;
-    for (int tap = 0; tap < 9; ++tap) {
-        const int iy = oy + tap / 3 - 1, ix = ox + tap % 3 - 1;
-        if (iy < 0 || iy >= d.h || ix < 0 || ix >= d.wd) continue;
-        for (int ci = 0; ci < d.cin; ++ci) {
-            const float xv = (float)x[(long)ci * hw + iy * d.wd + ix];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) acc[e] += xv * (float)w[(long)e * 9 * d.cin + tap * d.cin + ci];
-        }
+// weights [cout][9*cin] are staged once per block into LDS as [k][cout] so a thread's 8 output channels are one
+// 16-byte LDS read per (tap, ci); block = (256/nchunk) pixels x nchunk chunks, 8 pixel groups per block.
+constexpr int CONVIN_ITERS = 8;
+__global__ void conv_in_kernel(const slh_convin_desc d, int nchunk, int ppb) {
+    extern __shared__ __attribute__((aligned(16))) char cin_smem[];
+    __bf16* sw = (__bf16*)cin_smem;                     // [9*cin][cout]
+    const int K = 9 * d.cin;
+    for (int i = threadIdx.x; i < K * d.cout; i += blockDim.x) {
+        const int co = i / K, k = i - co * K;
+        sw[k * d.cout + co] = ((const __bf16*)d.w)[i];
     }
-    bf16x8 o;
+    __syncthreads();
+    const int chunk = threadIdx.x % nchunk, pl = threadIdx.x / nchunk;
+    const int hw = d.h * d.wd;
+    const long npix = (long)d.batch * hw;
+    float bias[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) o[e] = (__bf16)acc[e];
-    *(bf16x8*)((__bf16*)d.y + pix * d.ldy + chunk * 8) = o;
+    for (int e = 0; e < 8; ++e) bias[e] = d.bias ? (float)((const __bf16*)d.bias)[chunk * 8 + e] : 0.f;
+    for (int it = 0; it < CONVIN_ITERS; ++it) {
+        const long pix = ((long)blockIdx.x * CONVIN_ITERS + it) * ppb + pl;
+        if (pix >= npix) break;
+        const int b = (int)(pix / hw);
+        const int rem = (int)(pix - (long)b * hw);
+        const int oy = rem / d.wd, ox = rem - oy * d.wd;
+        const __bf16* x = (const __bf16*)d.x + (long)b * d.cin * hw;
+        float acc[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] = bias[e];
+        for (int tap = 0; tap < 9; ++tap) {
+            const int iy = oy + tap / 3 - 1, ix = ox + tap % 3 - 1;
+            if (iy < 0 || iy >= d.h || ix < 0 || ix >= d.wd) continue;
+            for (int ci = 0; ci < d.cin; ++ci) {
+                const float xv = (float)x[(long)ci * hw + iy * d.wd + ix];
+                const bf16x8 wv = *(const bf16x8*)(sw + (tap * d.cin + ci) * d.cout + chunk * 8);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[e] += xv * (float)wv[e];
+            }
+        }
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (__bf16)acc[e];
+        *(bf16x8*)((__bf16*)d.y + pix * d.ldy + chunk * 8) = o;
+    }
 }
 
 // ---- elementwise ---------------------------------------------------------------------------------------
@@ -244,8 +258,13 @@ extern "C" int slh_timestep_embed(const slh_tembed_desc* d, slh_stream_t stream)
 extern "C" int slh_conv_in(const slh_convin_desc* d, slh_stream_t stream) {
     SLH_CHECK(d && d->x && d->w && d->y, "slh_conv_in: null pointer");
     SLH_CHECK(d->cout % 8 == 0 && d->ldy % 8 == 0 && d->cin > 0 && d->cin <= 16, "slh_conv_in: bad shape");
-    const long total = (long)d->batch * d->h * d->wd * (d->cout / 8);
-    hipLaunchKernelGGL(conv_in_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, *d);
+    const int nchunk = d->cout / 8;
+    SLH_CHECK(nchunk <= 256 && 9 * d->cin * d->cout * 2 <= 64 * 1024, "slh_conv_in: weights must fit 64 KB of LDS");
+    const int ppb = 256 / nchunk;
+    const long npix = (long)d->batch * d->h * d->wd;
+    const long per_block = (long)ppb * CONVIN_ITERS;
+    hipLaunchKernelGGL(conv_in_kernel, dim3((unsigned)((npix + per_block - 1) / per_block)), dim3(nchunk * ppb),
+                       9 * d->cin * d->cout * 2, (hipStream_t)stream, *d, nchunk, ppb);
     SLH_LAUNCH_CHECK("slh_conv_in");
     return 0;
 }

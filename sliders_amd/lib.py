@@ -150,6 +150,14 @@ def check(rc: int, what: str = ""):
         raise SlidersHipError(f"{what} failed (rc={rc}): {last_error()}")
 
 
+def gemm_variant(desc) -> int:
+    """(MI<<8)|(NI<<4)|mode of the gemm_kernel<MI,NI,mode> instantiation slh_gemm launches for desc."""
+    lib = load()
+    lib.slh_gemm_variant.argtypes = [C.POINTER(GemmDesc)]
+    lib.slh_gemm_variant.restype = c_i32
+    return lib.slh_gemm_variant(C.byref(desc))
+
+
 def call(opcode: int, desc, stream: int):
     """Launch one op directly (used by the per-kernel parity tests)."""
     lib = load()
@@ -165,6 +173,7 @@ class Program:
         self.n_ops = 0
         self._buf = None
         self.op_names = []
+        self.ops = []          # (opcode, descriptor) kept for per-op timing / tuning tools
 
     def add(self, opcode: int, desc, name: str = ""):
         raw = bytes(desc)
@@ -173,6 +182,7 @@ class Program:
         self._chunks.append(bytes(hdr(opcode, len(raw))) + raw + b"\0" * pad)
         self.n_ops += 1
         self.op_names.append(name)
+        self.ops.append((opcode, desc))
         self._buf = None
 
     def memset(self, ptr: int, nbytes: int, value: int = 0, name: str = "memset"):
@@ -180,6 +190,7 @@ class Program:
 
     def extend(self, other: "Program"):
         self._chunks.extend(other._chunks)
+        self.ops.extend(other.ops)
         self.n_ops += other.n_ops
         self.op_names.extend(other.op_names)
         self._buf = None

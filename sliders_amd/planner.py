@@ -23,6 +23,7 @@ from . import lib
 from .arena import Arena, Buf
 from .config import UNetConfig
 from .lora_store import LoraEntry, LoraStore
+from .tuning import tuned_tile
 from .weights import WeightStore
 
 
@@ -190,6 +191,7 @@ class UNetPlan:
                          ld_res=residual.ld if residual else 0, ldc=out.ld, geglu=1 if geglu else 0, tile=0)
         if conv is not None:
             self._conv_fields(d, x0, conv, Ho, Wo)
+        d.tile = tuned_tile(d)
         self.prog.add(lib.OP_GEMM, d, name)
         if self.train:
             self.tape.append(dict(op="gemm", x=x, out=out, wname=wname, N=N, K=K, conv=conv, grp=grp, T=T,
@@ -662,6 +664,7 @@ class BackwardPlan:
             if grp is not None:
                 d.lora_t, d.ld_t, d.lora_up, d.lora_scale = U.ptr, 4 * len(grp), self.lora.down_ptr(grp[0]), self.scale_ptr
                 d.lora_groups, d.lora_rank, d.lora_up_rmajor = 1, 4 * len(grp), 1
+            d.tile = tuned_tile(d)
             self.prog.add(lib.OP_GEMM, d, name + ".dgrad")
             if x1 is not None:
                 if need0:
@@ -682,6 +685,7 @@ class BackwardPlan:
                              batch=self.nb, hs=Ho, ws=Wo, src_xform=2 if stride == 2 else 0, stride=1, ho=HL, wo=WL,
                              ldw=9 * N, M=self.nb * HL * WL, N=cin, K=9 * N, ld_res=tgt.ld, ldc=tgt.ld,
                              rows_per_sample=HL * WL)
+            d.tile = tuned_tile(d)
             self.prog.add(lib.OP_GEMM, d, name + ".dgrad")
             if grp is not None:
                 d2 = lib.LoraCdgradDesc(u=U.ptr, a_down=self.lora.down_ptr(grp[0]), scale=self.scale_ptr, gx=tgt.ptr,

@@ -1,0 +1,35 @@
+"""Measured tile choices for slh_gemm (written by scripts/tune_gemm.py on an MI355X).
+
+The C library has a fill-the-chip heuristic; the planner overrides it with the measured best tile for every
+(shape, addressing mode) it has an entry for.  Tables live in sliders_amd/tuning/*.json and are merged.
+"""
+from __future__ import annotations
+
+import glob
+import json
+import os
+from typing import Dict, Optional
+
+_TABLE: Optional[Dict[str, int]] = None
+
+
+def gemm_key(d) -> str:
+    return f"{d.M},{d.N},{d.K},m{d.mode},s{d.stride},x{d.src_xform},g{d.geglu}"
+
+
+def table() -> Dict[str, int]:
+    global _TABLE
+    if _TABLE is None:
+        _TABLE = {}
+        here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tuning")
+        for path in sorted(glob.glob(os.path.join(here, "*.json"))):
+            with open(path) as f:
+                _TABLE.update({k: int(v) for k, v in json.load(f).items()})
+    return _TABLE
+
+
+def tuned_tile(d) -> int:
+    """0 = no entry (library heuristic)."""
+    if os.environ.get("SLIDERS_NO_TUNING"):
+        return 0
+    return table().get(gemm_key(d), 0)
