@@ -93,39 +93,61 @@ def measure_roofline(eng, plan):
 
 
 def cpu_baseline(model, hw):
-    """One UNet denoise step of the same workload on the host cores with the CPU oracle (bf16 oneDNN)."""
+    """UNet denoise steps on the host cores with the CPU oracle (PyTorch restatement of the reference's
+    diffusers UNet).  Bounded to ~10-30 s of CPU work: the faster of bf16 / fp32 is picked with a short probe at
+    256x256, and if one full-resolution step would exceed the budget the largest resolution that fits is timed
+    and the rate is extrapolated by latent area (flagged in `sample`)."""
     from oracle.unet_oracle import build_unet
     from sliders_amd.config import CONFIGS
     torch.set_num_threads(os.cpu_count())
     cfg = CONFIGS[model]()
     net = build_unet(model, device="meta")
-    # cheap distinct-memory init: values do not matter for timing, but every weight must own its memory
     g = torch.Generator().manual_seed(0)
     block = (torch.rand(1 << 22, generator=g) - 0.5) * 0.05
     sd = {}
-    for k, v in net.state_dict().items():
+    for k, v in net.state_dict().items():   # cheap init; every weight owns its memory (values do not matter)
         n = v.numel()
         t = block.repeat((n + block.numel() - 1) // block.numel())[:n].reshape(v.shape).to(torch.bfloat16)
-        if k.endswith("norm.weight") or ".norm1.weight" in k or ".norm2.weight" in k or ".norm3.weight" in k or k == "conv_norm_out.weight":
+        if "norm" in k and k.endswith(".weight"):
             t = torch.ones_like(t)
         sd[k] = t
     net.load_state_dict(sd, assign=True)
     net.eval()
     B = 2
-    x = torch.randn(B, 4, hw, hw).bfloat16()
-    ctx = torch.randn(B, 77, cfg.cross_attention_dim).bfloat16()
-    kw = None
-    if cfg.is_xl:
-        kw = {"text_embeds": torch.randn(B, cfg.pooled_dim).bfloat16(),
-              "time_ids": torch.tensor([[hw * 8.0, hw * 8.0, 0, 0, hw * 8.0, hw * 8.0]] * B).bfloat16()}
-    with torch.no_grad():
-        t0 = time.time()
-        out = net(x, torch.tensor(500), ctx, kw).sample
-        dt = time.time() - t0
-    assert torch.isfinite(out.float()).all()
-    return {"value": round(1.0 / dt, 4), "unit": "steps/s", "cores": os.cpu_count(), "kind": "port",
-            "sample": f"1 UNet denoise step (CFG pair B=2, {model} {hw * 8}x{hw * 8}, bf16 torch/oneDNN forward, "
-                      f"{dt:.1f} s) with the CPU oracle (PyTorch restatement of the diffusers UNet)"}
+
+    def run(h, dtype):
+        x = torch.randn(B, 4, h, h).to(dtype)
+        ctx = torch.randn(B, 77, cfg.cross_attention_dim).to(dtype)
+        kw = None
+        if cfg.is_xl:
+            kw = {"text_embeds": torch.randn(B, cfg.pooled_dim).to(dtype),
+                  "time_ids": torch.tensor([[h * 8.0, h * 8.0, 0, 0, h * 8.0, h * 8.0]] * B).to(dtype)}
+        with torch.no_grad():
+            t0 = time.time()
+            out = net(x, torch.tensor(500), ctx, kw).sample
+            dt = time.time() - t0
+        assert torch.isfinite(out.float()).all()
+        return dt
+
+    probe_hw = min(32, hw)
+    t_bf = run(probe_hw, torch.bfloat16)
+    net.float()
+    t_fp = run(probe_hw, torch.float32)
+    dtype, t_probe = (torch.float32, t_fp) if t_fp <= t_bf else (torch.bfloat16, t_bf)
+    if dtype == torch.bfloat16:
+        net.bfloat16()
+    budget = 30.0
+    use_hw = hw
+    while use_hw > probe_hw and t_probe * (use_hw / probe_hw) ** 2 > budget:
+        use_hw //= 2
+    dt = run(use_hw, dtype) if use_hw != probe_hw else t_probe
+    scale = (hw / use_hw) ** 2
+    note = "" if use_hw == hw else (f"; timed at {use_hw * 8}x{use_hw * 8} ({dt:.1f} s) and EXTRAPOLATED x{scale:.0f} by "
+                                    f"latent area to {hw * 8}x{hw * 8}")
+    return {"value": round(1.0 / (dt * scale), 5), "unit": "steps/s", "cores": os.cpu_count(), "kind": "port",
+            "sample": f"1 UNet denoise step (CFG pair B=2, {model}, {'fp32' if dtype == torch.float32 else 'bf16'} "
+                      f"torch/oneDNN forward, probe bf16 {t_bf:.1f}s / fp32 {t_fp:.1f}s at {probe_hw * 8}px) with the CPU "
+                      f"oracle = PyTorch restatement of the diffusers UNet{note}"}
 
 
 def main():

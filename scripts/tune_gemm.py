@@ -53,7 +53,7 @@ table, total_best, total_heur = {}, 0.0, 0.0
 for key, ds in sorted(shapes.items(), key=lambda kv: -kv[1][0].M * kv[1][0].N * kv[1][0].K * len(kv[1])):
     d0 = ds[0]
     res = {}
-    for tile in (0x22, 0x21, 0x12, 0x11, 0):
+    for tile in (0x22, 0x21, 0x12, 0x11, 0x321, 0x312, 0x311, 0):
         if d0.geglu and (tile & 15) == 1:
             continue
         d = type(d0).from_buffer_copy(bytes(d0))
@@ -72,8 +72,8 @@ for key, ds in sorted(shapes.items(), key=lambda kv: -kv[1][0].M * kv[1][0].N * 
     table[key] = best
     total_best += res[best] * len(ds)
     total_heur += res[0] * len(ds)
-    print(f"{key:44s} x{len(ds):4d}  " + "  ".join(f"{t:02x}:{res[t]:7.1f}us" for t in res) +
-          f"  best {best:02x} {fl / res[best] / 1e6:6.0f} TF/s", flush=True)
+    print(f"{key:44s} x{len(ds):4d}  " + "  ".join(f"{t:03x}:{res[t]:6.1f}" for t in res) +
+          f"  best {best:03x} {fl / res[best] / 1e6:6.0f} TF/s", flush=True)
 print(f"sum over one fwd+bwd: heuristic {total_heur / 1e3:.2f} ms, tuned {total_best / 1e3:.2f} ms")
 out = args.out or os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "sliders_amd", "tuning",
                                f"gfx950_{args.model}_{hw}.json")

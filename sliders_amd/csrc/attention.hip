@@ -19,7 +19,8 @@ __device__ __forceinline__ int lds_off(int row, int slot) {
     return row * 128 + ((slot ^ ((row >> 1) & 7)) << 4);
 }
 
-__global__ __launch_bounds__(256) void attn_fwd_kernel(const slh_attn_desc p) {
+template <int NW>   // waves per workgroup: 4 (128 queries) or 2 (64 queries, used when the grid would not fill the chip)
+__global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const slh_attn_desc p) {
     __shared__ __attribute__((aligned(16))) char smem[4 * 8192];
     char* sK = smem;           // [2][64 kv][128 B]
     char* sV = smem + 16384;   // [2][64 d ][128 B]
@@ -28,7 +29,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const slh_attn_desc p) {
     const int lrow = lane & 31, lhi = lane >> 5;
     const int frow = lane >> 3, fslot = lane & 7;
     const int h = blockIdx.y, b = blockIdx.z;
-    const int q0 = blockIdx.x * 128 + wave * 32;
+    const int q0 = blockIdx.x * (32 * NW) + wave * 32;
 
     const __bf16* Q = (const __bf16*)p.q;
     const __bf16* K = (const __bf16*)p.k;
@@ -46,14 +47,14 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const slh_attn_desc p) {
     const int nt = (p.Tk + 63) / 64;
     auto stage = [&](int buf, int t) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int row = (wave + 4 * i) * 8 + frow;
+        for (int i = 0; i < 8 / NW; ++i) {
+            const int row = (wave + NW * i) * 8 + frow;
             const int ks = fslot ^ ((row >> 1) & 7);
             int kv = t * 64 + row;
             kv = kv < p.Tk ? kv : p.Tk - 1;
-            glds16(K + ((long)b * p.Tk + kv) * p.ldk + h * 64 + ks * 8, sK + buf * 8192 + (wave + 4 * i) * 1024);
+            glds16(K + ((long)b * p.Tk + kv) * p.ldk + h * 64 + ks * 8, sK + buf * 8192 + (wave + NW * i) * 1024);
             glds16(VT + (((long)b * p.H + h) * 64 + row) * p.ldvt + t * 64 + ks * 8,
-                   sV + buf * 8192 + (wave + 4 * i) * 1024);
+                   sV + buf * 8192 + (wave + NW * i) * 1024);
         }
     };
 
@@ -179,8 +180,12 @@ extern "C" int slh_attn_fwd(const slh_attn_desc* d, slh_stream_t stream) {
     SLH_CHECK(d->B > 0 && d->H > 0 && d->Tq > 0 && d->Tk > 0, "slh_attn_fwd: bad shape");
     SLH_CHECK(d->ldq % 8 == 0 && d->ldk % 8 == 0 && d->ldvt % 64 == 0 && d->ldo % 4 == 0, "slh_attn_fwd: alignment");
     SLH_CHECK(d->ldvt >= ((d->Tk + 63) / 64) * 64, "slh_attn_fwd: VT must be padded to a multiple of 64 keys");
-    dim3 grid((d->Tq + 127) / 128, d->H, d->B);
-    hipLaunchKernelGGL(attn_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, *d);
+    const long blocks4 = (long)((d->Tq + 127) / 128) * d->H * d->B;
+    if (blocks4 >= 512) {
+        hipLaunchKernelGGL(attn_fwd_kernel<4>, dim3((d->Tq + 127) / 128, d->H, d->B), dim3(256), 0, (hipStream_t)stream, *d);
+    } else {
+        hipLaunchKernelGGL(attn_fwd_kernel<2>, dim3((d->Tq + 63) / 64, d->H, d->B), dim3(128), 0, (hipStream_t)stream, *d);
+    }
     SLH_LAUNCH_CHECK("slh_attn_fwd");
     return 0;
 }

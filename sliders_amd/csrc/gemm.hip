@@ -40,15 +40,15 @@ __device__ __forceinline__ int lds_off(int row, int slot) {
     return row * 128 + ((slot ^ ((row >> 1) & 7)) << 4);
 }
 
-template <int MI, int NI, int MODE>
+template <int MI, int NI, int MODE, int STAGES>
 __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
     constexpr int BM = 64 * MI;
     constexpr int BN = 64 * NI;
     constexpr int XI = BM / 32;  // glds instructions per wave for the X tile (8 rows each, 4 waves)
     constexpr int WI = BN / 32;
-    __shared__ __attribute__((aligned(16))) char smem[2 * (BM + BN) * 128];
-    char* sX = smem;                   // [2][BM][128 B]
-    char* sW = smem + 2 * BM * 128;    // [2][BN][128 B]
+    __shared__ __attribute__((aligned(16))) char smem[STAGES * (BM + BN) * 128];
+    char* sX = smem;                        // [STAGES][BM][128 B]
+    char* sW = smem + STAGES * BM * 128;    // [STAGES][BN][128 B]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -154,12 +154,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
     const int nk = p.K / BK;
     const int lrow = lane & 31, lhi = lane >> 5;
 
-    stage(0, 0);
-    for (int kt = 0; kt < nk; ++kt) {
-        __syncthreads();  // drains this wave's glds (vmcnt(0)) and orders all waves
-        if (kt + 1 < nk) stage((kt + 1) & 1, kt + 1);
-        const char* cX = sX + (kt & 1) * (BM * 128);
-        const char* cW = sW + (kt & 1) * (BN * 128);
+    auto compute = [&](int buf) {
+        const char* cX = sX + buf * (BM * 128);
+        const char* cW = sW + buf * (BN * 128);
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             bf16x8 xf[MI], wf[NI];
@@ -174,6 +171,31 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
 #pragma unroll
                 for (int j = 0; j < NI; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[j], xf[i], acc[i][j], 0, 0, 0);
+        }
+    };
+
+    if constexpr (STAGES == 2) {
+        stage(0, 0);
+        for (int kt = 0; kt < nk; ++kt) {
+            __syncthreads();  // drains this wave's glds (vmcnt(0)) and orders all waves
+            if (kt + 1 < nk) stage((kt + 1) & 1, kt + 1);
+            compute(kt & 1);
+        }
+    } else {
+        // 3-deep ring: tile kt+1 stays in flight across the barrier (counted vmcnt, raw s_barrier), tile kt+2
+        // is issued right after it.  A wave's own glds for tile kt are retired by vmcnt(L); the barrier then
+        // guarantees every wave's share has landed and that nobody still reads the slot being refilled.
+        constexpr int L = XI + WI;   // LDS-DMA instructions per wave per stage
+        stage(0, 0);
+        if (nk > 1) stage(1, 1);
+        int cur = 0;
+        for (int kt = 0; kt < nk; ++kt) {
+            if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(L) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (kt + 2 < nk) stage(cur >= 1 ? cur - 1 : 2, kt + 2);
+            compute(cur);
+            cur = cur == 2 ? 0 : cur + 1;
         }
     }
 
@@ -281,10 +303,13 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
 }
 
 template <int MI, int NI>
-int launch_gemm(const GemmArgs& a, int mode, hipStream_t s) {
+int launch_gemm(const GemmArgs& a, int mode, int stages, hipStream_t s) {
     const int grid = a.tiles_m * a.tiles_n;
-    if (mode == 0) hipLaunchKernelGGL((gemm_kernel<MI, NI, 0>), dim3(grid), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((gemm_kernel<MI, NI, 1>), dim3(grid), dim3(256), 0, s, a);
+    if (stages == 3 && MI + NI <= 3) {   // 3 x 64 KB would not fit for the 128x128 tile
+        if (mode == 0) hipLaunchKernelGGL((gemm_kernel<MI, NI, 0, (MI + NI <= 3 ? 3 : 2)>), dim3(grid), dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((gemm_kernel<MI, NI, 1, (MI + NI <= 3 ? 3 : 2)>), dim3(grid), dim3(256), 0, s, a);
+    } else if (mode == 0) hipLaunchKernelGGL((gemm_kernel<MI, NI, 0, 2>), dim3(grid), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((gemm_kernel<MI, NI, 1, 2>), dim3(grid), dim3(256), 0, s, a);
     SLH_LAUNCH_CHECK("slh_gemm");
     return 0;
 }
@@ -296,7 +321,8 @@ static void pick_tile(const slh_gemm_desc* d, int& MI, int& NI) {
     MI = 2; NI = 2;
     if (d->tile) {
         MI = (d->tile >> 4) & 15; NI = d->tile & 15;
-        return;
+        if (MI) return;
+        MI = 2; NI = 2;
     }
     auto tiles = [&](int mi, int ni) { return ((d->M + 64 * mi - 1) / (64 * mi)) * ((d->N + 64 * ni - 1) / (64 * ni)); };
     if (tiles(2, 2) < 384) { MI = 2; NI = 1; }
@@ -365,8 +391,9 @@ extern "C" int slh_gemm(const slh_gemm_desc* d, slh_stream_t stream) {
     a.tiles_m = (d->M + 64 * MI - 1) / (64 * MI);
     a.tiles_n = (d->N + 64 * NI - 1) / (64 * NI);
     hipStream_t s = (hipStream_t)stream;
-    if (MI == 2 && NI == 2) return launch_gemm<2, 2>(a, d->mode, s);
-    if (MI == 2 && NI == 1) return launch_gemm<2, 1>(a, d->mode, s);
-    if (MI == 1 && NI == 2) return launch_gemm<1, 2>(a, d->mode, s);
-    return launch_gemm<1, 1>(a, d->mode, s);
+    const int stages = (d->tile >> 8) & 15;   // tile = (stages<<8)|(MI<<4)|NI ; stages 0/2 = double buffer
+    if (MI == 2 && NI == 2) return launch_gemm<2, 2>(a, d->mode, stages, s);
+    if (MI == 2 && NI == 1) return launch_gemm<2, 1>(a, d->mode, stages, s);
+    if (MI == 1 && NI == 2) return launch_gemm<1, 2>(a, d->mode, stages, s);
+    return launch_gemm<1, 1>(a, d->mode, stages, s);
 }

@@ -17,15 +17,16 @@ struct AddrArgs {  // shared A-operand addressing (same meaning as slh_gemm_desc
 };
 
 // ------------------------------------------------------------------------------------------------
-// skinny: 16 lanes per output row, 4 rows per wave, 16 rows per 256-thread block
+// skinny: LPR lanes per output row (16: many rows; 64: one wave per row, used when M is small so that the
+// grid still covers the chip and the serial K chain per lane stays short), 256 threads per block
 // ------------------------------------------------------------------------------------------------
-template <int RMAX>
+template <int RMAX, int LPR>
 __global__ __launch_bounds__(256) void skinny_kernel(AddrArgs A, const __bf16* __restrict__ w,
                                                      const __bf16* __restrict__ bias, void* out,
                                                      int M, int R, int K, int ldo, int out_kind, int kmajor) {
     const int tid = threadIdx.x;
-    const int sub = tid & 15;
-    const int m = blockIdx.x * 16 + (tid >> 4);
+    const int sub = tid & (LPR - 1);
+    const int m = blockIdx.x * (256 / LPR) + tid / LPR;
     const bool active = m < M;
     const int mm = active ? m : M - 1;
     float acc[RMAX];
@@ -64,7 +65,7 @@ __global__ __launch_bounds__(256) void skinny_kernel(AddrArgs A, const __bf16* _
     };
 
     if (A.mode == 0) {
-        for (int k = sub * 8; k < K; k += 128) {
+        for (int k = sub * 8; k < K; k += LPR * 8) {
             const __bf16* src = k < A.ca0 ? A.a0 + (long)mm * A.lda0 + k
                                           : A.a1 + (long)mm * A.lda1 + (k - A.ca0);
             fma_chunk(src, k);
@@ -83,7 +84,7 @@ __global__ __launch_bounds__(256) void skinny_kernel(AddrArgs A, const __bf16* _
             if (A.src_xform == 2) ok = ok & (((iy | ix) & 1) == 0);
             if (!ok) continue;
             const long pix = ((long)b * A.hs + (iy >> sh)) * A.ws + (ix >> sh);
-            for (int c = sub * 8; c < cin; c += 128) {
+            for (int c = sub * 8; c < cin; c += LPR * 8) {
                 const __bf16* src = c < A.ca0 ? A.a0 + pix * A.lda0 + c : A.a1 + pix * A.lda1 + (c - A.ca0);
                 fma_chunk(src, tap * cin + c);
             }
@@ -92,7 +93,7 @@ __global__ __launch_bounds__(256) void skinny_kernel(AddrArgs A, const __bf16* _
 #pragma unroll
     for (int r = 0; r < RMAX; ++r) {
 #pragma unroll
-        for (int o = 8; o > 0; o >>= 1) acc[r] += __shfl_xor(acc[r], o, 64);
+        for (int o = LPR / 2; o > 0; o >>= 1) acc[r] += __shfl_xor(acc[r], o, 64);
     }
     if (active && sub == 0) {
         if (out_kind == 0) {
@@ -283,17 +284,24 @@ extern "C" int slh_skinny(const slh_skinny_desc* d, slh_stream_t stream) {
     AddrArgs A;
     fill_addr(A, d->a0, d->a1, d->lda0, d->lda1, d->ca0, d->ca1, d->mode, d->hs, d->ws, d->src_xform, d->stride,
               d->ho, d->wo);
-    const int grid = (d->M + 15) / 16;
     hipStream_t s = (hipStream_t)stream;
-    if (d->R <= 4)
-        hipLaunchKernelGGL(skinny_kernel<4>, dim3(grid), dim3(256), 0, s, A, (const __bf16*)d->w,
-                           (const __bf16*)d->bias, d->out, d->M, d->R, d->K, d->ldo, d->out_kind, d->w_kmajor);
-    else if (d->R <= 12)
-        hipLaunchKernelGGL(skinny_kernel<12>, dim3(grid), dim3(256), 0, s, A, (const __bf16*)d->w,
-                           (const __bf16*)d->bias, d->out, d->M, d->R, d->K, d->ldo, d->out_kind, d->w_kmajor);
-    else
-        hipLaunchKernelGGL(skinny_kernel<16>, dim3(grid), dim3(256), 0, s, A, (const __bf16*)d->w,
-                           (const __bf16*)d->bias, d->out, d->M, d->R, d->K, d->ldo, d->out_kind, d->w_kmajor);
+    // one wave per row while that still gives < ~8 waves per SIMD of work; 16 lanes per row beyond
+    const bool wide = d->M <= 16384;
+#define SLH_SKINNY_LAUNCH(RM)                                                                                      \
+    do {                                                                                                           \
+        if (wide)                                                                                                  \
+            hipLaunchKernelGGL((skinny_kernel<RM, 64>), dim3((d->M + 3) / 4), dim3(256), 0, s, A,                  \
+                               (const __bf16*)d->w, (const __bf16*)d->bias, d->out, d->M, d->R, d->K, d->ldo,      \
+                               d->out_kind, d->w_kmajor);                                                          \
+        else                                                                                                       \
+            hipLaunchKernelGGL((skinny_kernel<RM, 16>), dim3((d->M + 15) / 16), dim3(256), 0, s, A,                \
+                               (const __bf16*)d->w, (const __bf16*)d->bias, d->out, d->M, d->R, d->K, d->ldo,      \
+                               d->out_kind, d->w_kmajor);                                                          \
+    } while (0)
+    if (d->R <= 4) SLH_SKINNY_LAUNCH(4);
+    else if (d->R <= 12) SLH_SKINNY_LAUNCH(12);
+    else SLH_SKINNY_LAUNCH(16);
+#undef SLH_SKINNY_LAUNCH
     SLH_LAUNCH_CHECK("slh_skinny");
     return 0;
 }

@@ -121,6 +121,10 @@ def load() -> C.CDLL:
         raise SlidersHipError(
             f"{LIB_PATH} not found: the HIP extension is not built. There is no CPU fallback; run "
             f"`make -C {os.path.join(_HERE, 'csrc')}` (or __graft_entry__.build()).")
+    # PyTorch-ROCm bundles its own libamdhip64.so.7; load it first so this library binds to the SAME HIP
+    # runtime instance (streams and device pointers are shared with torch).  Loading /opt/rocm's copy first
+    # leaves two runtimes in the process and every launch fails with "no ROCm-capable device is detected".
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     lib.slh_last_error.restype = C.c_char_p
     lib.slh_run_program.argtypes = [c_vp, c_i64, c_vp]

@@ -1,0 +1,66 @@
+"""Data parallelism for slider training: one process per GPU, `torch.distributed` (backend "nccl" = RCCL over
+xGMI on MI355X nodes, "gloo" in the CPU tests).
+
+The reference is single-GPU and draws ONE PromptEmbedsPair per iteration (train_lora_xl.py:170-172).  Iterations
+on different pairs / noise are independent given the adapter weights, so N ranks run N of them concurrently
+and exchange exactly one message per optimizer step: the flat fp32 LoRA-gradient buffer (17.3 MB for SDXL
+rank 4), summed with a single all-reduce and scaled by 1/N inside the fused AdamW kernel.  Everything else is
+derived locally and deterministically:
+  * k (number of partial-denoise steps, 1..49) is drawn from a generator seeded identically on every rank, so
+    all ranks do the same amount of work per step (otherwise the slowest rank could be 49x slower),
+  * the prompt pair is a rank-dependent index into the pair list, the latent noise a rank-dependent stream,
+  * adapter parameters and AdamW state are replicated and stay bit-identical because every rank applies the
+    same update to the same all-reduced gradient.
+N=1 reproduces the reference semantics exactly.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+import torch.distributed as dist
+
+
+def world_info(group=None):
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(group), dist.get_world_size(group)
+    return 0, 1
+
+
+class StepSampler:
+    """Per-iteration random choices, split into rank-shared and rank-local streams."""
+
+    def __init__(self, seed: int, rank: int, world: int, n_pairs: int, max_denoising_steps: int = 50):
+        self.rank, self.world, self.n_pairs = rank, world, n_pairs
+        self.max_steps = max_denoising_steps
+        self.shared = torch.Generator(device="cpu").manual_seed(seed)
+        self.local = torch.Generator(device="cpu").manual_seed(seed * 1000003 + 17 + rank)
+        self.step = 0
+
+    def next(self):
+        """-> (k, pair_index).  k is identical on all ranks; pair indices of one step are distinct whenever
+        world <= n_pairs."""
+        k = int(torch.randint(1, self.max_steps, (1,), generator=self.shared).item())
+        base = int(torch.randint(0, self.n_pairs, (1,), generator=self.shared).item())
+        pair = (base + self.rank) % self.n_pairs
+        self.step += 1
+        return k, pair
+
+    def noise(self, shape) -> torch.Tensor:
+        """Latent noise, drawn on the CPU like the reference (train_util.py:20-32)."""
+        return torch.randn(shape, generator=self.local)
+
+
+def allreduce_sum_(flat: torch.Tensor, group=None) -> float:
+    """In-place SUM all-reduce of the flat gradient buffer; returns the factor the optimizer must scale by."""
+    rank, world = world_info(group)
+    if world > 1:
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    return 1.0 / world
+
+
+def broadcast_params_(flat: torch.Tensor, group=None, src: int = 0):
+    """Make rank-local adapter init identical (only needed if ranks seeded their init differently)."""
+    rank, world = world_info(group)
+    if world > 1:
+        dist.broadcast(flat, src=src, group=group)

@@ -27,6 +27,7 @@ import torch
 from . import lib
 from .ddim import DDIMSchedule
 from .lora_store import LoraStore
+from .parallel import allreduce_sum_, world_info
 from .unet import UNetEngine
 
 
@@ -61,9 +62,8 @@ class SliderTrainer:
         self.denoise_guidance = denoise_guidance
         self.sched = DDIMSchedule()
         self.pg = process_group
-        self.world = 1
-        if process_group is not None or (torch.distributed.is_available() and torch.distributed.is_initialized()):
-            self.world = torch.distributed.get_world_size(process_group)
+        self.rank, self.world = world_info(process_group)
+        self.grad_scale = 1.0
         dev = engine.device
         cfg = engine.cfg
         engine.attach_lora(store) if engine.lora is not store else None
@@ -152,8 +152,7 @@ class SliderTrainer:
         # 5. backward into the flat fp32 gradient buffer, (all-reduce,) AdamW
         st.grads.zero_()
         bw.prog.run(s)
-        if self.world > 1:
-            torch.distributed.all_reduce(st.grads, group=self.pg)
+        self.grad_scale = allreduce_sum_(st.grads, self.pg)     # ONE collective per optimizer step
         self.optimizer_step()
         return self.loss
 
@@ -162,5 +161,5 @@ class SliderTrainer:
         st.opt_step += 1
         d = lib.AdamwDesc(param=st.params.data_ptr(), exp_avg=st.exp_avg.data_ptr(), exp_avg_sq=st.exp_avg_sq.data_ptr(),
                           grad=st.grads.data_ptr(), n=st.numel, lr=self.lr, beta1=self.betas[0], beta2=self.betas[1],
-                          eps=self.eps, weight_decay=self.wd, step=st.opt_step, grad_scale=1.0 / self.world)
+                          eps=self.eps, weight_decay=self.wd, step=st.opt_step, grad_scale=self.grad_scale)
         lib.call(lib.OP_ADAMW, d, _stream())

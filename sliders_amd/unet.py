@@ -57,6 +57,7 @@ class UNetEngine:
         self.train_plan: Optional[UNetPlan] = None
         self.one = torch.ones(1, dtype=torch.float32, device=self.device)
         self.grad_all_samples = False
+        self.autograd_param: Optional[torch.nn.Parameter] = None   # set by LoRANetwork.flat_parameter()
 
     # ---- reference-facing no-ops ----------------------------------------------------------------
     def to(self, *a, **k):
@@ -175,11 +176,37 @@ class UNetEngine:
         if mode == "train":
             self.train_plan = p
         out = p.io["eps"].tensor.clone()
+        if mode == "train" and torch.is_grad_enabled() and self.autograd_param is not None:
+            out = _EpsBridge.apply(self.autograd_param, out, self, p)
         if not return_dict:
             return (out,)
         return UNetOutput(out)
 
     forward = __call__
+
+
+class _EpsBridge(torch.autograd.Function):
+    """Lets the reference-shaped loop call `loss.backward()`: the engine output becomes a function of the flat
+    LoRA Parameter; backward replays the HIP backward program and returns the packed gradient (bf16, like
+    the reference's param.grad).  Samples outside the gradient-carrying half must receive a zero gradient
+    (true for the reference's guidance_scale=1 target prediction); otherwise set engine.grad_all_samples."""
+
+    @staticmethod
+    def forward(ctx, flat_param, eps, engine, plan):
+        ctx.engine, ctx.plan = engine, plan
+        return eps.view_as(eps)
+
+    @staticmethod
+    def backward(ctx, g):
+        eng, p = ctx.engine, ctx.plan
+        bw = p.backward
+        b0, nb = bw.b0, bw.nb
+        if b0 > 0 and bool((g[:b0] != 0).any()):
+            raise RuntimeError("non-zero gradient on the unconditional half: build the engine plan with "
+                               "engine.grad_all_samples = True")
+        eng.lora.grads.zero_()
+        eng.run_backward(p, d_eps=g[b0:b0 + nb])
+        return eng.lora.grads.to(torch.bfloat16), None, None, None
 
 
 class _VirtualWeights:

@@ -1,0 +1,84 @@
+"""Data-parallel path, world_size 2, gloo backend on CPU (the production backend is "nccl" = RCCL over xGMI).
+
+Checks the three properties the DP design relies on (sliders_amd/parallel.py):
+  * k (denoise length) is identical on all ranks, prompt pairs differ, noise streams differ;
+  * one all-reduce of the flat fp32 gradient buffer + the 1/N scale equals the gradient of the summed
+    per-rank losses divided by N (here: a small quadratic "adapter" whose gradient is known in closed form);
+  * replicated parameters stay bit-identical across ranks after the update.
+"""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from sliders_amd.parallel import StepSampler, allreduce_sum_, broadcast_params_, world_info
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        assert world_info() == (rank, world)
+        samp = StepSampler(seed=7, rank=rank, world=world, n_pairs=8)
+        ks, pairs = zip(*[samp.next() for _ in range(16)])
+        noise = samp.noise((1, 4, 8, 8))
+        # replicated parameters, per-rank data
+        torch.manual_seed(0)
+        w = torch.randn(1000)
+        broadcast_params_(w)
+        data = torch.randn(1000, generator=torch.Generator().manual_seed(100 + rank))
+        grad = (w - data).float()                 # d/dw 0.5*|w - data|^2 on this rank
+        scale = allreduce_sum_(grad)
+        w_new = w - 0.1 * grad * scale
+        q.put((rank, list(ks), list(pairs), noise.sum().item(), grad.clone(), scale, w_new.clone()))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_dp_world2_gloo():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=100) for _ in range(world)], key=lambda r: r[0])
+    for p in procs:
+        p.join(30)
+        assert p.exitcode == 0
+    (r0, k0, p0, n0, g0, s0, w0), (r1, k1, p1, n1, g1, s1, w1) = res
+    assert k0 == k1, "denoise length must be shared across ranks"
+    assert all(1 <= k <= 49 for k in k0)
+    assert all(a != b for a, b in zip(p0, p1)), "ranks must train different prompt pairs in a step"
+    assert n0 != n1, "ranks must draw different latent noise"
+    assert s0 == s1 == 0.5
+    assert torch.equal(g0, g1), "all-reduced gradient must be identical on every rank"
+    torch.manual_seed(0)
+    w = torch.randn(1000)
+    d0 = torch.randn(1000, generator=torch.Generator().manual_seed(100))
+    d1 = torch.randn(1000, generator=torch.Generator().manual_seed(101))
+    assert torch.allclose(g0, (w - d0) + (w - d1))
+    assert torch.equal(w0, w1), "replicated parameters diverged"
+
+
+def test_single_process_is_identity():
+    g = torch.arange(10, dtype=torch.float32)
+    assert allreduce_sum_(g) == 1.0 and torch.equal(g, torch.arange(10, dtype=torch.float32))
+    s = StepSampler(seed=1, rank=0, world=1, n_pairs=2)
+    k, p = s.next()
+    assert 1 <= k <= 49 and p in (0, 1)

@@ -1,0 +1,130 @@
+"""CPU tests of the host side: YAML schema vs the reference's parse (golden), C-ABI exports vs the header,
+static planner invariants on a virtual arena (no GPU memory), checkpoint file interchange."""
+import ctypes
+import json
+import os
+import re
+
+import pytest
+import torch
+
+from sliders_amd import lib
+from sliders_amd.arena import Arena
+from sliders_amd.config import CONFIGS
+from sliders_amd.config_util import load_config_from_yaml
+from sliders_amd.lora_store import LoraStore
+from sliders_amd.modules import build_tree
+from sliders_amd.planner import BackwardPlan, UNetPlan
+from sliders_amd.prompt_util import PromptEmbedsPair, PromptSettings, load_prompts_from_yaml
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+G = os.path.join(ROOT, "tests", "golden")
+
+
+def test_yaml_schema_matches_reference_parse():
+    gold = json.load(open(os.path.join(G, "schema.json")))
+    cfg = load_config_from_yaml(os.path.join(G, "config_sample.yaml"))
+    assert json.loads(cfg.model_dump_json()) == gold["config"]
+    plain = load_prompts_from_yaml(os.path.join(G, "prompts_sample.yaml"))
+    assert [json.loads(p.model_dump_json()) for p in plain] == gold["prompts"]
+    attr = load_prompts_from_yaml(os.path.join(G, "prompts_sample.yaml"), ["male", "female"])
+    assert [json.loads(p.model_dump_json()) for p in attr] == gold["prompts_attr"]
+    # unknown keys (the GPT prompt files' `guidance:`) are ignored -> guidance_scale falls back to 1.0
+    assert plain[1].guidance_scale == 1.0 and plain[0].guidance_scale == 4
+    with pytest.raises(Exception):
+        PromptSettings(positive="x")
+
+
+def test_prompt_pair_loss_formula():
+    st = PromptSettings(target="a", action="enhance", guidance_scale=2.0)
+    pair = PromptEmbedsPair(torch.nn.MSELoss(), None, None, None, None, st)
+    t, p, u, n = [torch.randn(1, 4, 8, 8) for _ in range(4)]
+    got = pair.loss(target_latents=t, positive_latents=p, unconditional_latents=u, neutral_latents=n)
+    assert torch.allclose(got, ((t - (n + 2.0 * (p - u))) ** 2).mean())
+    pair.action = "erase"
+    got = pair.loss(target_latents=t, positive_latents=p, unconditional_latents=u, neutral_latents=n)
+    assert torch.allclose(got, ((t - (n - 2.0 * (p - u))) ** 2).mean())
+
+
+def test_c_abi_exports_every_declared_symbol():
+    """libsliders_hip.so loads without a GPU and exports exactly the entry points include/sliders_hip.h declares."""
+    hdr = open(os.path.join(ROOT, "include", "sliders_hip.h")).read()
+    declared = set(re.findall(r"^(?:int|const char\*)\s+(slh_\w+)\s*\(", hdr, flags=re.M))
+    assert len(declared) >= 25
+    l = lib.load()
+    for sym in sorted(declared):
+        assert hasattr(l, sym), f"{sym} declared in sliders_hip.h but not exported"
+    assert declared == set(lib.EXPORTS) | {"slh_gemm_variant"}
+    assert l.slh_version() >= 1
+    # descriptor sizes were cross-checked inside lib.load(); a bad descriptor is rejected with a message
+    d = lib.GemmDesc()
+    assert l.slh_gemm(ctypes.byref(d), None) != 0
+    assert b"slh_gemm" in l.slh_last_error()
+
+
+class _FakeWeights:
+    def __init__(self, cfg):
+        self.temb_offsets, self.resnet_paths, off = {}, [], 0
+        for n, m in build_tree(cfg).named_modules():
+            if m.cls == "ResnetBlock2D":
+                self.resnet_paths.append(n)
+                self.temb_offsets[n] = off
+                off += m.out_dim
+        self.temb_total = off
+
+    def ptr(self, name):
+        return 0x1000
+
+    def has(self, name):
+        return True
+
+
+@pytest.mark.parametrize("name,hw,method", [("tiny_sdxl", 16, "noxattn"), ("tiny_sd1", 16, "full"), ("sdxl", 128, "noxattn")])
+def test_planner_static_invariants(name, hw, method):
+    cfg = CONFIGS[name]()
+    store = LoraStore(cfg, train_method=method, init="none")
+    store.temb_tcol = torch.zeros(1, dtype=torch.int32)
+    counts = {}
+    for mode in ("off", "on", "train"):
+        va, vz = Arena(1 << 50, None), Arena(1 << 40, None)
+        p = UNetPlan(cfg, _FakeWeights(cfg), va, vz, 2, hw, hw, 77, store if mode != "off" else None, mode, 0x10)
+        ops = p.prog.ops
+        counts[mode] = len(ops)
+        # every allocation is 256-byte aligned and allocations never overlap
+        spans = sorted((s, e) for s, e, _ in va.allocs)
+        assert all(s % 256 == 0 for s, _ in spans)
+        assert all(spans[i][1] <= spans[i + 1][0] for i in range(len(spans) - 1))
+        gemms = [d for o, d in ops if o == lib.OP_GEMM]
+        assert all(d.K % 64 == 0 and d.N % 4 == 0 and d.ldc % 4 == 0 for d in gemms)
+        if mode == "off":
+            assert not any(d.lora_t for d in gemms), "adapters off must not launch any LoRA work"
+            assert not any(o == lib.OP_SKINNY for o, d in ops[:-1])
+        else:
+            n_lora = sum(1 for d in gemms if d.lora_t)
+            assert n_lora > 0
+        if mode == "train":
+            bw = BackwardPlan(p, 1, 1, 0x20)
+            assert len(bw.prog.ops) > len(ops)
+            dg = [d for o, d in bw.prog.ops if o == lib.OP_GEMM]
+            assert all(d.M == d_.M for d, d_ in zip(dg[:1], dg[:1]))
+            assert all(d.K % 64 == 0 for d in dg)
+    assert counts["off"] < counts["on"] <= counts["train"]
+    if name == "sdxl":
+        assert counts["off"] < 1300     # one launch per fused op: ~1.15k for the whole SDXL UNet
+
+
+def test_checkpoint_file_is_reference_loadable(tmp_path):
+    """save_weights writes a torch .pt OrderedDict with the reference's keys; it strict-loads into the oracle
+    restatement of the reference's LoRANetwork (the notebooks' `network.load_state_dict(torch.load(path))`)."""
+    from oracle.lora_oracle import LoRANetworkOracle
+    from oracle.unet_oracle import build_unet
+    cfg = CONFIGS["tiny_sdxl"]()
+    s = LoraStore(cfg, train_method="noxattn")
+    path = tmp_path / "slider_alpha1.0_rank4_noxattn_last.pt"
+    torch.save(s.state_dict(torch.bfloat16), path)
+    sd = torch.load(path)
+    assert all(v.dtype == torch.bfloat16 for v in sd.values())
+    net = build_unet("tiny_sdxl", seed=0)
+    nw = LoRANetworkOracle(net, rank=4, multiplier=1.0, alpha=1.0, train_method="noxattn")
+    nw.load_state_dict(sd, strict=True)
+    assert list(nw.state_dict().keys()) == list(sd.keys())

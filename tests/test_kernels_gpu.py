@@ -40,7 +40,7 @@ def _pack_conv(w):
     return w.permute(0, 2, 3, 1).reshape(w.shape[0], -1).contiguous()
 
 
-@pytest.mark.parametrize("tile", [0x22, 0x21, 0x12, 0x11])
+@pytest.mark.parametrize("tile", [0x22, 0x21, 0x12, 0x11, 0x321, 0x312, 0x311])
 @pytest.mark.parametrize("M,N,K", [(256, 128, 64), (300, 320, 320), (1024, 640, 1280), (154, 256, 2048)])
 def test_gemm_dense(dev, M, N, K, tile):
     torch.manual_seed(M + N + K)
@@ -129,7 +129,7 @@ def _perm_cols(g):
 
 
 @pytest.mark.parametrize("stride,xform", [(1, 0), (2, 0), (1, 1), (1, 2)])
-@pytest.mark.parametrize("tile", [0x22, 0x11])
+@pytest.mark.parametrize("tile", [0x22, 0x11, 0x312, 0x311])
 def test_gemm_conv3x3(dev, stride, xform, tile):
     torch.manual_seed(3 + stride + xform)
     B, H, W, Ci, Co = 2, 12, 20, 128, 192
@@ -281,7 +281,7 @@ def test_layernorm(dev, C):
     report(f"layernorm_bwd C{C}", dx, xi.grad + dx_init.float(), 1.5e-2)
 
 
-@pytest.mark.parametrize("B,H,Tq,Tk", [(2, 5, 1024, 1024), (1, 3, 192, 192), (2, 4, 256, 77), (1, 2, 100, 333)])
+@pytest.mark.parametrize("B,H,Tq,Tk", [(2, 5, 1024, 1024), (1, 3, 192, 192), (2, 4, 256, 77), (1, 2, 100, 333), (4, 8, 2048, 2048)])
 def test_attention_fwd(dev, B, H, Tq, Tk):
     torch.manual_seed(9)
     C = H * 64

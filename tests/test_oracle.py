@@ -1,0 +1,165 @@
+"""CPU tests that pin the oracle (and the product-side host logic) to the reference.
+
+The golden files under tests/golden/ were produced by the reference's own unmodified Python in the authoring
+container (tests/golden/make_golden.py); nothing here reads /root/reference.
+"""
+import hashlib
+import json
+import math
+import os
+
+import pytest
+import torch
+
+from oracle.ddim_oracle import DDIMScheduler
+from oracle.lora_oracle import LoRANetworkOracle
+from oracle.unet_oracle import build_unet
+from sliders_amd.config import CONFIGS
+from sliders_amd.ddim import DDIMSchedule
+from sliders_amd.lora_store import LoraStore
+from sliders_amd.modules import build_tree, lora_targets
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def test_param_counts_match_published_architectures():
+    """859,520,964 (SD-1.x) and 2,567,463,684 (SDXL-base) UNet parameters."""
+    for name, n in (("sd1", 859_520_964), ("sdxl", 2_567_463_684)):
+        net = build_unet(name, device="meta")
+        assert sum(p.numel() for p in net.parameters()) == n
+
+
+def test_module_tree_matches_oracle():
+    for name in ("sd1", "sdxl", "tiny_sd1", "tiny_sdxl"):
+        net = build_unet(name, device="meta")
+        a = [(n, m.__class__.__name__) for n, m in net.named_modules()]
+        b = [(n, m.cls) for n, m in build_tree(CONFIGS[name]()).named_modules()]
+        assert a == b
+
+
+def _key_shapes(store):
+    return [[k, list(v.shape)] for k, v in store.state_dict().items()]
+
+
+@pytest.mark.parametrize("name", ["sd1", "sdxl"])
+def test_lora_census_and_checkpoint_layout_match_reference(name):
+    """Key order, names and shapes of LoRANetwork.state_dict() (lora.py:231-248) - what the reference's
+    inference notebooks strict-load."""
+    gold = json.load(open(os.path.join(G, "lora_census.json")))
+    for method in ("noxattn", "full", "xattn", "selfattn", "innoxattn", "noxattn-hspace", "noxattn-hspace-last"):
+        ent = gold[f"{name}/{method}"]
+        tg = lora_targets(CONFIGS[name](), method)
+        assert len(tg) == ent["modules"]
+        keys = []
+        n_params = 0
+        for t in tg:
+            k = 3 if t.kind == "conv3" else 1
+            dn = [t.rank, t.in_dim] if t.kind == "linear" else [t.rank, t.in_dim, k, k]
+            up = [t.out_dim, t.rank] if t.kind == "linear" else [t.out_dim, t.rank, 1, 1]
+            keys += [[t.lora_name + ".alpha", []], [t.lora_name + ".lora_down.weight", dn],
+                     [t.lora_name + ".lora_up.weight", up]]
+            n_params += t.rank * t.in_dim * (9 if t.kind == "conv3" else 1) + t.out_dim * t.rank
+        assert n_params == ent["params"]
+        text = "\n".join(f"{k}:{tuple(s)}" for k, s in keys)
+        assert hashlib.sha256(text.encode()).hexdigest() == ent["sha256"], (name, method)
+        if "keys" in ent:
+            assert keys == ent["keys"]
+    assert gold["sd1/noxattn"]["modules"] == 150 and gold["sdxl/noxattn"]["modules"] == 346
+
+
+def test_lora_store_state_dict_roundtrip_and_layout():
+    cfg = CONFIGS["tiny_sdxl"]()
+    torch.manual_seed(3)
+    s = LoraStore(cfg, train_method="full")
+    s.params.copy_(torch.randn(s.numel).to(torch.bfloat16))
+    sd = s.state_dict()
+    s2 = LoraStore(cfg, train_method="full", init="none")
+    s2.load_state_dict(sd)
+    assert torch.equal(s.params, s2.params)
+    # fused groups are adjacent in the packed buffer
+    grp = s.fused_group([f"down_blocks.1.attentions.0.transformer_blocks.0.attn1.{x}" for x in ("to_q", "to_k", "to_v")])
+    assert grp is not None and grp[1].down_off == grp[0].down_off + grp[0].down_numel
+    with pytest.raises(KeyError):
+        s2.load_state_dict({k: v for k, v in list(sd.items())[3:]})
+
+
+def test_lora_oracle_matches_reference_golden():
+    """oracle/lora_oracle.py + oracle UNet reproduce what the reference's LoRANetwork / predict_noise[_xl] /
+    diffusion[_xl] computed (fp32) in the authoring container."""
+    gold = torch.load(os.path.join(G, "tiny_forward.pt"))
+    for key, e in gold.items():
+        name, method = key.split("/")
+        net = build_unet(name, seed=0)
+        nw = LoRANetworkOracle(net, rank=4, multiplier=1.0, alpha=1.0, train_method=method)
+        nw.load_state_dict(e["lora_state_dict"], strict=True)
+        lat, ctx, t = e["latents"], e["ctx"], e["t"]
+        kw = {"text_embeds": e["pooled"], "time_ids": e["time_ids"]} if "pooled" in e else None
+        sch = DDIMScheduler()
+        sch.set_timesteps(50)
+        with torch.no_grad():
+            with nw:
+                eps_on = net(torch.cat([lat] * 2), torch.tensor(t), ctx, kw).sample
+                u, c = eps_on.chunk(2)
+                pred = u + 3 * (c - u)
+                x = lat
+                for ts in sch.timesteps[0:3]:
+                    ep = net(torch.cat([x] * 2), ts, ctx, kw).sample
+                    uu, cc = ep.chunk(2)
+                    x = sch.step(uu + 3 * (cc - uu), ts, x).prev_sample
+            eps_off = net(torch.cat([lat] * 2), torch.tensor(t), ctx, kw).sample
+        for got, ref, nm in ((eps_on, e["eps_on"], "eps_on"), (eps_off, e["eps_off"], "eps_off"),
+                             (pred, e["pred_on_g3"], "pred"), (x, e["denoised_3"], "denoised")):
+            err = (got - ref).abs().max().item()
+            assert err < 2e-5, f"{key} {nm}: {err}"
+
+
+def test_loss_golden():
+    gold = torch.load(os.path.join(G, "loss.pt"))
+    t = gold["inputs"]
+    for action, sign in (("erase", -1), ("enhance", 1)):
+        tl = t["target"].clone().requires_grad_(True)
+        y = t["neutral"] + sign * 4.0 * (t["positive"] - t["unconditional"]) if sign == 1 else \
+            t["neutral"] - 4.0 * (t["positive"] - t["unconditional"])
+        l = torch.nn.functional.mse_loss(tl, y)
+        l.backward()
+        assert torch.equal(l.detach(), gold[action]["loss"])
+        assert torch.equal(tl.grad, gold[action]["grad"])
+
+
+def test_ddim_closed_form_and_tables():
+    sch = DDIMScheduler()
+    sch.set_timesteps(50)
+    assert sch.timesteps[:3].tolist() == [980, 960, 940] and sch.timesteps[-1].item() == 0
+    sch.set_timesteps(1000)
+    # reference quirk D.1: epsilon is evaluated at timesteps_1000[int(k*1000/50)] = 999 - 20k
+    assert [int(sch.timesteps[int(k * 1000 / 50)]) for k in (1, 25, 49)] == [979, 499, 19]
+    sch.set_timesteps(50)
+    a = torch.cumprod(1 - torch.linspace(0.00085 ** 0.5, 0.012 ** 0.5, 1000, dtype=torch.float64) ** 2, 0)
+    x = torch.randn(1, 4, 8, 8, dtype=torch.float64)
+    e = torch.randn(1, 4, 8, 8, dtype=torch.float64)
+    for t in (980, 500, 20, 0):
+        at, ap = a[t], (a[t - 20] if t >= 20 else torch.tensor(1.0, dtype=torch.float64))
+        x0 = (x - (1 - at).sqrt() * e) / at.sqrt()
+        ref = ap.sqrt() * x0 + (1 - ap).sqrt() * e
+        got = sch.step(e.float(), t, x.float()).prev_sample
+        assert (got.double() - ref).abs().max() < 5e-5 * max(1.0, ref.abs().max().item())
+        # product-side scalar table agrees with the oracle's
+        p = DDIMSchedule()
+        assert p.step_coefficients(t, 50) == sch.step_coefficients(t)
+    assert DDIMSchedule().make_timesteps(50) == sch.timesteps.tolist()
+
+
+def test_lora_init_follows_reference_rng_order():
+    """LoraStore.init_reference draws the RNG exactly like LoRAModule.__init__ (lora.py:68-97): same seed ->
+    same kaiming_uniform(a=1) down weights as the oracle network built module by module."""
+    cfg = CONFIGS["tiny_sdxl"]()
+    torch.manual_seed(1234)
+    s = LoraStore(cfg, train_method="noxattn")
+    net = build_unet("tiny_sdxl", seed=0)
+    torch.manual_seed(1234)
+    nw = LoRANetworkOracle(net, rank=4, multiplier=1.0, alpha=1.0, train_method="noxattn")
+    sd = s.state_dict()
+    for m in nw.unet_loras:
+        ref = m.lora_down.weight.detach().to(torch.bfloat16)
+        assert torch.equal(sd[m.lora_name + ".lora_down.weight"], ref), m.lora_name
+        assert sd[m.lora_name + ".lora_up.weight"].abs().max() == 0
