@@ -92,30 +92,63 @@ def measure_roofline(eng, plan):
     }
 
 
+def _mem_limit_gb():
+    for path in ("/sys/fs/cgroup/memory.max", "/sys/fs/cgroup/memory/memory.limit_in_bytes"):
+        try:
+            v = open(path).read().strip()
+            if v.isdigit():
+                return int(v) / 2 ** 30
+        except OSError:
+            pass
+    try:
+        return os.sysconf("SC_PAGE_SIZE") * os.sysconf("SC_PHYS_PAGES") / 2 ** 30
+    except (ValueError, OSError):
+        return 64.0
+
+
 def cpu_baseline(model, hw):
     """UNet denoise steps on the host cores with the CPU oracle (PyTorch restatement of the reference's
-    diffusers UNet).  Bounded to ~10-30 s of CPU work: the faster of bf16 / fp32 is picked with a short probe at
-    256x256, and if one full-resolution step would exceed the budget the largest resolution that fits is timed
-    and the rate is extrapolated by latent area (flagged in `sample`)."""
+    diffusers UNet).  Bounded to ~10-30 s of CPU work: the dtype (bf16 / fp32) is chosen with a GEMM
+    micro-probe (hosts without AMX run bf16 an order of magnitude slower), a 256x256 probe step estimates the
+    cost, and if one full-resolution step would exceed the budget the largest resolution that fits is timed and
+    the rate is extrapolated by latent area (flagged in `sample`)."""
     from oracle.unet_oracle import build_unet
     from sliders_amd.config import CONFIGS
+
+    def log(msg):
+        print(f"[cpu_baseline] {msg}", file=sys.stderr, flush=True)
+
     torch.set_num_threads(os.cpu_count())
     cfg = CONFIGS[model]()
+    a32, b32 = torch.randn(2048, 1280), torch.randn(1280, 1280)
+    tm = {}
+    for dt in (torch.float32, torch.bfloat16):
+        a, b = a32.to(dt), b32.to(dt)
+        a @ b
+        t0 = time.time()
+        for _ in range(5):
+            a @ b
+        tm[dt] = time.time() - t0
+    need32 = 4 * 2.6e9 / 2 ** 30 * 1.3 if model == "sdxl" else 6.0
+    dtype = torch.float32 if (tm[torch.float32] < tm[torch.bfloat16] and _mem_limit_gb() > need32 + 8) else torch.bfloat16
+    log(f"gemm probe fp32 {tm[torch.float32]:.3f}s bf16 {tm[torch.bfloat16]:.3f}s, mem limit {_mem_limit_gb():.0f} GB -> {dtype}")
     net = build_unet(model, device="meta")
     g = torch.Generator().manual_seed(0)
-    block = (torch.rand(1 << 22, generator=g) - 0.5) * 0.05
+    block = ((torch.rand(1 << 22, generator=g) - 0.5) * 0.05).to(dtype)
     sd = {}
     for k, v in net.state_dict().items():   # cheap init; every weight owns its memory (values do not matter)
         n = v.numel()
-        t = block.repeat((n + block.numel() - 1) // block.numel())[:n].reshape(v.shape).to(torch.bfloat16)
+        t = block.repeat((n + block.numel() - 1) // block.numel())[:n].reshape(v.shape).clone()
         if "norm" in k and k.endswith(".weight"):
             t = torch.ones_like(t)
         sd[k] = t
     net.load_state_dict(sd, assign=True)
+    del sd
     net.eval()
+    log("oracle built")
     B = 2
 
-    def run(h, dtype):
+    def run(h):
         x = torch.randn(B, 4, h, h).to(dtype)
         ctx = torch.randn(B, 77, cfg.cross_attention_dim).to(dtype)
         kw = None
@@ -130,24 +163,20 @@ def cpu_baseline(model, hw):
         return dt
 
     probe_hw = min(32, hw)
-    t_bf = run(probe_hw, torch.bfloat16)
-    net.float()
-    t_fp = run(probe_hw, torch.float32)
-    dtype, t_probe = (torch.float32, t_fp) if t_fp <= t_bf else (torch.bfloat16, t_bf)
-    if dtype == torch.bfloat16:
-        net.bfloat16()
+    t_probe = run(probe_hw)
+    log(f"probe step at {probe_hw * 8}px: {t_probe:.1f}s")
     budget = 30.0
     use_hw = hw
     while use_hw > probe_hw and t_probe * (use_hw / probe_hw) ** 2 > budget:
         use_hw //= 2
-    dt = run(use_hw, dtype) if use_hw != probe_hw else t_probe
+    dt = run(use_hw) if use_hw != probe_hw else t_probe
     scale = (hw / use_hw) ** 2
     note = "" if use_hw == hw else (f"; timed at {use_hw * 8}x{use_hw * 8} ({dt:.1f} s) and EXTRAPOLATED x{scale:.0f} by "
                                     f"latent area to {hw * 8}x{hw * 8}")
     return {"value": round(1.0 / (dt * scale), 5), "unit": "steps/s", "cores": os.cpu_count(), "kind": "port",
             "sample": f"1 UNet denoise step (CFG pair B=2, {model}, {'fp32' if dtype == torch.float32 else 'bf16'} "
-                      f"torch/oneDNN forward, probe bf16 {t_bf:.1f}s / fp32 {t_fp:.1f}s at {probe_hw * 8}px) with the CPU "
-                      f"oracle = PyTorch restatement of the diffusers UNet{note}"}
+                      f"torch/oneDNN forward, {dt:.1f} s) with the CPU oracle = PyTorch restatement of the diffusers "
+                      f"UNet{note}"}
 
 
 def main():
@@ -228,6 +257,8 @@ def main():
                    "iterations_per_s": round(a.steps * world / dt, 4), "prompt_pairs": len(pairs),
                    "parallelism": f"dp{world}", "final_loss": loss},
     }
+    if rank == 0:
+        print("[bench] timed region done: " + json.dumps({k: res[k] for k in ("value", "ms_per_step")}), file=sys.stderr, flush=True)
     if rank == 0 and world == 1:
         if not a.no_roofline:
             eng.set_lora(False)

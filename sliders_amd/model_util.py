@@ -1,0 +1,73 @@
+"""Model loading for the MI355X engine (the reference's trainscripts/textsliders/model_util.py:29-278 uses diffusers
+pipelines for this; here only the pieces the hot path needs).
+
+ * `load_unet_engine(name_or_path)`: a diffusers-format directory (`unet/config.json` +
+   `unet/diffusion_pytorch_model.safetensors`) -> UNetEngine.  Single-file `.ckpt/.safetensors` checkpoints
+   need the diffusers key conversion and are not supported yet.
+ * `load_text_encoders_xl / encode_prompts_xl`: CLIP text encoders through the installed `transformers`
+   (they run once before the loop - train_lora_xl.py:121-156 - and are not on the hot path).
+ * `create_noise_scheduler`: DDIM as configured at model_util.py:237-246; the other schedulers are out of scope.
+No checkpoints exist in the build image (HF_HUB_OFFLINE), so `synthetic_engine` provides seeded random-init
+weights with the real shapes for throughput runs and tests.
+"""
+from __future__ import annotations
+
+import os
+from typing import Optional, Tuple
+
+import torch
+
+from .config import CONFIGS, UNetConfig, config_from_json
+from .random_init import random_state_dict
+from .train_util import DDIMScheduler
+from .unet import UNetEngine
+
+
+def create_noise_scheduler(scheduler_name: str = "ddim", prediction_type: str = "epsilon"):
+    if scheduler_name.lower().replace(" ", "_") != "ddim" or prediction_type != "epsilon":
+        raise ValueError("only the DDIM / epsilon scheduler of the reference's default configs is implemented")
+    return DDIMScheduler()
+
+
+def load_unet_engine(name_or_path: str, device="cuda:0") -> UNetEngine:
+    unet_dir = os.path.join(name_or_path, "unet")
+    cfg_path = os.path.join(unet_dir, "config.json")
+    if not os.path.isfile(cfg_path):
+        raise FileNotFoundError(
+            f"{cfg_path} not found: pass a local diffusers-format model directory (this image has no network; "
+            f"use synthetic_engine() for random-init weights)")
+    cfg = config_from_json(cfg_path)
+    from safetensors.torch import load_file
+    wpath = os.path.join(unet_dir, "diffusion_pytorch_model.safetensors")
+    if not os.path.isfile(wpath):
+        wpath = os.path.join(unet_dir, "diffusion_pytorch_model.fp16.safetensors")
+    sd = load_file(wpath)
+    return UNetEngine(cfg, sd, device)
+
+
+def synthetic_engine(model: str = "sdxl", device="cuda:0", seed: int = 0) -> UNetEngine:
+    cfg = CONFIGS[model]()
+    return UNetEngine(cfg, random_state_dict(cfg, device, seed), device)
+
+
+def load_text_encoders_xl(name_or_path: str, device, dtype=torch.bfloat16):
+    from transformers import CLIPTextModel, CLIPTextModelWithProjection, CLIPTokenizer
+    toks = [CLIPTokenizer.from_pretrained(name_or_path, subfolder="tokenizer"),
+            CLIPTokenizer.from_pretrained(name_or_path, subfolder="tokenizer_2", pad_token_id=0)]
+    encs = [CLIPTextModel.from_pretrained(name_or_path, subfolder="text_encoder").to(device, dtype).eval(),
+            CLIPTextModelWithProjection.from_pretrained(name_or_path, subfolder="text_encoder_2").to(device, dtype).eval()]
+    return toks, encs
+
+
+@torch.no_grad()
+def encode_prompts_xl(tokenizers, text_encoders, prompts, num_images_per_prompt: int = 1) -> Tuple[torch.Tensor, torch.Tensor]:
+    """train_util.py:77-133: penultimate hidden states of both encoders concatenated (77 x 2048) + pooled (1280)."""
+    embeds, pooled = [], None
+    for tok, enc in zip(tokenizers, text_encoders):
+        ids = tok(prompts, padding="max_length", max_length=tok.model_max_length, truncation=True,
+                  return_tensors="pt").input_ids.to(enc.device)
+        out = enc(ids, output_hidden_states=True)
+        pooled = out[0]
+        embeds.append(out.hidden_states[-2])
+    text = torch.concat(embeds, dim=-1).repeat_interleave(num_images_per_prompt, dim=0)
+    return text, pooled.repeat_interleave(num_images_per_prompt, dim=0)
