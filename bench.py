@@ -96,7 +96,7 @@ def _mem_limit_gb():
     for path in ("/sys/fs/cgroup/memory.max", "/sys/fs/cgroup/memory/memory.limit_in_bytes"):
         try:
             v = open(path).read().strip()
-            if v.isdigit():
+            if v.isdigit() and int(v) < (1 << 50):
                 return int(v) / 2 ** 30
         except OSError:
             pass

@@ -55,6 +55,9 @@ typedef struct slh_gemm_desc {
     const float* lora_scale; /* device scalar: multiplier * alpha / rank */
     const void* residual;    /* [M][ld_res] bf16 or NULL (may alias c) */
     void* c;                 /* [M][ldc] bf16 (N/2 columns when geglu) */
+    const void* lora_down;   /* [rank][K] bf16 or NULL: FUSED down-projection, T = A.lora_down^T is computed inside
+                                the same kernel (rank = 4*lora_groups <= 12); excludes lora_t */
+    float* lora_t_out;       /* optional [M][ld_t] fp32: the fused T, kept for the backward pass */
     int32_t lda0, lda1, ca0, ca1;
     int32_t mode;            /* 0 dense, 1 conv3x3 */
     int32_t batch, hs, ws;   /* conv: source image dims */

@@ -25,6 +25,7 @@ struct GemmArgs {
     const __bf16* a0; const __bf16* a1; const __bf16* w;
     const __bf16* bias; const __bf16* rowbias; const float* lora_t; const __bf16* lora_up;
     const float* lora_scale; const __bf16* residual; __bf16* c;
+    const __bf16* lora_down; float* lora_t_out;
     int lda0, lda1, ca0, ca1;
     int hs, ws, src_xform, stride, ho, wo;
     int ldw, M, N, K;
@@ -40,15 +41,20 @@ __device__ __forceinline__ int lds_off(int row, int slot) {
     return row * 128 + ((slot ^ ((row >> 1) & 7)) << 4);
 }
 
-template <int MI, int NI, int MODE, int STAGES>
+template <int MI, int NI, int MODE, int STAGES, bool LORA>
 __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
     constexpr int BM = 64 * MI;
     constexpr int BN = 64 * NI;
     constexpr int XI = BM / 32;  // glds instructions per wave for the X tile (8 rows each, 4 waves)
     constexpr int WI = BN / 32;
-    __shared__ __attribute__((aligned(16))) char smem[STAGES * (BM + BN) * 128];
+    // LORA: the rank-r down matrix A (lora_down, [r][K], r <= 12, zero-padded to 32 rows) rides along as a third
+    // operand tile; every wave multiplies it with the X fragments it already holds, so T = X.A^T of the block's own
+    // rows is available in registers for the epilogue without a separate pass over X (lora.py:108-112 fused).
+    constexpr int LROWS = LORA ? 32 : 0;
+    __shared__ __attribute__((aligned(16))) char smem[STAGES * (BM + BN + LROWS) * 128];
     char* sX = smem;                        // [STAGES][BM][128 B]
     char* sW = smem + STAGES * BM * 128;    // [STAGES][BN][128 B]
+    char* sL = smem + STAGES * (BM + BN) * 128;   // [STAGES][32][128 B]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -141,6 +147,13 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
         }
 #pragma unroll
         for (int i = 0; i < WI; ++i) glds16(wptr[i] + k0, dW + (wave + 4 * i) * 1024);
+        if (LORA) {
+            const int row = wave * 8 + frow;
+            const __bf16* src = row < p.lora_rank
+                                    ? p.lora_down + (long)row * p.K + k0 + ((fslot ^ ((row >> 1) & 7)) << 3)
+                                    : (const __bf16*)slh_zero_page;
+            glds16(src, sL + buf * (32 * 128) + wave * 1024);
+        }
     };
 
     f32x16 acc[MI][NI];
@@ -151,26 +164,46 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+    f32x16 accl[MI];   // LORA: accl[i][r'] = T[m = ...i*32 + lrow][rank index (r'&3) + 8*(r'>>2) + 4*lhi]
+    if (LORA) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) accl[i][r] = 0.f;
+    }
     const int nk = p.K / BK;
     const int lrow = lane & 31, lhi = lane >> 5;
 
     auto compute = [&](int buf) {
         const char* cX = sX + buf * (BM * 128);
         const char* cW = sW + buf * (BN * 128);
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            bf16x8 xf[MI], wf[NI];
+        // fragments are double-buffered in registers: the ds_read_b128 of k-step ks+1 are issued before the MFMAs
+        // of k-step ks, so LDS latency hides under the matrix pipe instead of being exposed 4x per K tile
+        const char* cL = sL + buf * (32 * 128);
+        bf16x8 xf[2][MI], wf[2][NI], lf[2];
+        auto load_frags = [&](int set, int ks) {
+            if (LORA) lf[set] = *(const bf16x8*)(cL + lds_off(lrow, ks * 2 + lhi));
 #pragma unroll
             for (int i = 0; i < MI; ++i)
-                xf[i] = *(const bf16x8*)(cX + lds_off(wm * (32 * MI) + i * 32 + lrow, ks * 2 + lhi));
+                xf[set][i] = *(const bf16x8*)(cX + lds_off(wm * (32 * MI) + i * 32 + lrow, ks * 2 + lhi));
 #pragma unroll
             for (int j = 0; j < NI; ++j)
-                wf[j] = *(const bf16x8*)(cW + lds_off(wn * (32 * NI) + j * 32 + lrow, ks * 2 + lhi));
+                wf[set][j] = *(const bf16x8*)(cW + lds_off(wn * (32 * NI) + j * 32 + lrow, ks * 2 + lhi));
+        };
+        load_frags(0, 0);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            if (ks < 3) load_frags((ks + 1) & 1, ks + 1);
 #pragma unroll
             for (int i = 0; i < MI; ++i)
 #pragma unroll
                 for (int j = 0; j < NI; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[j], xf[i], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks & 1][j], xf[ks & 1][i], acc[i][j], 0, 0, 0);
+            if (LORA) {
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+                    accl[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lf[ks & 1], xf[ks & 1][i], accl[i], 0, 0, 0);
+            }
         }
     };
 
@@ -185,7 +218,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
         // 3-deep ring: tile kt+1 stays in flight across the barrier (counted vmcnt, raw s_barrier), tile kt+2
         // is issued right after it.  A wave's own glds for tile kt are retired by vmcnt(L); the barrier then
         // guarantees every wave's share has landed and that nobody still reads the slot being refilled.
-        constexpr int L = XI + WI;   // LDS-DMA instructions per wave per stage
+        constexpr int L = XI + WI + (LORA ? 1 : 0);   // LDS-DMA instructions per wave per stage
         stage(0, 0);
         if (nk > 1) stage(1, 1);
         int cur = 0;
@@ -201,13 +234,30 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
 
     // ---- epilogue ---------------------------------------------------------------------------------
     // acc[i][j][r] = C[m = m0 + wm*32*MI + i*32 + lrow][n = n0 + wn*32*NI + j*32 + (r&3) + 8*(r>>2) + 4*lhi]
-    const float lscale = p.lora_t ? *p.lora_scale : 0.f;
+    const bool have_t = LORA || p.lora_t != nullptr;
+    const float lscale = have_t ? *p.lora_scale : 0.f;
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
         const int m = m0 + wm * (32 * MI) + i * 32 + lrow;
         if (m >= p.M) continue;
         f32x4 tv[3];
-        if (p.lora_t) {
+        if (LORA) {
+            // ranks 0-3 sit in registers 0-3 of the lhi=0 half, 4-7 in registers 0-3 of the lhi=1 half, 8-11 in
+            // registers 4-7 of the lhi=0 half: one exchange with lane^32 gives every lane all of its row's T
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float x0 = accl[i][e], x1 = accl[i][4 + e];
+                const float y0 = __shfl_xor(x0, 32, 64), y1 = __shfl_xor(x1, 32, 64);
+                tv[0][e] = lhi == 0 ? x0 : y0;
+                tv[1][e] = lhi == 1 ? x0 : y0;
+                tv[2][e] = lhi == 0 ? x1 : y1;
+            }
+            if (p.lora_t_out && tile_n == 0 && wn == 0 && lhi == 0) {
+#pragma unroll
+                for (int g = 0; g < 3; ++g)
+                    if (g * 4 < p.lora_rank) *(f32x4*)(p.lora_t_out + (long)m * p.ld_t + g * 4) = tv[g];
+            }
+        } else if (p.lora_t) {
 #pragma unroll
             for (int g = 0; g < 3; ++g)
                 if (g * 4 < p.ld_t) tv[g] = *(const f32x4*)(p.lora_t + (long)m * p.ld_t + g * 4);
@@ -233,7 +283,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) v[e] += (float)b4[e];
                     }
-                    if (p.lora_t && !p.lora_up_rmajor) {
+                    if (have_t && !p.lora_up_rmajor) {
                         const int g = n / p.lora_cols_per_group;
                         const f32x4 t = g == 0 ? tv[0] : (g == 1 ? tv[1] : tv[2]);
 #pragma unroll
@@ -242,7 +292,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
                             v[e] += lscale * (t[0] * (float)u[0] + t[1] * (float)u[1] +
                                               t[2] * (float)u[2] + t[3] * (float)u[3]);
                         }
-                    } else if (p.lora_t) {
+                    } else if (have_t) {
                         // backward-data form: the "up" matrix is lora_down as stored, [rank][N], rank 4..12
                         float s4[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -302,16 +352,21 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
     }
 }
 
-template <int MI, int NI>
-int launch_gemm(const GemmArgs& a, int mode, int stages, hipStream_t s) {
+template <int MI, int NI, int MODE, bool LORA>
+int launch_gemm2(const GemmArgs& a, int stages, hipStream_t s) {
     const int grid = a.tiles_m * a.tiles_n;
-    if (stages == 3 && MI + NI <= 3) {   // 3 x 64 KB would not fit for the 128x128 tile
-        if (mode == 0) hipLaunchKernelGGL((gemm_kernel<MI, NI, 0, (MI + NI <= 3 ? 3 : 2)>), dim3(grid), dim3(256), 0, s, a);
-        else hipLaunchKernelGGL((gemm_kernel<MI, NI, 1, (MI + NI <= 3 ? 3 : 2)>), dim3(grid), dim3(256), 0, s, a);
-    } else if (mode == 0) hipLaunchKernelGGL((gemm_kernel<MI, NI, 0, 2>), dim3(grid), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((gemm_kernel<MI, NI, 1, 2>), dim3(grid), dim3(256), 0, s, a);
+    constexpr bool can3 = (MI + NI <= 3);   // 3 x 64 KB would not fit for the 128x128 tile
+    if (stages == 3 && can3) hipLaunchKernelGGL((gemm_kernel<MI, NI, MODE, (can3 ? 3 : 2), LORA>), dim3(grid), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((gemm_kernel<MI, NI, MODE, 2, LORA>), dim3(grid), dim3(256), 0, s, a);
     SLH_LAUNCH_CHECK("slh_gemm");
     return 0;
+}
+
+template <int MI, int NI>
+int launch_gemm(const GemmArgs& a, int mode, int stages, hipStream_t s) {
+    const bool lora = a.lora_down != nullptr;
+    if (mode == 0) return lora ? launch_gemm2<MI, NI, 0, true>(a, stages, s) : launch_gemm2<MI, NI, 0, false>(a, stages, s);
+    return lora ? launch_gemm2<MI, NI, 1, true>(a, stages, s) : launch_gemm2<MI, NI, 1, false>(a, stages, s);
 }
 
 }  // namespace
@@ -356,6 +411,14 @@ extern "C" int slh_gemm(const slh_gemm_desc* d, slh_stream_t stream) {
         SLH_CHECK(d->src_xform >= 0 && d->src_xform <= 2, "slh_gemm: bad src_xform");
         SLH_CHECK(d->M == d->batch * d->ho * d->wo, "slh_gemm: conv M mismatch");
     }
+    if (d->lora_down) {
+        SLH_CHECK(!d->lora_t && d->lora_up && d->lora_scale && !d->lora_up_rmajor && !d->geglu,
+                  "slh_gemm: fused lora_down excludes an external T / r-major up / geglu");
+        SLH_CHECK(d->lora_groups >= 1 && d->lora_groups <= 3 && d->lora_rank == 4 * d->lora_groups &&
+                      d->N % d->lora_groups == 0 && (d->N / d->lora_groups) % 4 == 0,
+                  "slh_gemm: fused lora needs rank = 4 * groups");
+        if (d->lora_t_out) SLH_CHECK(d->ld_t >= d->lora_rank && d->ld_t % 4 == 0, "slh_gemm: ld_t for lora_t_out");
+    }
     if (d->lora_t) {
         SLH_CHECK(d->lora_up && d->lora_scale, "slh_gemm: lora pointers");
         SLH_CHECK(d->lora_groups >= 1 && d->lora_groups <= 3 && d->N % d->lora_groups == 0 &&
@@ -381,11 +444,12 @@ extern "C" int slh_gemm(const slh_gemm_desc* d, slh_stream_t stream) {
     a.bias = (const __bf16*)d->bias; a.rowbias = (const __bf16*)d->rowbias; a.lora_t = d->lora_t;
     a.lora_up = (const __bf16*)d->lora_up; a.lora_scale = d->lora_scale;
     a.residual = (const __bf16*)d->residual; a.c = (__bf16*)d->c;
+    a.lora_down = (const __bf16*)d->lora_down; a.lora_t_out = d->lora_t_out;
     a.lda0 = d->lda0; a.lda1 = d->lda1; a.ca0 = d->ca0; a.ca1 = d->ca1;
     a.hs = d->hs; a.ws = d->ws; a.src_xform = d->src_xform; a.stride = d->stride; a.ho = d->ho; a.wo = d->wo;
     a.ldw = d->ldw; a.M = d->M; a.N = d->N; a.K = d->K;
     a.ld_rowbias = d->ld_rowbias; a.rows_per_sample = d->rows_per_sample > 0 ? d->rows_per_sample : 1;
-    a.ld_t = d->ld_t; a.lora_cols_per_group = d->lora_t ? d->N / d->lora_groups : 1;
+    a.ld_t = d->ld_t; a.lora_cols_per_group = (d->lora_t || d->lora_down) ? d->N / d->lora_groups : 1;
     a.ld_res = d->ld_res; a.ldc = d->ldc; a.geglu = d->geglu;
     a.lora_rank = d->lora_rank > 0 ? d->lora_rank : 4; a.lora_up_rmajor = d->lora_up_rmajor;
     a.tiles_m = (d->M + 64 * MI - 1) / (64 * MI);

@@ -29,7 +29,7 @@ def _ints(*names):
 
 
 GemmDesc = _struct("GemmDesc", _ptrs("a0", "a1", "w", "bias", "rowbias", "lora_t", "lora_up", "lora_scale",
-                                     "residual", "c")
+                                     "residual", "c", "lora_down", "lora_t_out")
                    + _ints("lda0", "lda1", "ca0", "ca1", "mode", "batch", "hs", "ws", "src_xform", "stride",
                            "ho", "wo", "ldw", "M", "N", "K", "ld_rowbias", "rows_per_sample", "ld_t",
                            "lora_groups", "ld_res", "ldc", "geglu", "tile", "lora_rank", "lora_up_rmajor"))

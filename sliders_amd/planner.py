@@ -14,6 +14,7 @@ unfused so its pre-activation is available; `build_backward()` then emits the ba
 """
 from __future__ import annotations
 
+import os
 from dataclasses import dataclass, field
 from typing import Dict, List, Optional, Tuple, Union
 
@@ -174,14 +175,21 @@ class UNetPlan:
             out = self.act(B, Ho, Wo, Nout, name)
         grp = self._lora_group(lora_paths) if lora_paths else None
         T = None
+        fused = grp is not None and os.environ.get("SLIDERS_LORA_UNFUSED") is None
         if grp is not None:
             R = sum(e.target.rank for e in grp)
-            T = self.skinny(x, self.lora.down_ptr(grp[0]), R, K, conv, M, Ho, Wo, name + ".lora_down")
+            if fused:
+                # lora_down rides inside the GEMM (third operand tile); T is only written out for the backward
+                T = self.f32((M, R), name + ".T") if self.train else None
+            else:
+                T = self.skinny(x, self.lora.down_ptr(grp[0]), R, K, conv, M, Ho, Wo, name + ".lora_down")
         d = lib.GemmDesc(a0=x0.ptr, a1=x1.ptr if x1 else 0,
                          w=w_ptr if w_ptr is not None else self.w.ptr(wname + ".w"),
                          bias=(bias_ptr if bias_ptr is not None else (self.w.ptr(wname + ".b") if bias else 0)),
                          rowbias=rowbias[0] if rowbias else 0,
-                         lora_t=T.ptr if T else 0, lora_up=self.lora.up_ptr(grp[0]) if grp else 0,
+                         lora_t=T.ptr if (T and not fused) else 0, lora_up=self.lora.up_ptr(grp[0]) if grp else 0,
+                         lora_down=self.lora.down_ptr(grp[0]) if fused else 0,
+                         lora_t_out=T.ptr if (T and fused) else 0, lora_rank=(4 * len(grp)) if fused else 0,
                          lora_scale=self.lora_scale_ptr if grp else 0,
                          residual=residual.ptr if residual else 0, c=out.ptr,
                          lda0=x0.ld, lda1=x1.ld if x1 else 0, ca0=x0.C, ca1=x1.C if x1 else 0,

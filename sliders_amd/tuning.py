@@ -32,4 +32,8 @@ def tuned_tile(d) -> int:
     """0 = no entry (library heuristic)."""
     if os.environ.get("SLIDERS_NO_TUNING"):
         return 0
-    return table().get(gemm_key(d), 0)
+    t = table().get(gemm_key(d), 0)
+    force = os.environ.get("SLIDERS_FORCE_STAGES")     # experiment knob: 2 or 3 for every non-128x128 tile
+    if force and t and (t & 0xFF) != 0x22:
+        t = (t & 0xFF) | (int(force) << 8 if force == "3" else 0)
+    return t

@@ -435,3 +435,52 @@ def test_lora_wgrad(dev):
     yy = F.conv2d(img.float(), wd, padding=1)
     yy.backward(U.view(B, H, W, 4).permute(0, 3, 1, 2))
     report("wgrad_conv", out, 0.25 * wd.grad.permute(0, 2, 3, 1).reshape(4, -1), 1e-4)
+
+
+@pytest.mark.parametrize("tile", [0x22, 0x21, 0x12, 0x11, 0x311])
+def test_gemm_fused_lora_down(dev, tile):
+    """LoRAModule.forward fused into one launch: y = x W^T + b + s (x A^T) B^T, T = x A^T written for backward."""
+    torch.manual_seed(31)
+    for groups, M, N, K in ((1, 300, 320, 640), (3, 512, 3 * 128, 1280)):
+        x = bf(torch.randn(M, K, device=dev))
+        w = bf(torch.randn(N, K, device=dev) / math.sqrt(K))
+        b = bf(torch.randn(N, device=dev))
+        A = bf(torch.randn(4 * groups, K, device=dev) / math.sqrt(K))
+        up = bf(torch.randn(N, 4, device=dev))
+        scale = torch.tensor([0.25], device=dev)
+        c = torch.zeros(M, N, device=dev, dtype=torch.bfloat16)
+        Tout = torch.zeros(M, 4 * groups, device=dev)
+        d = lib.GemmDesc(a0=p(x), w=p(w), bias=p(b), c=p(c), lora_down=p(A), lora_up=p(up), lora_scale=p(scale),
+                         lora_t_out=p(Tout), lda0=K, ca0=K, mode=0, stride=1, ldw=K, M=M, N=N, K=K, ldc=N,
+                         rows_per_sample=M, ld_t=4 * groups, lora_groups=groups, lora_rank=4 * groups, tile=tile)
+        lib.call(lib.OP_GEMM, d, stream())
+        torch.cuda.synchronize()
+        T = x.float() @ A.float().t()
+        ref = x.float() @ w.float().t() + b.float()
+        ng = N // groups
+        for g in range(groups):
+            ref[:, g * ng:(g + 1) * ng] += 0.25 * T[:, 4 * g:4 * g + 4] @ up.float()[g * ng:(g + 1) * ng].t()
+        report(f"gemm_fused_lora g{groups} tile{tile:x}", c, ref, TOL)
+        report(f"gemm_fused_lora T g{groups} tile{tile:x}", Tout, T, 1e-5)
+    # conv form (3x3, stride 2) with the down matrix in [r][tap][Cin] order
+    B, H, W, Ci, Co = 2, 16, 12, 64, 128
+    img = bf(torch.randn(B, Ci, H, W, device=dev))
+    w4 = bf(torch.randn(Co, Ci, 3, 3, device=dev) / math.sqrt(9 * Ci))
+    a4 = bf(torch.randn(4, Ci, 3, 3, device=dev) / math.sqrt(9 * Ci))
+    up = bf(torch.randn(Co, 4, device=dev))
+    scale = torch.tensor([0.25], device=dev)
+    ref_img = _conv_ref(img.float(), w4.float(), 2)
+    t_img = _conv_ref(img.float(), a4.float(), 2)
+    Ho, Wo = ref_img.shape[2:]
+    ref = _to_pix(ref_img) + 0.25 * _to_pix(t_img) @ up.float().t()
+    M = B * Ho * Wo
+    c = torch.zeros(M, Co, device=dev, dtype=torch.bfloat16)
+    Tout = torch.zeros(M, 4, device=dev)
+    d = lib.GemmDesc(a0=p(bf(_to_pix(img.float()))), w=p(_pack_conv(w4)), c=p(c), lora_down=p(_pack_conv(a4)), lora_up=p(up),
+                     lora_scale=p(scale), lora_t_out=p(Tout), lda0=Ci, ca0=Ci, mode=1, batch=B, hs=H, ws=W, stride=2, ho=Ho,
+                     wo=Wo, ldw=9 * Ci, M=M, N=Co, K=9 * Ci, ldc=Co, rows_per_sample=Ho * Wo, ld_t=4, lora_groups=1,
+                     lora_rank=4, tile=tile)
+    lib.call(lib.OP_GEMM, d, stream())
+    torch.cuda.synchronize()
+    report(f"conv_fused_lora tile{tile:x}", c, ref, TOL)
+    report(f"conv_fused_lora T tile{tile:x}", Tout, _to_pix(t_img), 1e-5)
