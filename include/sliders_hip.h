@@ -258,6 +258,7 @@ int slh_elementwise(const slh_ew_desc* d, slh_stream_t stream);
 typedef struct slh_cfg_ddim_desc {
     const void* eps; const void* x; void* out;
     void* out2;              /* optional second copy of the result (the CFG pair's duplicated latent input) */
+    const void* eps_text;    /* optional: text-half epsilon [nb][chw] when it is not stored right after the uncond half */
     int32_t nb, chw;
     float guidance;
     float c_sqrt_beta_t, c_inv_sqrt_alpha_t, c_sqrt_alpha_prev, c_dir;

@@ -178,7 +178,8 @@ __global__ __launch_bounds__(256) void cfg_ddim_kernel(const slh_cfg_ddim_desc d
     const long n = (long)d.nb * d.chw;
     if (i >= n) return;
     const __bf16* eps = (const __bf16*)d.eps;
-    const float u = (float)eps[i], t = (float)eps[n + i];
+    const float u = (float)eps[i];
+    const float t = d.eps_text ? (float)((const __bf16*)d.eps_text)[i] : (float)eps[n + i];
     // train_util.py:166-169: uncond + g * (text - uncond), every tensor op rounds to bf16
     const float diff = round_bf16(t - u);
     const float scaled = round_bf16(d.guidance * diff);

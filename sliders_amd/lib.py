@@ -59,7 +59,7 @@ TembedDesc = _struct("TembedDesc", _ptrs("vals", "out") + _ints("nb", "n_vals", 
 ConvInDesc = _struct("ConvInDesc", _ptrs("x", "w", "bias", "y") + _ints("batch", "cin", "h", "wd", "cout", "ldy"))
 EwDesc = _struct("EwDesc", _ptrs("a", "b", "out") + _ints("M", "C", "lda", "ldb", "ldo", "op", "iarg", "iarg2")
                  + [("alpha", c_f32)] + _ints("pad_"))
-CfgDdimDesc = _struct("CfgDdimDesc", _ptrs("eps", "x", "out", "out2") + _ints("nb", "chw")
+CfgDdimDesc = _struct("CfgDdimDesc", _ptrs("eps", "x", "out", "out2", "eps_text") + _ints("nb", "chw")
                       + [("guidance", c_f32), ("c_sqrt_beta_t", c_f32), ("c_inv_sqrt_alpha_t", c_f32),
                          ("c_sqrt_alpha_prev", c_f32), ("c_dir", c_f32)] + _ints("do_step"))
 LossDesc = _struct("LossDesc", _ptrs("target", "positive", "neutral", "uncond", "loss", "dtarget", "dtarget_pix")

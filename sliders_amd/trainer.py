@@ -54,7 +54,8 @@ def _stream() -> int:
 class SliderTrainer:
     def __init__(self, engine: UNetEngine, store: LoraStore, H: int, W: int, batch_size: int = 1,
                  lr: float = 2e-4, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.01,
-                 max_denoising_steps: int = 50, denoise_guidance: float = 3.0, process_group=None):
+                 max_denoising_steps: int = 50, denoise_guidance: float = 3.0, process_group=None,
+                 dedup_frozen: bool = True):
         self.eng, self.store = engine, store
         self.H, self.W, self.bs = H, W, batch_size
         self.lr, self.betas, self.eps, self.wd = lr, betas, eps, weight_decay
@@ -79,6 +80,7 @@ class SliderTrainer:
         self.t50 = self.sched.make_timesteps(max_denoising_steps)
         self.t1000 = self.sched.make_timesteps(1000)
         self.unet_passes = 0
+        self.dedup_frozen = dedup_frozen
 
     # ---- helpers ------------------------------------------------------------------------------------
     def _load_cond(self, p, ctx, pooled):
@@ -92,9 +94,9 @@ class SliderTrainer:
         s[: self.bs].copy_(lat)
         s[self.bs:].copy_(lat)
 
-    def _cfg(self, p, out, guidance, coeff=None, out2=None, x=None):
-        d = lib.CfgDdimDesc(eps=p.io["eps"].ptr, x=x or 0, out=out, out2=out2 or 0, nb=self.bs, chw=self.chw,
-                            guidance=guidance, do_step=0)
+    def _cfg(self, p, out, guidance, coeff=None, out2=None, x=None, eps_text=None):
+        d = lib.CfgDdimDesc(eps=p.io["eps"].ptr, x=x or 0, out=out, out2=out2 or 0, eps_text=eps_text or 0,
+                            nb=self.bs, chw=self.chw, guidance=guidance, do_step=0)
         if coeff is not None:
             d.c_sqrt_beta_t, d.c_inv_sqrt_alpha_t, d.c_sqrt_alpha_prev, d.c_dir = coeff
             d.do_step = 1
@@ -107,6 +109,34 @@ class SliderTrainer:
         p.prog.run(_stream())
         self.unet_passes += 1
         self._cfg(p, out.data_ptr(), 1.0)
+
+    def _frozen_dedup(self, pair: PairEmbeds, t_cur: int):
+        """The reference's three frozen predictions are CFG pairs [uncond; positive], [uncond; neutral] and
+        [uncond; uncond] on the SAME latents and timestep (train_lora_xl.py:236-295): five of the six samples
+        are the unconditional one.  One UNet pass over [uncond, positive, neutral] produces the same three epsilon
+        tensors (kernels are deterministic per sample); the combines `u + 1*(x - u)` keep the reference's bf16
+        rounding.  Still counted as 3 denoise steps (that is what the reference executes)."""
+        eng, bs = self.eng, self.bs
+        p3 = eng.plan(3 * bs, self.H, self.W, "off")
+        s = p3.io["sample"].tensor
+        for j in range(3):
+            s[j * bs:(j + 1) * bs].copy_(self.denoised)
+        ctx = p3.io["ctx"].tensor
+        ctx[:bs].copy_(pair.ctx_uncond[:bs]); ctx[bs:2 * bs].copy_(pair.ctx_positive[bs:]); ctx[2 * bs:].copy_(pair.ctx_neutral[bs:])
+        if eng.cfg.is_xl:
+            p3.io["time_ids"].tensor.copy_(self.time_ids[:1].expand(3 * bs, 6))
+            ai = p3.io["add_in"].tensor
+            pd = eng.cfg.pooled_dim
+            ai[:bs, :pd].copy_(pair.pooled_uncond[:bs]); ai[bs:2 * bs, :pd].copy_(pair.pooled_positive[bs:])
+            ai[2 * bs:, :pd].copy_(pair.pooled_neutral[bs:])
+        p3.io["t"].tensor.fill_(float(t_cur))
+        p3.prog.run(_stream())
+        self.unet_passes += 3
+        e = p3.io["eps"].ptr
+        blk = bs * self.chw * 2
+        self._cfg(p3, self.e_pos.data_ptr(), 1.0, eps_text=e + blk)
+        self._cfg(p3, self.e_neu.data_ptr(), 1.0, eps_text=e + 2 * blk)
+        self._cfg(p3, self.e_unc.data_ptr(), 1.0, eps_text=e)
 
     # ---- one iteration ------------------------------------------------------------------------------
     def iteration(self, pair: PairEmbeds, k: int, noise: torch.Tensor) -> torch.Tensor:
@@ -132,10 +162,13 @@ class SliderTrainer:
         t_cur = self.t1000[int(k * 1000 / self.nsteps)]
         # 2. frozen-model predictions, adapters off (train_lora_xl.py:236-295)
         eng.set_lora(False)
-        p_off = eng.plan(B, self.H, self.W, "off")
-        self._predict(p_off, self.denoised, pair.ctx_positive, pair.pooled_positive, t_cur, self.e_pos)
-        self._predict(p_off, self.denoised, pair.ctx_neutral, pair.pooled_neutral, t_cur, self.e_neu)
-        self._predict(p_off, self.denoised, pair.ctx_uncond, pair.pooled_uncond, t_cur, self.e_unc)
+        if self.dedup_frozen:
+            self._frozen_dedup(pair, t_cur)
+        else:
+            p_off = eng.plan(B, self.H, self.W, "off")
+            self._predict(p_off, self.denoised, pair.ctx_positive, pair.pooled_positive, t_cur, self.e_pos)
+            self._predict(p_off, self.denoised, pair.ctx_neutral, pair.pooled_neutral, t_cur, self.e_neu)
+            self._predict(p_off, self.denoised, pair.ctx_uncond, pair.pooled_uncond, t_cur, self.e_unc)
         # 3. target prediction with the adapters on, kept for backward (train_lora_xl.py:302-322)
         eng.set_lora(True, 1.0)
         p_tr = eng.plan(B, self.H, self.W, "train")

@@ -115,7 +115,9 @@ class UNetEngine:
         p = self._plans.get(key)
         if p is not None:
             return p
-        modes = ["off"] + (["on", "train"] if self.lora is not None else [])
+        # size the shared arena for the requested plan and, once adapters are attached, for the training plan
+        # of the same shape (so 'on' -> 'train' does not trigger a regrow that invalidates cached plans)
+        modes = {mode} | ({"train"} if (self.lora is not None and mode != "off") else set())
         need = max(self._virtual_size(B, H, W, m) for m in modes)
         self._ensure_arena(need)
         if mode == "train":

@@ -1,0 +1,123 @@
+"""Step-level parity: one whole training iteration of the fused trainer (sliders_amd/trainer.py) against the same
+iteration written with the reference's loop structure (train_lora_xl.py:162-356) on the CPU oracle in fp32:
+partial DDIM denoise with adapters on (guidance 3), three frozen predictions, target prediction, guidance loss,
+backward.  Also: the de-duplicated frozen pass equals the three separate CFG-pair passes."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle.ddim_oracle import DDIMScheduler
+from oracle.lora_oracle import LoRANetworkOracle
+from oracle.unet_oracle import build_unet
+from sliders_amd.config import CONFIGS
+from sliders_amd.lora_store import LoraStore
+from sliders_amd.trainer import PairEmbeds, SliderTrainer
+from sliders_amd.unet import UNetEngine
+from tests.util import rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(dev, name="tiny_sdxl", seed=5):
+    cfg = CONFIGS[name]()
+    g = torch.Generator().manual_seed(seed)
+    torch.manual_seed(seed)
+    store = LoraStore(cfg, rank=4, alpha=1.0, train_method="noxattn", device=dev)
+    for e in store.entries:
+        store.params[e.up_off:e.up_off + e.up_numel] = (torch.randn(e.up_numel, generator=g) * 0.03).to(dev, torch.bfloat16)
+    emb = {k: torch.randn(1, 77, cfg.cross_attention_dim, generator=g) for k in ("target", "positive", "neutral", "uncond")}
+    pool = {k: torch.randn(1, cfg.pooled_dim, generator=g) for k in emb}
+    noise = torch.randn(1, 4, 16, 16, generator=g)
+    return cfg, store, emb, pool, noise
+
+
+def _pair(emb, pool, dev):
+    cat = lambda x: torch.cat([emb["uncond"], x]).to(dev, torch.bfloat16).contiguous()
+    pc = lambda x: torch.cat([pool["uncond"], x]).to(dev, torch.bfloat16).contiguous()
+    return PairEmbeds(cat(emb["target"]), cat(emb["positive"]), cat(emb["neutral"]), cat(emb["uncond"]),
+                      pc(pool["target"]), pc(pool["positive"]), pc(pool["neutral"]), pc(pool["uncond"]),
+                      guidance_scale=4.0, action="enhance")
+
+
+def test_iteration_matches_reference_loop_on_oracle(dev):
+    name, k, hw = "tiny_sdxl", 3, 16
+    cfg, store, emb, pool, noise = _setup(dev)
+    sd = store.state_dict()
+    params0 = store.params.clone()
+    eng = UNetEngine(cfg, build_unet(name, seed=0).state_dict(), dev)
+    tr = SliderTrainer(eng, store, hw, hw, lr=2e-4)
+    loss = tr.iteration(_pair(emb, pool, dev), k, noise.to(dev))
+    torch.cuda.synchronize()
+    assert tr.unet_passes == k + 4
+    # ---- the reference loop on the oracle (fp32) ----
+    net = build_unet(name, seed=0)
+    nw = LoRANetworkOracle(net, rank=4, multiplier=1.0, alpha=1.0, train_method="noxattn")
+    nw.load_state_dict(sd, strict=True)
+    for p_ in nw.parameters():
+        p_.requires_grad_(True)
+    sch = DDIMScheduler()
+    tid = torch.tensor([[128.0, 128.0, 0, 0, 128.0, 128.0]] * 2)
+
+    def predict(x, which, t, g):
+        ctx = torch.cat([emb["uncond"], emb[which]])
+        kw = {"text_embeds": torch.cat([pool["uncond"], pool[which]]), "time_ids": tid}
+        e = net(torch.cat([x] * 2), t, ctx, kw).sample
+        u, c = e.chunk(2)
+        return u + g * (c - u)
+
+    with torch.no_grad():
+        sch.set_timesteps(50)
+        x = noise.clone()
+        with nw:
+            for t in sch.timesteps[0:k]:
+                x = sch.step(predict(x, "target", t, 3), t, x).prev_sample
+        sch.set_timesteps(1000)
+        t_cur = sch.timesteps[int(k * 1000 / 50)]
+        pos, neu, unc = (predict(x, w, t_cur, 1) for w in ("positive", "neutral", "uncond"))
+    with nw:
+        tgt = predict(x, "target", t_cur, 1)
+    ref_loss = F.mse_loss(tgt, neu + 4.0 * (pos - unc))
+    ref_loss.backward()
+    flat = torch.zeros(store.numel)
+    mods = {m.lora_name: m for m in nw.unet_loras}
+    for e in store.entries:
+        m = mods[e.name]
+        flat[e.down_off:e.down_off + e.down_numel] = store._down_to_kernel(e, m.lora_down.weight.grad)
+        flat[e.up_off:e.up_off + e.up_numel] = m.lora_up.weight.grad.reshape(-1)
+    r_den = rel_err(tr.denoised.float().cpu(), x)
+    r_tgt = rel_err(tr.e_tgt.float().cpu(), tgt.detach())
+    cos = F.cosine_similarity(store.grads.cpu(), flat, dim=0).item()
+    print(f"[parity] iteration: denoised rel_l2={r_den:.3e} target-eps rel_l2={r_tgt:.3e} loss {loss.item():.5e} vs "
+          f"{ref_loss.item():.5e} grad cosine {cos:.5f} |g| {store.grads.norm().item():.3e} vs {flat.norm().item():.3e}")
+    assert r_den < 2e-2 and r_tgt < 3e-2
+    assert abs(loss.item() - ref_loss.item()) < 0.1 * ref_loss.item()
+    assert cos > 0.98
+    # AdamW moved every trainable parameter by about lr (first step: |update| ~ lr)
+    delta = (store.params.float() - params0.float()).abs()
+    assert delta.max().item() < 5e-4 and delta.max().item() > 0
+
+
+def test_dedup_frozen_equals_three_cfg_pairs(dev):
+    """Same engine, same denoised latents, same timestep: the one-pass [uncond, positive, neutral] evaluation
+    against the reference's three CFG-pair passes.  Not bit-identical run to run (GroupNorm statistics are
+    summed with fp32 atomics, a 1-ulp bf16 flip then propagates), so the bound is the bf16 noise floor."""
+    name, k, hw = "tiny_sdxl", 2, 16
+    cfg, store, emb, pool, noise = _setup(dev)
+    eng = UNetEngine(cfg, build_unet(name, seed=0).state_dict(), dev)
+    tr = SliderTrainer(eng, store, hw, hw, dedup_frozen=True)
+    pair = _pair(emb, pool, dev)
+    tr.iteration(pair, k, noise.to(dev))
+    torch.cuda.synchronize()
+    ded = [t.float().cpu().clone() for t in (tr.e_pos, tr.e_neu, tr.e_unc)]
+    t_cur = tr.t1000[int(k * 1000 / tr.nsteps)]
+    eng.set_lora(False)
+    p_off = eng.plan(2, hw, hw, "off")
+    tr._predict(p_off, tr.denoised, pair.ctx_positive, pair.pooled_positive, t_cur, tr.e_pos)
+    tr._predict(p_off, tr.denoised, pair.ctx_neutral, pair.pooled_neutral, t_cur, tr.e_neu)
+    tr._predict(p_off, tr.denoised, pair.ctx_uncond, pair.pooled_uncond, t_cur, tr.e_unc)
+    torch.cuda.synchronize()
+    for a, b, nm in zip(ded, (tr.e_pos, tr.e_neu, tr.e_unc), ("pos", "neu", "unc")):
+        b = b.float().cpu()
+        r = rel_err(a, b)
+        print(f"[parity] dedup {nm}: rel_l2 {r:.3e} max abs diff {(a - b).abs().max().item():.3e}")
+        assert r < 1e-2
