@@ -176,9 +176,9 @@ typedef struct slh_ln_bwd_desc {
 int slh_layernorm_bwd(const slh_ln_bwd_desc* d, slh_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
- * Attention, head_dim 64 (SDXL) : O = softmax(Q K^T * scale) V per (sample, head).
- * Q [B][Tq][ldq] (head h at columns h*64..), K [B][Tk][ldk], VT [B][H][64][ldvt] (V transposed by
- * slh_transpose_heads), O [B][Tq][ldo]; lse [B][H][Tq] fp32 (log2 domain) or NULL.
+ * Attention: O = softmax(Q K^T * scale) V per (sample, head); head dims 64 (SDXL), 40/80/160 (SD-1.x).
+ * Q [B][Tq][ldq] (head h at columns h*D..), K [B][Tk][ldk], VT [B][H][Dp][ldvt] (V transposed by
+ * slh_transpose_heads, Dp = 64*ceil(D/64)), O [B][Tq][ldo]; lse [B][H][Tq] fp32 (log2 domain) or NULL.
  * Replaces Attention + XFormersAttnProcessor (train_lora.py:68).
  * ---------------------------------------------------------------------------------------------- */
 typedef struct slh_attn_desc {
@@ -187,6 +187,8 @@ typedef struct slh_attn_desc {
     float* lse;
     int32_t B, H, Tq, Tk, ldq, ldk, ldvt, ldo;
     float scale;
+    int32_t D;               /* head dim: 0/64 (SDXL) or 40 / 80 / 160 (SD-1.x); head h = columns [h*D, (h+1)*D);
+                                VT is [B][H][64*ceil(D/64)][ldvt] with zero rows for d >= D */
 } slh_attn_desc;
 int slh_attn_fwd(const slh_attn_desc* d, slh_stream_t stream);
 
@@ -194,6 +196,7 @@ int slh_attn_fwd(const slh_attn_desc* d, slh_stream_t stream);
 typedef struct slh_transpose_desc {
     const void* src; void* dst;
     int32_t B, H, T, ld, ldt;
+    int32_t D;               /* head dim (0 = 64); dst is [B][H][64*ceil(D/64)][ldt] */
 } slh_transpose_desc;
 int slh_transpose_heads(const slh_transpose_desc* d, slh_stream_t stream);
 
@@ -211,6 +214,8 @@ typedef struct slh_attn_bwd_desc {
     int32_t B, H, Tq, Tk, ldq, ldk, ldv, ldo, lddo, ldkt, ldqt, lddq, lddk, lddv;
     float scale;
     int32_t need_dkv;
+    int32_t D;               /* head dim (0 = 64); kt / qt / dot use the padded [B][H][64*ceil(D/64)][ld] layout */
+    int32_t pad_;
 } slh_attn_bwd_desc;
 int slh_attn_bwd(const slh_attn_bwd_desc* d, slh_stream_t stream);
 

@@ -98,8 +98,8 @@ def tiny_sd1_config() -> UNetConfig:
     """Same topology as SD-1.x, 1/5 width (channels stay multiples of 64) - for fast tests."""
     return UNetConfig(
         sample_size=16,
-        block_out_channels=(64, 128, 256, 256),
-        attention_head_dim=(1, 2, 4, 4),   # head dim 64 everywhere
+        block_out_channels=(64, 128, 320, 320),
+        attention_head_dim=(8, 8, 8, 8),   # 8 heads like SD-1.x -> head dims 8 / 16 / 40 / 40
         cross_attention_dim=128,
     )
 

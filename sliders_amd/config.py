@@ -72,8 +72,8 @@ def sdxl_config() -> UNetConfig:
 
 
 def tiny_sd1_config() -> UNetConfig:
-    return UNetConfig(sample_size=16, block_out_channels=(64, 128, 256, 256),
-                      attention_head_dim=(1, 2, 4, 4), cross_attention_dim=128)
+    return UNetConfig(sample_size=16, block_out_channels=(64, 128, 320, 320),
+                      attention_head_dim=(8, 8, 8, 8), cross_attention_dim=128)   # head dims 8 / 16 / 40 / 40
 
 
 def tiny_sdxl_config() -> UNetConfig:

@@ -49,12 +49,12 @@ LnDesc = _struct("LnDesc", _ptrs("x", "gamma", "beta", "y", "mean_rstd") + _ints
 LnBwdDesc = _struct("LnBwdDesc", _ptrs("x", "gamma", "dy", "mean_rstd", "dx")
                     + _ints("M", "C", "ldx", "lddy", "lddx", "accumulate"))
 AttnDesc = _struct("AttnDesc", _ptrs("q", "k", "vt", "o", "lse")
-                   + _ints("B", "H", "Tq", "Tk", "ldq", "ldk", "ldvt", "ldo") + [("scale", c_f32)])
-TransposeDesc = _struct("TransposeDesc", _ptrs("src", "dst") + _ints("B", "H", "T", "ld", "ldt"))
+                   + _ints("B", "H", "Tq", "Tk", "ldq", "ldk", "ldvt", "ldo") + [("scale", c_f32)] + _ints("D"))
+TransposeDesc = _struct("TransposeDesc", _ptrs("src", "dst") + _ints("B", "H", "T", "ld", "ldt", "D"))
 AttnBwdDesc = _struct("AttnBwdDesc", _ptrs("q", "k", "v", "o", "d_o", "kt", "qt", "dot", "lse", "delta", "dq", "dk", "dv")
                       + _ints("B", "H", "Tq", "Tk", "ldq", "ldk", "ldv", "ldo", "lddo", "ldkt", "ldqt", "lddq", "lddk",
                               "lddv")
-                      + [("scale", c_f32)] + _ints("need_dkv"))
+                      + [("scale", c_f32)] + _ints("need_dkv", "D", "pad_"))
 TembedDesc = _struct("TembedDesc", _ptrs("vals", "out") + _ints("nb", "n_vals", "dim", "ldo", "col0"))
 ConvInDesc = _struct("ConvInDesc", _ptrs("x", "w", "bias", "y") + _ints("batch", "cin", "h", "wd", "cout", "ldy"))
 EwDesc = _struct("EwDesc", _ptrs("a", "b", "out") + _ints("M", "C", "lda", "ldb", "ldo", "op", "iarg", "iarg2")

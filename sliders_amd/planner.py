@@ -235,15 +235,17 @@ class UNetPlan:
     def attention(self, q: Act, k: Act, v: Act, Tk: int, heads: int, name: str) -> Act:
         """q [B*Tq][C] view, k/v [B*Tk][C] views (any ld); returns [B*Tq][C]."""
         B, Tq, C = q.B, q.HW, q.C
-        assert C == heads * 64, "only head_dim 64 is implemented"
+        D = C // heads
+        assert D * heads == C and D % 8 == 0 and D <= 192, f"unsupported head_dim {D}"
+        Dp = (D + 63) // 64 * 64
         ldt = (Tk + 63) // 64 * 64
-        vt = self.arena.alloc((B, heads, 64, ldt), torch.bfloat16, name + ".vt")
-        self.prog.add(lib.OP_TRANSPOSE_HEADS, lib.TransposeDesc(src=v.ptr, dst=vt.ptr, B=B, H=heads, T=Tk, ld=v.ld, ldt=ldt),
-                      name + ".vt")
+        vt = self.arena.alloc((B, heads, Dp, ldt), torch.bfloat16, name + ".vt")
+        self.prog.add(lib.OP_TRANSPOSE_HEADS, lib.TransposeDesc(src=v.ptr, dst=vt.ptr, B=B, H=heads, T=Tk, ld=v.ld, ldt=ldt,
+                                                                D=D), name + ".vt")
         o = self.act(q.B, q.H, q.W, C, name)
         lse = self.f32((B * heads * Tq + 64,), name + ".lse") if self.train else None   # padded: bwd reads by 64s
         d = lib.AttnDesc(q=q.ptr, k=k.ptr, vt=vt.ptr, o=o.ptr, lse=lse.ptr if lse else 0, B=B, H=heads, Tq=Tq, Tk=Tk,
-                         ldq=q.ld, ldk=k.ld, ldvt=ldt, ldo=o.ld, scale=64 ** -0.5)
+                         ldq=q.ld, ldk=k.ld, ldvt=ldt, ldo=o.ld, scale=D ** -0.5, D=D)
         self.prog.add(lib.OP_ATTN_FWD, d, name)
         if self.train:
             self.tape.append(dict(op="attn", q=q, k=k, v=v, o=o, lse=lse, Tk=Tk, heads=heads, name=name))
@@ -561,10 +563,11 @@ class BackwardPlan:
         self._ew(lib.EW_GEGLU_BWD, ps, gp, go, "bwd." + rec["name"], C=out.C)
 
     def _transpose(self, src: Act, heads: int, T: int, name: str):
+        D = src.C // heads
         ldt = (T + 63) // 64 * 64
-        t = self.arena.alloc((self.nb, heads, 64, ldt), torch.bfloat16, name)
+        t = self.arena.alloc((self.nb, heads, (D + 63) // 64 * 64, ldt), torch.bfloat16, name)
         self.prog.add(lib.OP_TRANSPOSE_HEADS, lib.TransposeDesc(src=src.ptr, dst=t.ptr, B=self.nb, H=heads, T=T,
-                                                                ld=src.ld, ldt=ldt), name)
+                                                                ld=src.ld, ldt=ldt, D=D), name)
         return t, ldt
 
     def _b_attn(self, rec):
@@ -582,7 +585,7 @@ class BackwardPlan:
         d = lib.AttnBwdDesc(q=qs.ptr, k=ks.ptr, v=vs.ptr, o=os_.ptr, d_o=go.ptr, kt=kt.ptr,
                             lse=rec["lse"].ptr + 4 * self.b0 * heads * Tq, delta=delta.ptr, dq=gq.ptr,
                             B=self.nb, H=heads, Tq=Tq, Tk=Tk, ldq=qs.ld, ldk=ks.ld, ldv=vs.ld, ldo=os_.ld, lddo=go.ld,
-                            ldkt=ldkt, lddq=gq.ld, scale=64 ** -0.5, need_dkv=need_dkv)
+                            ldkt=ldkt, lddq=gq.ld, scale=(q.C // heads) ** -0.5, need_dkv=need_dkv, D=q.C // heads)
         if need_dkv:
             qt, ldqt = self._transpose(qs, heads, Tq, "bwd." + rec["name"] + ".qt")
             dot, _ = self._transpose(go, heads, Tq, "bwd." + rec["name"] + ".dot")

@@ -25,10 +25,13 @@ from tests.util import bf, p, rel_err, report, stream
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("B,H,Tq,Tk,dkv", [(1, 3, 256, 256, 1), (2, 2, 192, 192, 1), (1, 4, 320, 77, 0), (1, 2, 100, 77, 1)])
-def test_attention_bwd(dev, B, H, Tq, Tk, dkv):
+@pytest.mark.parametrize("B,H,Tq,Tk,dkv,D", [(1, 3, 256, 256, 1, 64), (2, 2, 192, 192, 1, 64), (1, 4, 320, 77, 0, 64),
+                                              (1, 2, 100, 77, 1, 64), (1, 8, 256, 256, 1, 40), (1, 4, 128, 77, 1, 80),
+                                              (1, 8, 64, 64, 1, 160), (1, 2, 200, 77, 0, 160), (1, 4, 96, 96, 1, 16)])
+def test_attention_bwd(dev, B, H, Tq, Tk, dkv, D):
     torch.manual_seed(21)
-    C = H * 64
+    C = H * D
+    sc = D ** -0.5
     q = bf(torch.randn(B * Tq, C, device=dev))
     k = bf(torch.randn(B * Tk, C, device=dev))
     v = bf(torch.randn(B * Tk, C, device=dev))
@@ -36,15 +39,15 @@ def test_attention_bwd(dev, B, H, Tq, Tk, dkv):
 
     def tr(x, T):
         ldt = (T + 63) // 64 * 64
-        t = torch.zeros(B, H, 64, ldt, device=dev, dtype=torch.bfloat16)
-        lib.call(lib.OP_TRANSPOSE_HEADS, lib.TransposeDesc(src=p(x), dst=p(t), B=B, H=H, T=T, ld=C, ldt=ldt), stream())
+        t = torch.zeros(B, H, (D + 63) // 64 * 64, ldt, device=dev, dtype=torch.bfloat16)
+        lib.call(lib.OP_TRANSPOSE_HEADS, lib.TransposeDesc(src=p(x), dst=p(t), B=B, H=H, T=T, ld=C, ldt=ldt, D=D), stream())
         return t, ldt
 
     vt, ldvt = tr(v, Tk)
     o = torch.zeros(B * Tq, C, device=dev, dtype=torch.bfloat16)
     lse = torch.zeros(B * H * Tq + 64, device=dev)
     lib.call(lib.OP_ATTN_FWD, lib.AttnDesc(q=p(q), k=p(k), vt=p(vt), o=p(o), lse=p(lse), B=B, H=H, Tq=Tq, Tk=Tk, ldq=C,
-                                           ldk=C, ldvt=ldvt, ldo=C, scale=0.125), stream())
+                                           ldk=C, ldvt=ldvt, ldo=C, scale=sc, D=D), stream())
     kt, ldkt = tr(k, Tk)
     qt, ldqt = tr(q, Tq)
     dot, _ = tr(go, Tq)
@@ -54,15 +57,15 @@ def test_attention_bwd(dev, B, H, Tq, Tk, dkv):
     delta = torch.zeros(B * H * Tq + 64, device=dev)
     d = lib.AttnBwdDesc(q=p(q), k=p(k), v=p(v), o=p(o), d_o=p(go), kt=p(kt), qt=p(qt), dot=p(dot), lse=p(lse),
                         delta=p(delta), dq=p(dq), dk=p(dk), dv=p(dv), B=B, H=H, Tq=Tq, Tk=Tk, ldq=C, ldk=C, ldv=C, ldo=C,
-                        lddo=C, ldkt=ldkt, ldqt=ldqt, lddq=C, lddk=C, lddv=C, scale=0.125, need_dkv=dkv)
+                        lddo=C, ldkt=ldkt, ldqt=ldqt, lddq=C, lddk=C, lddv=C, scale=sc, need_dkv=dkv, D=D)
     lib.call(lib.OP_ATTN_BWD, d, stream())
     torch.cuda.synchronize()
-    qf = q.float().reshape(B, Tq, H, 64).transpose(1, 2).requires_grad_(True)
-    kf = k.float().reshape(B, Tk, H, 64).transpose(1, 2).requires_grad_(True)
-    vf = v.float().reshape(B, Tk, H, 64).transpose(1, 2).requires_grad_(True)
-    out = torch.softmax(qf @ kf.transpose(-1, -2) * 0.125, -1) @ vf
-    out.backward(go.float().reshape(B, Tq, H, 64).transpose(1, 2))
-    report(f"attn_bwd dq B{B} H{H} Tq{Tq} Tk{Tk}", dq, qf.grad.transpose(1, 2).reshape(B * Tq, C), 1.5e-2)
+    qf = q.float().reshape(B, Tq, H, D).transpose(1, 2).requires_grad_(True)
+    kf = k.float().reshape(B, Tk, H, D).transpose(1, 2).requires_grad_(True)
+    vf = v.float().reshape(B, Tk, H, D).transpose(1, 2).requires_grad_(True)
+    out = torch.softmax(qf @ kf.transpose(-1, -2) * sc, -1) @ vf
+    out.backward(go.float().reshape(B, Tq, H, D).transpose(1, 2))
+    report(f"attn_bwd dq B{B} H{H} Tq{Tq} Tk{Tk} D{D}", dq, qf.grad.transpose(1, 2).reshape(B * Tq, C), 1.5e-2)
     if dkv:
         report("attn_bwd dk", dk, kf.grad.transpose(1, 2).reshape(B * Tk, C), 1.5e-2)
         report("attn_bwd dv", dv, vf.grad.transpose(1, 2).reshape(B * Tk, C), 1.5e-2)

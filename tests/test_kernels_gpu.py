@@ -281,10 +281,12 @@ def test_layernorm(dev, C):
     report(f"layernorm_bwd C{C}", dx, xi.grad + dx_init.float(), 1.5e-2)
 
 
-@pytest.mark.parametrize("B,H,Tq,Tk", [(2, 5, 1024, 1024), (1, 3, 192, 192), (2, 4, 256, 77), (1, 2, 100, 333), (4, 8, 2048, 2048)])
-def test_attention_fwd(dev, B, H, Tq, Tk):
+@pytest.mark.parametrize("B,H,Tq,Tk,D", [(2, 5, 1024, 1024, 64), (1, 3, 192, 192, 64), (2, 4, 256, 77, 64),
+                                          (1, 2, 100, 333, 64), (4, 8, 2048, 2048, 64), (2, 8, 1024, 1024, 40),
+                                          (1, 8, 256, 77, 80), (2, 8, 64, 64, 160), (1, 4, 200, 77, 160), (1, 8, 96, 96, 8)])
+def test_attention_fwd(dev, B, H, Tq, Tk, D):
     torch.manual_seed(9)
-    C = H * 64
+    C = H * D
     self_attn = Tq == Tk
     if self_attn:
         qkv = bf(torch.randn(B * Tq, 3 * C, device=dev))
@@ -296,24 +298,25 @@ def test_attention_fwd(dev, B, H, Tq, Tk):
         q, k, v = qb, kvb[:, :C], kvb[:, C:]
         ldq, ldk, ldv = C, 2 * C, 2 * C
     ldt = (Tk + 63) // 64 * 64
-    vt = torch.full((B, H, 64, ldt), float("nan"), device=dev, dtype=torch.bfloat16)
-    lib.call(lib.OP_TRANSPOSE_HEADS, lib.TransposeDesc(src=v.data_ptr(), dst=p(vt), B=B, H=H, T=Tk, ld=ldv, ldt=ldt), stream())
+    Dp = (D + 63) // 64 * 64
+    vt = torch.full((B, H, Dp, ldt), float("nan"), device=dev, dtype=torch.bfloat16)
+    lib.call(lib.OP_TRANSPOSE_HEADS, lib.TransposeDesc(src=v.data_ptr(), dst=p(vt), B=B, H=H, T=Tk, ld=ldv, ldt=ldt, D=D), stream())
     torch.cuda.synchronize()
-    vref = v.reshape(B, Tk, H, 64).permute(0, 2, 3, 1)
-    assert torch.equal(vt[..., :Tk], vref), "transpose_heads mismatch"
-    assert (vt[..., Tk:] == 0).all(), "transpose_heads padding must be zero"
+    vref = v.reshape(B, Tk, H, D).permute(0, 2, 3, 1)
+    assert torch.equal(vt[:, :, :D, :Tk], vref), "transpose_heads mismatch"
+    assert (vt[..., Tk:] == 0).all() and (vt[:, :, D:] == 0).all(), "transpose_heads padding must be zero"
     o = torch.zeros(B * Tq, C, device=dev, dtype=torch.bfloat16)
     lse = torch.zeros(B, H, Tq, device=dev)
     d = lib.AttnDesc(q=q.data_ptr(), k=k.data_ptr(), vt=p(vt), o=p(o), lse=p(lse), B=B, H=H, Tq=Tq, Tk=Tk, ldq=ldq,
-                     ldk=ldk, ldvt=ldt, ldo=C, scale=0.125)
+                     ldk=ldk, ldvt=ldt, ldo=C, scale=D ** -0.5, D=D)
     lib.call(lib.OP_ATTN_FWD, d, stream())
     torch.cuda.synchronize()
-    qf = q.float().reshape(B, Tq, H, 64).transpose(1, 2)
-    kf = k.float().reshape(B, Tk, H, 64).transpose(1, 2)
-    vf = v.float().reshape(B, Tk, H, 64).transpose(1, 2)
-    s = qf @ kf.transpose(-1, -2) * 0.125
+    qf = q.float().reshape(B, Tq, H, D).transpose(1, 2)
+    kf = k.float().reshape(B, Tk, H, D).transpose(1, 2)
+    vf = v.float().reshape(B, Tk, H, D).transpose(1, 2)
+    s = qf @ kf.transpose(-1, -2) * D ** -0.5
     ref = (torch.softmax(s, -1) @ vf).transpose(1, 2).reshape(B * Tq, C)
-    report(f"attn_fwd B{B} H{H} Tq{Tq} Tk{Tk}", o, ref, 8e-3)
+    report(f"attn_fwd B{B} H{H} Tq{Tq} Tk{Tk} D{D}", o, ref, 8e-3)
     report("attn_lse", lse, torch.logsumexp(s, -1) * 1.4426950408889634, 1e-4)
 
 

@@ -116,3 +116,38 @@ def test_unet_forward_parity_with_lora(dev, name, method):
         e_on = run_oracle(net32, x, 700, ctx, kw, torch.float32)
     print(f"[parity] adapter effect size rel_l2(on, off) = {rel_err(e_on, e_plain):.3e}")
     assert rel_err(e_on, e_plain) > 1e-3, "test is vacuous: adapters have no visible effect"
+
+
+@pytest.mark.parametrize("name", ["sd1", "sdxl"])
+def test_full_size_forward_parity(dev, name):
+    """The real SD-1.x / SDXL architectures (859.5 M / 2567 M parameters, seeded random init) at 256x256:
+    HIP engine vs the fp32 CPU oracle on identical bf16-rounded weights."""
+    import os
+    import time
+    from sliders_amd.random_init import random_state_dict
+    try:
+        ram = os.sysconf("SC_PAGE_SIZE") * os.sysconf("SC_PHYS_PAGES") / 2 ** 30
+    except (ValueError, OSError):
+        ram = 0
+    if ram < (24 if name == "sdxl" else 10):
+        pytest.skip(f"needs more host RAM for the fp32 oracle (have {ram:.0f} GB)")
+    cfg = CONFIGS[name]()
+    hw = 32
+    sd = random_state_dict(cfg, "cpu", 0, torch.bfloat16)
+    eng = UNetEngine(cfg, sd, dev)
+    x, ctx, kw = make_inputs(cfg, 2, hw)
+    got = run_engine(eng, x, 400, ctx, kw, dev)
+    del eng
+    torch.cuda.empty_cache()
+    net = build_unet(name, device="meta")
+    net.load_state_dict({k: v.float() for k, v in sd.items()}, assign=True)
+    del sd
+    t0 = time.time()
+    with torch.no_grad():
+        kwd = {k: v.to(torch.bfloat16).float() for k, v in kw.items()} if kw else None
+        e32 = net(x.to(torch.bfloat16).float(), torch.tensor(400), ctx.to(torch.bfloat16).float(), kwd).sample
+    r = rel_err(got, e32)
+    print(f"[parity] full-size {name} 256x256: engine rel_l2={r:.3e} max_abs={(got - e32).abs().max():.3e} "
+          f"eps rms={e32.pow(2).mean().sqrt():.3f} (fp32 oracle forward {time.time() - t0:.1f}s on {os.cpu_count()} cores)")
+    assert torch.isfinite(got).all()
+    assert r < 3e-2
