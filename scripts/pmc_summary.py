@@ -1,0 +1,19 @@
+"""Aggregate a rocprofv3 --pmc counter_collection CSV per kernel name (sum of counters, dispatch count)."""
+import csv
+import glob
+import sys
+from collections import defaultdict
+
+d = sys.argv[1]
+files = glob.glob(d + "/**/*counter_collection.csv", recursive=True)
+agg = defaultdict(lambda: defaultdict(float))
+cnt = defaultdict(set)
+for f in files:
+    for r in csv.DictReader(open(f)):
+        k = r["Kernel_Name"][:60]
+        agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
+        cnt[k].add(r["Dispatch_Id"])
+names = sorted({c for v in agg.values() for c in v})
+print("kernel,dispatches," + ",".join(names))
+for k, v in sorted(agg.items(), key=lambda kv: -kv[1].get("SQ_WAVE_CYCLES", kv[1].get("GRBM_GUI_ACTIVE", 0))):
+    print(f"{k},{len(cnt[k])}," + ",".join(f"{v.get(n, 0):.4g}" for n in names))

@@ -21,7 +21,8 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--model", default="sdxl")
 ap.add_argument("--hw", type=int, default=128)
 ap.add_argument("--out", default=None)
-ap.add_argument("--reps", type=int, default=5)
+ap.add_argument("--reps", type=int, default=3)
+ap.add_argument("--fwd-only", action="store_true")
 args = ap.parse_args()
 
 dev = torch.device("cuda:0")
@@ -44,7 +45,7 @@ eng.run_backward(d_eps=torch.randn(1, 4, hw, hw, device=dev) * 1e-3)
 torch.cuda.synchronize()
 
 shapes = {}
-for prog in (p.prog, p.backward.prog):
+for prog in ((p.prog,) if args.fwd_only else (p.prog, p.backward.prog)):
     for opcode, d in prog.ops:
         if opcode == lib.OP_GEMM:
             shapes.setdefault(gemm_key(d), []).append(d)
@@ -53,9 +54,11 @@ table, total_best, total_heur = {}, 0.0, 0.0
 for key, ds in sorted(shapes.items(), key=lambda kv: -kv[1][0].M * kv[1][0].N * kv[1][0].K * len(kv[1])):
     d0 = ds[0]
     res = {}
-    for tile in (0x22, 0x21, 0x12, 0x11, 0x321, 0x312, 0x311, 0):
+    for tile in (0x22, 0x21, 0x12, 0x11, 0x321, 0x312, 0x311, 0x4022, 0x4322, 0x4012, 0x4312, 0):
         if d0.geglu and (tile & 15) == 1:
             continue
+        if (tile >> 12) == 4 and d0.M * d0.N < 256 * 128 * 64:
+            continue    # 8-wave tiles only make sense when they still give >= 64 workgroups
         d = type(d0).from_buffer_copy(bytes(d0))
         d.tile = tile
         # never let a tuning launch corrupt live accumulation buffers: drop residual aliasing on c
@@ -72,12 +75,17 @@ for key, ds in sorted(shapes.items(), key=lambda kv: -kv[1][0].M * kv[1][0].N * 
     table[key] = best
     total_best += res[best] * len(ds)
     total_heur += res[0] * len(ds)
-    print(f"{key:44s} x{len(ds):4d}  " + "  ".join(f"{t:03x}:{res[t]:6.1f}" for t in res) +
-          f"  best {best:03x} {fl / res[best] / 1e6:6.0f} TF/s", flush=True)
+    print(f"{key:44s} x{len(ds):4d}  " + "  ".join(f"{t:x}:{res[t]:.1f}" for t in res) +
+          f"  best {best:x} {fl / res[best] / 1e6:6.0f} TF/s", flush=True)
 print(f"sum over one fwd+bwd: heuristic {total_heur / 1e3:.2f} ms, tuned {total_best / 1e3:.2f} ms")
 out = args.out or os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "sliders_amd", "tuning",
                                f"gfx950_{args.model}_{hw}.json")
 os.makedirs(os.path.dirname(out), exist_ok=True)
+old = {}
+if os.path.exists(out):
+    with open(out) as f:
+        old = json.load(f)
+old.update(table)
 with open(out, "w") as f:
-    json.dump(table, f, indent=0, sort_keys=True)
+    json.dump(old, f, indent=0, sort_keys=True)
 print("wrote", out)

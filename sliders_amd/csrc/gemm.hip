@@ -41,12 +41,16 @@ __device__ __forceinline__ int lds_off(int row, int slot) {
     return row * 128 + ((slot ^ ((row >> 1) & 7)) << 4);
 }
 
-template <int MI, int NI, int MODE, int STAGES, bool LORA>
-__global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
-    constexpr int BM = 64 * MI;
+// WM = waves along M (2: 4-wave workgroup, tile 64*MI x 64*NI; 4: 8-wave workgroup, tile 128*MI x 64*NI - twice
+// the W-tile reuse per byte pulled from L2, which is what bounds these kernels)
+template <int MI, int NI, int MODE, int STAGES, bool LORA, int WM>
+__global__ __launch_bounds__(128 * WM) void gemm_kernel(const GemmArgs p) {
+    constexpr int NW = 2 * WM;
+    constexpr int BM = 32 * MI * WM;
     constexpr int BN = 64 * NI;
-    constexpr int XI = BM / 32;  // glds instructions per wave for the X tile (8 rows each, 4 waves)
-    constexpr int WI = BN / 32;
+    constexpr int XI = BM / (8 * NW);  // glds instructions per wave for the X tile (8 rows each)
+    constexpr int WI = BN / (8 * NW);
+    static_assert(XI >= 1 && WI >= 1, "tile too small for this many waves");
     // LORA: the rank-r down matrix A (lora_down, [r][K], r <= 12, zero-padded to 32 rows) rides along as a third
     // operand tile; every wave multiplies it with the X fragments it already holds, so T = X.A^T of the block's own
     // rows is available in registers for the epilogue without a separate pass over X (lora.py:108-112 fused).
@@ -85,7 +89,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
     int xks[XI];                  // logical k-slot this lane fetches (inverse swizzle)
 #pragma unroll
     for (int i = 0; i < XI; ++i) {
-        const int row = (wave + 4 * i) * 8 + frow;
+        const int row = (wave + NW * i) * 8 + frow;
         int m = m0 + row;
         m = m < p.M ? m : p.M - 1;
         xks[i] = fslot ^ ((row >> 1) & 7);
@@ -103,7 +107,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
     const __bf16* wptr[WI];
 #pragma unroll
     for (int i = 0; i < WI; ++i) {
-        const int row = (wave + 4 * i) * 8 + frow;
+        const int row = (wave + NW * i) * 8 + frow;
         int n = n0 + row;
         n = n < p.N ? n : p.N - 1;
         wptr[i] = p.w + (long)n * p.ldw + ((fslot ^ ((row >> 1) & 7)) << 3);
@@ -120,7 +124,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
 #pragma unroll
             for (int i = 0; i < XI; ++i) {
                 const __bf16* src = base + (s1 ? xrow_off1[i] : xrow_off0[i]) + kk + (xks[i] << 3);
-                glds16(src, dX + (wave + 4 * i) * 1024);
+                glds16(src, dX + (wave + NW * i) * 1024);
             }
         } else {
             const int tap = k0 / cin;
@@ -142,17 +146,17 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
                 const long pix = ((long)xb[i] * p.hs + sy) * p.ws + sx;
                 const __bf16* src = ok ? base + pix * ld + cc + (xks[i] << 3)
                                        : (const __bf16*)slh_zero_page;
-                glds16(src, dX + (wave + 4 * i) * 1024);
+                glds16(src, dX + (wave + NW * i) * 1024);
             }
         }
 #pragma unroll
-        for (int i = 0; i < WI; ++i) glds16(wptr[i] + k0, dW + (wave + 4 * i) * 1024);
+        for (int i = 0; i < WI; ++i) glds16(wptr[i] + k0, dW + (wave + NW * i) * 1024);
         if (LORA) {
-            const int row = wave * 8 + frow;
+            const int row = (wave & 3) * 8 + frow;   // with 8 waves the upper four re-issue the same rows (benign)
             const __bf16* src = row < p.lora_rank
                                     ? p.lora_down + (long)row * p.K + k0 + ((fslot ^ ((row >> 1) & 7)) << 3)
                                     : (const __bf16*)slh_zero_page;
-            glds16(src, sL + buf * (32 * 128) + wave * 1024);
+            glds16(src, sL + buf * (32 * 128) + (wave & 3) * 1024);
         }
     };
 
@@ -352,32 +356,36 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs p) {
     }
 }
 
-template <int MI, int NI, int MODE, bool LORA>
-int launch_gemm2(const GemmArgs& a, int stages, hipStream_t s) {
+template <int MI, int NI, int MODE, bool LORA, int WM>
+int launch_gemm3(const GemmArgs& a, int stages, hipStream_t s) {
     const int grid = a.tiles_m * a.tiles_n;
-    constexpr bool can3 = (MI + NI <= 3);   // 3 x 64 KB would not fit for the 128x128 tile
-    if (stages == 3 && can3) hipLaunchKernelGGL((gemm_kernel<MI, NI, MODE, (can3 ? 3 : 2), LORA>), dim3(grid), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((gemm_kernel<MI, NI, MODE, 2, LORA>), dim3(grid), dim3(256), 0, s, a);
+    constexpr int lds3 = 3 * (32 * MI * WM + 64 * NI + (LORA ? 32 : 0)) * 128;
+    constexpr bool can3 = lds3 <= 160 * 1024 && (WM == 4 || MI + NI <= 3);
+    if (stages == 3 && can3)
+        hipLaunchKernelGGL((gemm_kernel<MI, NI, MODE, (can3 ? 3 : 2), LORA, WM>), dim3(grid), dim3(128 * WM), 0, s, a);
+    else
+        hipLaunchKernelGGL((gemm_kernel<MI, NI, MODE, 2, LORA, WM>), dim3(grid), dim3(128 * WM), 0, s, a);
     SLH_LAUNCH_CHECK("slh_gemm");
     return 0;
 }
 
-template <int MI, int NI>
+template <int MI, int NI, int WM>
 int launch_gemm(const GemmArgs& a, int mode, int stages, hipStream_t s) {
     const bool lora = a.lora_down != nullptr;
-    if (mode == 0) return lora ? launch_gemm2<MI, NI, 0, true>(a, stages, s) : launch_gemm2<MI, NI, 0, false>(a, stages, s);
-    return lora ? launch_gemm2<MI, NI, 1, true>(a, stages, s) : launch_gemm2<MI, NI, 1, false>(a, stages, s);
+    if (mode == 0) return lora ? launch_gemm3<MI, NI, 0, true, WM>(a, stages, s) : launch_gemm3<MI, NI, 0, false, WM>(a, stages, s);
+    return lora ? launch_gemm3<MI, NI, 1, true, WM>(a, stages, s) : launch_gemm3<MI, NI, 1, false, WM>(a, stages, s);
 }
 
 }  // namespace
 
 // tile choice: explicit (d->tile, set by the planner from the tuned table) or a fill-the-chip heuristic
-static void pick_tile(const slh_gemm_desc* d, int& MI, int& NI) {
-    MI = 2; NI = 2;
+static void pick_tile(const slh_gemm_desc* d, int& MI, int& NI, int& WM) {
+    MI = 2; NI = 2; WM = 2;
     if (d->tile) {
         MI = (d->tile >> 4) & 15; NI = d->tile & 15;
+        WM = ((d->tile >> 12) & 15) == 4 ? 4 : 2;
         if (MI) return;
-        MI = 2; NI = 2;
+        MI = 2; NI = 2; WM = 2;
     }
     auto tiles = [&](int mi, int ni) { return ((d->M + 64 * mi - 1) / (64 * mi)) * ((d->N + 64 * ni - 1) / (64 * ni)); };
     if (tiles(2, 2) < 384) { MI = 2; NI = 1; }
@@ -387,9 +395,9 @@ static void pick_tile(const slh_gemm_desc* d, int& MI, int& NI) {
 
 // (MI<<8)|(NI<<4)|mode of the kernel instantiation slh_gemm would launch: gemm_kernel<MI, NI, mode>
 extern "C" int slh_gemm_variant(const slh_gemm_desc* d) {
-    int MI, NI;
-    pick_tile(d, MI, NI);
-    return (MI << 8) | (NI << 4) | (d->mode & 15);
+    int MI, NI, WM;
+    pick_tile(d, MI, NI, WM);
+    return (WM << 12) | (MI << 8) | (NI << 4) | (d->mode & 15);
 }
 
 extern "C" int slh_gemm(const slh_gemm_desc* d, slh_stream_t stream) {
@@ -434,9 +442,10 @@ extern "C" int slh_gemm(const slh_gemm_desc* d, slh_stream_t stream) {
     if (d->residual) SLH_CHECK(d->ld_res % 4 == 0, "slh_gemm: ld_res");
     if (d->geglu) SLH_CHECK(d->N % 64 == 0 && !d->lora_t && !d->residual && !d->rowbias, "slh_gemm: geglu constraints");
 
-    int MI = 2, NI = 2;
-    pick_tile(d, MI, NI);
+    int MI = 2, NI = 2, WM = 2;
+    pick_tile(d, MI, NI, WM);
     SLH_CHECK((MI == 1 || MI == 2) && (NI == 1 || NI == 2), "slh_gemm: bad tile");
+    SLH_CHECK(WM == 2 || NI == 2, "slh_gemm: 8-wave tiles need NI = 2");
     if (d->geglu) SLH_CHECK(NI == 2, "slh_gemm: geglu needs NI=2");
 
     GemmArgs a;
@@ -452,12 +461,16 @@ extern "C" int slh_gemm(const slh_gemm_desc* d, slh_stream_t stream) {
     a.ld_t = d->ld_t; a.lora_cols_per_group = (d->lora_t || d->lora_down) ? d->N / d->lora_groups : 1;
     a.ld_res = d->ld_res; a.ldc = d->ldc; a.geglu = d->geglu;
     a.lora_rank = d->lora_rank > 0 ? d->lora_rank : 4; a.lora_up_rmajor = d->lora_up_rmajor;
-    a.tiles_m = (d->M + 64 * MI - 1) / (64 * MI);
+    a.tiles_m = (d->M + 32 * MI * WM - 1) / (32 * MI * WM);
     a.tiles_n = (d->N + 64 * NI - 1) / (64 * NI);
     hipStream_t s = (hipStream_t)stream;
-    const int stages = (d->tile >> 8) & 15;   // tile = (stages<<8)|(MI<<4)|NI ; stages 0/2 = double buffer
-    if (MI == 2 && NI == 2) return launch_gemm<2, 2>(a, d->mode, stages, s);
-    if (MI == 2 && NI == 1) return launch_gemm<2, 1>(a, d->mode, stages, s);
-    if (MI == 1 && NI == 2) return launch_gemm<1, 2>(a, d->mode, stages, s);
-    return launch_gemm<1, 1>(a, d->mode, stages, s);
+    const int stages = (d->tile >> 8) & 15;   // tile = (WM<<12)|(stages<<8)|(MI<<4)|NI ; stages 0/2 = double buffer
+    if (WM == 4) {
+        if (MI == 2) return launch_gemm<2, 2, 4>(a, d->mode, stages, s);   // 256 x 128, 8 waves
+        return launch_gemm<1, 2, 4>(a, d->mode, stages, s);                // 128 x 128, 8 waves
+    }
+    if (MI == 2 && NI == 2) return launch_gemm<2, 2, 2>(a, d->mode, stages, s);
+    if (MI == 2 && NI == 1) return launch_gemm<2, 1, 2>(a, d->mode, stages, s);
+    if (MI == 1 && NI == 2) return launch_gemm<1, 2, 2>(a, d->mode, stages, s);
+    return launch_gemm<1, 1, 2>(a, d->mode, stages, s);
 }

@@ -40,7 +40,7 @@ def _pack_conv(w):
     return w.permute(0, 2, 3, 1).reshape(w.shape[0], -1).contiguous()
 
 
-@pytest.mark.parametrize("tile", [0x22, 0x21, 0x12, 0x11, 0x321, 0x312, 0x311])
+@pytest.mark.parametrize("tile", [0x22, 0x21, 0x12, 0x11, 0x321, 0x312, 0x311, 0x4022, 0x4322, 0x4012, 0x4312])
 @pytest.mark.parametrize("M,N,K", [(256, 128, 64), (300, 320, 320), (1024, 640, 1280), (154, 256, 2048)])
 def test_gemm_dense(dev, M, N, K, tile):
     torch.manual_seed(M + N + K)
@@ -95,7 +95,7 @@ def test_gemm_geglu(dev):
     b = bf(torch.randn(N, device=dev))
     from sliders_amd.weights import _geglu_perm
     wp, bp = _geglu_perm(w), _geglu_perm(b)
-    for tile in (0x22, 0x12):
+    for tile in (0x22, 0x12, 0x4022, 0x4312):
         c = torch.zeros(M, n_out, device=dev, dtype=torch.bfloat16)
         d = lib.GemmDesc(a0=p(x), w=p(wp), bias=p(bp), c=p(c), lda0=K, ca0=K, mode=0, stride=1, ldw=K, M=M, N=N, K=K,
                          ldc=n_out, geglu=1, rows_per_sample=M, tile=tile)
@@ -129,7 +129,7 @@ def _perm_cols(g):
 
 
 @pytest.mark.parametrize("stride,xform", [(1, 0), (2, 0), (1, 1), (1, 2)])
-@pytest.mark.parametrize("tile", [0x22, 0x11, 0x312, 0x311])
+@pytest.mark.parametrize("tile", [0x22, 0x11, 0x312, 0x311, 0x4022, 0x4312])
 def test_gemm_conv3x3(dev, stride, xform, tile):
     torch.manual_seed(3 + stride + xform)
     B, H, W, Ci, Co = 2, 12, 20, 128, 192
@@ -440,7 +440,7 @@ def test_lora_wgrad(dev):
     report("wgrad_conv", out, 0.25 * wd.grad.permute(0, 2, 3, 1).reshape(4, -1), 1e-4)
 
 
-@pytest.mark.parametrize("tile", [0x22, 0x21, 0x12, 0x11, 0x311])
+@pytest.mark.parametrize("tile", [0x22, 0x21, 0x12, 0x11, 0x311, 0x4022, 0x4322, 0x4012])
 def test_gemm_fused_lora_down(dev, tile):
     """LoRAModule.forward fused into one launch: y = x W^T + b + s (x A^T) B^T, T = x A^T written for backward."""
     torch.manual_seed(31)
