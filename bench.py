@@ -78,13 +78,14 @@ def measure_roofline(eng, plan):
         g["flops"] += gemm_flops(d)
         g["calls"] += 1
     var, g = max(groups.items(), key=lambda kv: kv[1]["ms"])
-    mi, ni, mode = var >> 8, (var >> 4) & 15, var & 15
+    def name(v):   # template arguments <MI, NI, MODE, ..., WM> of the instantiation (WM*2 waves per workgroup)
+        return f"gemm_kernel<MI={(v >> 8) & 15},NI={(v >> 4) & 15},MODE={v & 15},WM={v >> 12}>"
     achieved = g["flops"] / (g["ms"] * 1e-3) / 1e12
-    table = {f"gemm_kernel<{v >> 8},{(v >> 4) & 15},{v & 15}>": dict(
+    table = {name(v): dict(
         calls_per_pass=x["calls"], ms_per_pass=round(x["ms"], 3), tflops=round(x["flops"] / (x["ms"] * 1e-3) / 1e12, 1))
         for v, x in sorted(groups.items())}
     return {
-        "bound": "mfma", "kernel": f"gemm_kernel<{mi}, {ni}, {mode}>",
+        "bound": "mfma", "kernel": name(var),
         "achieved": round(achieved, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
         "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": None,
         "flop_per_launch": g["flops"] / g["calls"], "avg_launch_us": round(1e3 * g["ms"] / g["calls"], 2),
@@ -130,7 +131,9 @@ def cpu_baseline(model, hw):
             a @ b
         tm[dt] = time.time() - t0
     need32 = 4 * 2.6e9 / 2 ** 30 * 1.3 if model == "sdxl" else 6.0
-    dtype = torch.float32 if (tm[torch.float32] < tm[torch.bfloat16] and _mem_limit_gb() > need32 + 8) else torch.bfloat16
+    # fp32 whenever it fits: oneDNN bf16 convolutions fall off a cliff on hosts whose bf16 GEMM probe looks fine
+    # (measured: 261 s for one 256x256 step in bf16 vs 6.4 s in fp32 on the same class of EPYC host)
+    dtype = torch.float32 if _mem_limit_gb() > need32 + 8 else torch.bfloat16
     log(f"gemm probe fp32 {tm[torch.float32]:.3f}s bf16 {tm[torch.bfloat16]:.3f}s, mem limit {_mem_limit_gb():.0f} GB -> {dtype}")
     net = build_unet(model, device="meta")
     g = torch.Generator().manual_seed(0)
@@ -162,17 +165,21 @@ def cpu_baseline(model, hw):
         assert torch.isfinite(out.float()).all()
         return dt
 
-    probe_hw = min(32, hw)
-    t_probe = run(probe_hw)
-    log(f"probe step at {probe_hw * 8}px: {t_probe:.1f}s")
-    budget = 30.0
-    use_hw = hw
-    while use_hw > probe_hw and t_probe * (use_hw / probe_hw) ** 2 > budget:
-        use_hw //= 2
-    dt = run(use_hw) if use_hw != probe_hw else t_probe
+    # ladder 64px -> 128px -> ... : go one size up only while 4x the last step (area scaling) fits what is left of
+    # the ~30 s budget, so a slow host can never stretch the default bench run by minutes
+    budget, spent = 30.0, 0.0
+    use_hw = min(8, hw)
+    dt = run(use_hw)
+    spent += dt
+    log(f"step at {use_hw * 8}px: {dt:.1f}s")
+    while use_hw < hw and 4.0 * dt <= budget - spent:
+        use_hw *= 2
+        dt = run(use_hw)
+        spent += dt
+        log(f"step at {use_hw * 8}px: {dt:.1f}s")
     scale = (hw / use_hw) ** 2
     note = "" if use_hw == hw else (f"; timed at {use_hw * 8}x{use_hw * 8} ({dt:.1f} s) and EXTRAPOLATED x{scale:.0f} by "
-                                    f"latent area to {hw * 8}x{hw * 8}")
+                                    f"latent area to {hw * 8}x{hw * 8} (optimistic for the CPU: self-attention grows faster than area)")
     return {"value": round(1.0 / (dt * scale), 5), "unit": "steps/s", "cores": os.cpu_count(), "kind": "port",
             "sample": f"1 UNet denoise step (CFG pair B=2, {model}, {'fp32' if dtype == torch.float32 else 'bf16'} "
                       f"torch/oneDNN forward, {dt:.1f} s) with the CPU oracle = PyTorch restatement of the diffusers "

@@ -47,7 +47,7 @@ const char* slh_last_error(void);
 typedef struct slh_gemm_desc {
     const void* a0;          /* source 0 (bf16) */
     const void* a1;          /* source 1 or NULL: channels [ca0, ca0+ca1) */
-    const void* w;           /* [N][K] bf16 */
+    const void* w;           /* bf16 weights: [N][ldw] row-major (w_layout 0) or tile-packed (w_layout 1) */
     const void* bias;        /* [N] bf16 or NULL */
     const void* rowbias;     /* [batch][ld_rowbias] bf16 or NULL: per-sample per-channel add (time embedding) */
     const float* lora_t;     /* [M][ld_t] fp32 or NULL */
@@ -70,12 +70,18 @@ typedef struct slh_gemm_desc {
     int32_t ld_t, lora_groups; /* N/lora_groups columns share one rank-4 slice of T */
     int32_t ld_res, ldc;
     int32_t geglu;           /* 1: out[:, j] = a_j * gelu(g_j); W rows pre-permuted in 64-row blocks [32 a | 32 g] */
-    int32_t tile;            /* 0 auto; else (MI<<4)|NI with MI,NI in {1,2}: block tile (64*MI) x (64*NI) */
+    int32_t tile;            /* 0 auto; else (WM<<12)|(stages<<8)|(MI<<4)|NI, MI,NI in {1,2}, WM in {0|2, 4}: WM*2 waves per
+                                workgroup, block tile (32*MI*WM) x (64*NI) */
     int32_t lora_rank;       /* 0 = 4.  With lora_up_rmajor: total rank 4 | 8 | 12 (T has that many columns) */
     int32_t lora_up_rmajor;  /* 1: lora_up is [rank][N] (= lora_down as stored): backward-data LoRA term */
+    int32_t w_layout;        /* 0: w is [N][ldw].  1: frozen weights repacked once at load time into the order the kernel
+                                streams them: [ceil(N/64)][K/64] blocks of 64 rows x 64 k (8 KB contiguous, rows past N
+                                zero), 16-byte slot s of row r stored at slot s ^ ((r>>1)&7) (the LDS swizzle applied
+                                in memory, so every LDS-DMA instruction reads 1 KB of consecutive addresses); ldw unused */
+    int32_t reserved_;
 } slh_gemm_desc;
 int slh_gemm(const slh_gemm_desc* d, slh_stream_t stream);
-/* (MI<<8)|(NI<<4)|mode of the kernel instantiation gemm_kernel<MI,NI,mode> slh_gemm would launch for d
+/* (WM<<12)|(MI<<8)|(NI<<4)|mode of the kernel instantiation gemm_kernel<MI,NI,mode,..,WM> slh_gemm would launch for d
  * (used by bench.py to attribute measured time and algorithmic FLOPs to one profiled kernel name). */
 int slh_gemm_variant(const slh_gemm_desc* d);
 
@@ -105,7 +111,7 @@ int slh_skinny(const slh_skinny_desc* d, slh_stream_t stream);
  * ---------------------------------------------------------------------------------------------- */
 typedef struct slh_gemv_desc {
     const void* x;           /* [nb][ldx] bf16 */
-    const void* w;           /* [N][K] bf16 */
+    const void* w;           /* bf16 weights: [N][ldw] row-major (w_layout 0) or tile-packed (w_layout 1) */
     const void* bias;        /* [N] bf16 or NULL */
     const void* addend;      /* [nb][ld_add] bf16 or NULL */
     const float* lora_t;     /* [nb][ld_t] fp32 or NULL */

@@ -19,6 +19,7 @@ ap.add_argument("--hw", type=int, default=128)
 ap.add_argument("--batch", type=int, default=2)
 ap.add_argument("--iters", type=int, default=10)
 ap.add_argument("--lora", action="store_true")
+ap.add_argument("--warm", type=int, default=3)
 args = ap.parse_args()
 
 dev = torch.device("cuda:0")
@@ -47,7 +48,7 @@ torch.cuda.synchronize()
 print("eps rms", out.float().pow(2).mean().sqrt().item(), "finite", bool(torch.isfinite(out.float()).all()), flush=True)
 p = eng.plan(B, hw, hw, mode)
 s = torch.cuda.current_stream().cuda_stream
-for _ in range(3):
+for _ in range(args.warm):
     p.prog.run(s)
 torch.cuda.synchronize()
 t0 = time.time()

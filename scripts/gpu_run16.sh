@@ -1,0 +1,6 @@
+#!/bin/bash
+mkdir -p gpurun_out
+timeout 600 python -m pytest tests/test_kernels_gpu.py -x -q -m gpu -k "gemm" > gpurun_out/t16_kernels.log 2>&1; tail -2 gpurun_out/t16_kernels.log
+python scripts/probe_gemm.py --reps 50 > gpurun_out/t16_probe.log 2>&1; cut -c1-120 gpurun_out/t16_probe.log
+python scripts/bench_forward.py --lora --iters 10 > gpurun_out/t16_fwd_on.log 2>&1; tail -1 gpurun_out/t16_fwd_on.log
+python scripts/bench_forward.py --iters 10 > gpurun_out/t16_fwd_off.log 2>&1; tail -1 gpurun_out/t16_fwd_off.log

@@ -10,7 +10,8 @@ agg = defaultdict(lambda: defaultdict(float))
 cnt = defaultdict(set)
 for f in files:
     for r in csv.DictReader(open(f)):
-        k = r["Kernel_Name"][:60]
+        k = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "")
+        k = k.split("(")[0][:70].replace(",", ";")
         agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
         cnt[k].add(r["Dispatch_Id"])
 names = sorted({c for v in agg.values() for c in v})

@@ -54,7 +54,7 @@ table, total_best, total_heur = {}, 0.0, 0.0
 for key, ds in sorted(shapes.items(), key=lambda kv: -kv[1][0].M * kv[1][0].N * kv[1][0].K * len(kv[1])):
     d0 = ds[0]
     res = {}
-    for tile in (0x22, 0x21, 0x12, 0x11, 0x321, 0x312, 0x311, 0x4022, 0x4322, 0x4012, 0x4312, 0):
+    for tile in (0x22, 0x21, 0x12, 0x11, 0x4022, 0x4012, 0x4011, 0):
         if d0.geglu and (tile & 15) == 1:
             continue
         if (tile >> 12) == 4 and d0.M * d0.N < 256 * 128 * 64:

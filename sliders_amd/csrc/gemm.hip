@@ -17,6 +17,8 @@
 // GEGLU.proj, FeedForward.net.2, Transformer2DModel.proj_in/out) plus the LoRA branch of
 // trainscripts/textsliders/lora.py:108-112.
 #include "common.h"
+#include <cstdlib>
+#include <cstdint>
 #include "../../include/sliders_hip.h"
 
 namespace {
@@ -30,8 +32,10 @@ struct GemmArgs {
     int hs, ws, src_xform, stride, ho, wo;
     int ldw, M, N, K;
     int ld_rowbias, rows_per_sample, ld_t, lora_cols_per_group, ld_res, ldc, geglu;
-    int lora_rank, lora_up_rmajor;
-    int tiles_m, tiles_n;
+    int lora_rank, lora_up_rmajor, w_packed;
+    int tiles_m, tiles_n, group_m;
+    int store16;  // c and ldc allow 16-byte row stores
+    int probe;   // diagnostics (slh_gemm_desc.reserved_): 1 skip tile refills, 2 skip MFMA work, 4 skip the epilogue
 };
 
 constexpr int BK = 64;
@@ -43,8 +47,18 @@ __device__ __forceinline__ int lds_off(int row, int slot) {
 
 // WM = waves along M (2: 4-wave workgroup, tile 64*MI x 64*NI; 4: 8-wave workgroup, tile 128*MI x 64*NI - twice
 // the W-tile reuse per byte pulled from L2, which is what bounds these kernels)
+// waves per SIMD the LDS footprint allows (workgroups per CU x waves per workgroup / 4 SIMDs); handed to the
+// register allocator as the occupancy target so the epilogue's temporaries cannot cost a resident wave
+constexpr int gemm_waves_per_simd(int MI, int NI, int STAGES, bool LORA, int WM) {
+    const int lds = STAGES * (32 * MI * WM + 64 * NI + (LORA ? 32 : 0)) * 128;
+    int blocks = (160 * 1024) / lds;
+    int w = blocks * 2 * WM / 4;
+    if (LORA && MI * NI == 1 && WM == 2) w = 4;   // 64x64 + fused LoRA needs ~110 registers: 4 waves, not 5
+    return w < 1 ? 1 : (w > 8 ? 8 : w);
+}
+
 template <int MI, int NI, int MODE, int STAGES, bool LORA, int WM>
-__global__ __launch_bounds__(128 * WM) void gemm_kernel(const GemmArgs p) {
+__global__ __launch_bounds__(128 * WM, gemm_waves_per_simd(MI, NI, STAGES, LORA, WM)) void gemm_kernel(const GemmArgs p) {
     constexpr int NW = 2 * WM;
     constexpr int BM = 32 * MI * WM;
     constexpr int BN = 64 * NI;
@@ -65,8 +79,10 @@ __global__ __launch_bounds__(128 * WM) void gemm_kernel(const GemmArgs p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
 
-    // ---- XCD-aware tile mapping: block b runs on XCD b%8; give each XCD a contiguous chunk of the
-    // tile sequence (m fastest inside an n panel) so neighbours share the W panel in that XCD's L2.
+    // ---- XCD-aware tile mapping: block b runs on XCD b%8 (own 4 MB L2); give each XCD a contiguous chunk of a
+    // grouped tile sequence: groups of group_m consecutive m-tiles, inside a group m fastest, then n.  The host
+    // sizes the groups so that one group's X rows stay resident in the XCD's L2 while the W panels stream past
+    // once (measured before grouping: L2 hit rate 62-78 %, fabric fetches 6-14x the unique operand bytes).
     int bid = blockIdx.x;
     {
         const int nblk = gridDim.x;
@@ -74,8 +90,16 @@ __global__ __launch_bounds__(128 * WM) void gemm_kernel(const GemmArgs p) {
         const int xcd = bid & 7, idx = bid >> 3;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
-    const int tile_n = bid / p.tiles_m;
-    const int tile_m = bid - tile_n * p.tiles_m;
+    int tile_m, tile_n;
+    {
+        const int gsz = p.group_m * p.tiles_n;
+        const int g = bid / gsz;
+        const int first_m = g * p.group_m;
+        const int gm = min(p.group_m, p.tiles_m - first_m);
+        const int r = bid - g * gsz;
+        tile_n = r / gm;
+        tile_m = first_m + r - tile_n * gm;
+    }
     const int m0 = tile_m * BM, n0 = tile_n * BN;
 
     // ---- per-lane fill geometry --------------------------------------------------------------
@@ -110,8 +134,10 @@ __global__ __launch_bounds__(128 * WM) void gemm_kernel(const GemmArgs p) {
         const int row = (wave + NW * i) * 8 + frow;
         int n = n0 + row;
         n = n < p.N ? n : p.N - 1;
-        wptr[i] = p.w + (long)n * p.ldw + ((fslot ^ ((row >> 1) & 7)) << 3);
+        wptr[i] = p.w_packed ? p.w + ((long)(n >> 6) * (p.K >> 6)) * 4096 + ((n & 63) << 6) + (fslot << 3)
+                             : p.w + (long)n * p.ldw + ((fslot ^ ((row >> 1) & 7)) << 3);
     }
+    const int wkstep = p.w_packed ? 4096 : BK;   // elements between consecutive K tiles of one W row group
 
     auto stage = [&](int buf, int kt) {
         const int k0 = kt * BK;
@@ -150,7 +176,7 @@ __global__ __launch_bounds__(128 * WM) void gemm_kernel(const GemmArgs p) {
             }
         }
 #pragma unroll
-        for (int i = 0; i < WI; ++i) glds16(wptr[i] + k0, dW + (wave + NW * i) * 1024);
+        for (int i = 0; i < WI; ++i) glds16(wptr[i] + (long)kt * wkstep, dW + (wave + NW * i) * 1024);
         if (LORA) {
             const int row = (wave & 3) * 8 + frow;   // with 8 waves the upper four re-issue the same rows (benign)
             const __bf16* src = row < p.lora_rank
@@ -215,9 +241,10 @@ __global__ __launch_bounds__(128 * WM) void gemm_kernel(const GemmArgs p) {
         stage(0, 0);
         for (int kt = 0; kt < nk; ++kt) {
             __syncthreads();  // drains this wave's glds (vmcnt(0)) and orders all waves
-            if (kt + 1 < nk) stage((kt + 1) & 1, kt + 1);
-            compute(kt & 1);
+            if (kt + 1 < nk && !(p.probe & 1)) stage((kt + 1) & 1, kt + 1);
+            if (!(p.probe & 2)) compute(kt & 1);
         }
+        if (p.probe & 4) return;
     } else {
         // 3-deep ring: tile kt+1 stays in flight across the barrier (counted vmcnt, raw s_barrier), tile kt+2
         // is issued right after it.  A wave's own glds for tile kt are retired by vmcnt(L); the barrier then
@@ -238,13 +265,60 @@ __global__ __launch_bounds__(128 * WM) void gemm_kernel(const GemmArgs p) {
 
     // ---- epilogue ---------------------------------------------------------------------------------
     // acc[i][j][r] = C[m = m0 + wm*32*MI + i*32 + lrow][n = n0 + wn*32*NI + j*32 + (r&3) + 8*(r>>2) + 4*lhi]
+    if (p.geglu) {
+        // GEGLU: W rows are stored in 64-row blocks [32 value rows | 32 gate rows]; NI is 2 here, so
+        // sub-tile j=0 holds the values and j=1 the gates of the same 32 output columns.
+        if (NI == 2) {
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                const int m = m0 + wm * (32 * MI) + i * 32 + lrow;
+                if (m >= p.M) continue;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int n = n0 + wn * 64 + q * 8 + lhi * 4;          // row index of the value rows
+                    const int nout = ((n0 + wn * 64) >> 1) + q * 8 + lhi * 4;
+                    if (n + 32 >= p.N) continue;
+                    float a[4], g[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { a[e] = acc[i][0][q * 4 + e]; g[e] = acc[i][NI - 1][q * 4 + e]; }
+                    if (p.bias) {
+                        const bf16x4 ba = *(const bf16x4*)(p.bias + n);
+                        const bf16x4 bg = *(const bf16x4*)(p.bias + n + 32);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { a[e] += (float)ba[e]; g[e] += (float)bg[e]; }
+                    }
+                    bf16x4 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        // reference rounds proj(x) to bf16 before chunk/gelu
+                        const float av = round_bf16(a[e]), gv = round_bf16(g[e]);
+                        o[e] = (__bf16)(av * round_bf16(gelu_erf_f(gv)));
+                    }
+                    *(bf16x4*)(p.c + (long)m * p.ldc + nout) = o;
+                }
+            }
+        }
+        return;
+    }
+
+    // The MFMA result layout gives a lane 4 consecutive columns of ONE row, so a direct store touches 32 rows per
+    // instruction with 8-byte pieces (store-issue bound).  Each wave therefore transposes its 32 x (32*NI) sub-tile
+    // through a private, swizzled LDS patch and writes whole 64/128-byte row segments with 16-byte stores.
+    constexpr int S = 4 * NI;                  // 16-byte slots per staged row
+    constexpr int LOG2S = NI == 2 ? 3 : 2;
+    __syncthreads();                           // every wave is done reading the operand stages being reused below
+    char* sE = smem + wave * (32 * S * 16);
     const bool have_t = LORA || p.lora_t != nullptr;
     const float lscale = have_t ? *p.lora_scale : 0.f;
+    const int ncol0 = n0 + wn * (32 * NI);
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
-        const int m = m0 + wm * (32 * MI) + i * 32 + lrow;
-        if (m >= p.M) continue;
+        const int mbase = m0 + wm * (32 * MI) + i * 32;
+        const int m = mbase + lrow;
+        const bool mok = m < p.M;
         f32x4 tv[3];
+#pragma unroll
+        for (int g = 0; g < 3; ++g) tv[g] = f32x4{0.f, 0.f, 0.f, 0.f};
         if (LORA) {
             // ranks 0-3 sit in registers 0-3 of the lhi=0 half, 4-7 in registers 0-3 of the lhi=1 half, 8-11 in
             // registers 4-7 of the lhi=0 half: one exchange with lane^32 gives every lane all of its row's T
@@ -256,27 +330,27 @@ __global__ __launch_bounds__(128 * WM) void gemm_kernel(const GemmArgs p) {
                 tv[1][e] = lhi == 1 ? x0 : y0;
                 tv[2][e] = lhi == 0 ? x1 : y1;
             }
-            if (p.lora_t_out && tile_n == 0 && wn == 0 && lhi == 0) {
+            if (mok && p.lora_t_out && tile_n == 0 && wn == 0 && lhi == 0) {
 #pragma unroll
                 for (int g = 0; g < 3; ++g)
                     if (g * 4 < p.lora_rank) *(f32x4*)(p.lora_t_out + (long)m * p.ld_t + g * 4) = tv[g];
             }
-        } else if (p.lora_t) {
+        } else if (p.lora_t && mok) {
 #pragma unroll
             for (int g = 0; g < 3; ++g)
                 if (g * 4 < p.ld_t) tv[g] = *(const f32x4*)(p.lora_t + (long)m * p.ld_t + g * 4);
         }
-        const __bf16* rb = p.rowbias ? p.rowbias + (long)(m / p.rows_per_sample) * p.ld_rowbias : nullptr;
-        if (!p.geglu) {
+        const __bf16* rb = (p.rowbias && mok) ? p.rowbias + (long)(m / p.rows_per_sample) * p.ld_rowbias : nullptr;
+        const int hb = (lrow >> LOG2S) & 1;
 #pragma unroll
-            for (int j = 0; j < NI; ++j) {
+        for (int j = 0; j < NI; ++j) {
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int n = n0 + wn * (32 * NI) + j * 32 + q * 8 + lhi * 4;
-                    if (n >= p.N) continue;
-                    float v[4];
+            for (int q = 0; q < 4; ++q) {
+                const int n = ncol0 + j * 32 + q * 8 + lhi * 4;
+                float v[4];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = acc[i][j][q * 4 + e];
+                for (int e = 0; e < 4; ++e) v[e] = acc[i][j][q * 4 + e];
+                if (mok && n < p.N) {
                     if (p.bias) {
                         const bf16x4 b4 = *(const bf16x4*)(p.bias + n);
 #pragma unroll
@@ -318,41 +392,39 @@ __global__ __launch_bounds__(128 * WM) void gemm_kernel(const GemmArgs p) {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) v[e] += (float)r4[e];
                     }
-                    bf16x4 o;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) o[e] = (__bf16)v[e];
-                    *(bf16x4*)(p.c + (long)m * p.ldc + n) = o;
                 }
+                bf16x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = (__bf16)v[e];
+                // logical 16-byte slot j*4+q, 8-byte half lhi of row lrow; slot ^ row and half ^ row-bit keep both
+                // the 8-byte writes and the 16-byte row reads off each other's banks
+                const int slot = (j * 4 + q) ^ (lrow & (S - 1));
+                *(bf16x4*)(sE + lrow * (S * 16) + slot * 16 + ((lhi ^ hb) << 3)) = o;
             }
-        } else {
-            // GEGLU: W rows are stored in 64-row blocks [32 value rows | 32 gate rows]; NI is 2 here, so
-            // sub-tile j=0 holds the values and j=1 the gates of the same 32 output columns.
-            if (NI == 2) {
+        }
+        __builtin_amdgcn_wave_barrier();       // same-wave LDS ops retire in order; only the compiler must not reorder
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int n = n0 + wn * 64 + q * 8 + lhi * 4;          // row index of the value rows
-                    const int nout = ((n0 + wn * 64) >> 1) + q * 8 + lhi * 4;
-                    if (n + 32 >= p.N) continue;
-                    float a[4], g[4];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) { a[e] = acc[i][0][q * 4 + e]; g[e] = acc[i][NI - 1][q * 4 + e]; }
-                    if (p.bias) {
-                        const bf16x4 ba = *(const bf16x4*)(p.bias + n);
-                        const bf16x4 bg = *(const bf16x4*)(p.bias + n + 32);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) { a[e] += (float)ba[e]; g[e] += (float)bg[e]; }
+        for (int it = 0; it < S / 2; ++it) {
+            const int idx = it * 64 + lane;
+            const int row = idx / S, slot = idx % S;
+            bf16x8 t8 = *(const bf16x8*)(sE + row * (S * 16) + ((slot ^ (row & (S - 1))) << 4));
+            if ((row >> LOG2S) & 1) t8 = __builtin_shufflevector(t8, t8, 4, 5, 6, 7, 0, 1, 2, 3);
+            const int m2 = mbase + row, n2 = ncol0 + slot * 8;
+            if (m2 < p.M && n2 < p.N) {
+                __bf16* dst = p.c + (long)m2 * p.ldc + n2;
+                if (n2 + 8 <= p.N) {
+                    if (p.store16) {
+                        *(bf16x8*)dst = t8;
+                    } else {
+                        *(bf16x4*)dst = __builtin_shufflevector(t8, t8, 0, 1, 2, 3);
+                        *(bf16x4*)(dst + 4) = __builtin_shufflevector(t8, t8, 4, 5, 6, 7);
                     }
-                    bf16x4 o;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        // reference rounds proj(x) to bf16 before chunk/gelu
-                        const float av = round_bf16(a[e]), gv = round_bf16(g[e]);
-                        o[e] = (__bf16)(av * round_bf16(gelu_erf_f(gv)));
-                    }
-                    *(bf16x4*)(p.c + (long)m * p.ldc + nout) = o;
+                } else {
+                    *(bf16x4*)dst = __builtin_shufflevector(t8, t8, 0, 1, 2, 3);   // N % 4 == 0: exactly 4 columns left
                 }
             }
         }
+        __builtin_amdgcn_wave_barrier();
     }
 }
 
@@ -391,6 +463,32 @@ static void pick_tile(const slh_gemm_desc* d, int& MI, int& NI, int& WM) {
     if (tiles(2, 2) < 384) { MI = 2; NI = 1; }
     if (!d->geglu && tiles(2, 2) < 192) { MI = 1; NI = 1; }
     if (d->geglu) { NI = 2; if (tiles(2, 2) < 256) MI = 1; }
+}
+
+// L2 blocking: number of m-tile groups G (see the kernel's tile mapping).  An XCD's chunk of the grouped sequence reads
+// its groups' X rows once if a group fits the L2 budget, and sweeps W once per group it touches, so the fabric
+// traffic is about  X * max(1, 8/G) + G * W ; pick the power of two that minimises it.
+static int pick_group_m(const slh_gemm_desc* d, int tiles_m) {
+    static const char* env = getenv("SLIDERS_GEMM_GROUPS");   // measurement aid: force G (1 = ungrouped order)
+    if (tiles_m <= 1) return 1;
+    int G = 1;
+    if (env && atoi(env) > 0) {
+        G = atoi(env);
+    } else {
+        const int cin = d->ca0 + d->ca1;
+        double xb = 2.0 * d->M * cin;
+        if (d->mode == 1) xb = 2.0 * d->batch * d->hs * d->ws * cin;     // unique source pixels of the implicit GEMM
+        const double wb = 2.0 * d->N * d->K;
+        const double budget = 2.75e6;                                    // of the 4 MB L2: the rest holds W panels + C
+        double best = -1.0;
+        for (int g = 1; g <= tiles_m; g *= 2) {
+            if (xb / g > budget && 2 * g <= tiles_m) continue;
+            const double cost = xb * (g < 8 ? 8.0 / g : 1.0) + g * wb;
+            if (best < 0.0 || cost < best) { best = cost; G = g; }
+        }
+    }
+    if (G > tiles_m) G = tiles_m;
+    return (tiles_m + G - 1) / G;
 }
 
 // (MI<<8)|(NI<<4)|mode of the kernel instantiation slh_gemm would launch: gemm_kernel<MI, NI, mode>
@@ -445,7 +543,8 @@ extern "C" int slh_gemm(const slh_gemm_desc* d, slh_stream_t stream) {
     int MI = 2, NI = 2, WM = 2;
     pick_tile(d, MI, NI, WM);
     SLH_CHECK((MI == 1 || MI == 2) && (NI == 1 || NI == 2), "slh_gemm: bad tile");
-    SLH_CHECK(WM == 2 || NI == 2, "slh_gemm: 8-wave tiles need NI = 2");
+    SLH_CHECK(WM == 2 || NI == 2 || MI == 1, "slh_gemm: 8-wave tiles are 128x64, 128x128 or 256x128");
+    SLH_CHECK(d->w_layout == 0 || d->w_layout == 1, "slh_gemm: bad w_layout");
     if (d->geglu) SLH_CHECK(NI == 2, "slh_gemm: geglu needs NI=2");
 
     GemmArgs a;
@@ -461,12 +560,17 @@ extern "C" int slh_gemm(const slh_gemm_desc* d, slh_stream_t stream) {
     a.ld_t = d->ld_t; a.lora_cols_per_group = (d->lora_t || d->lora_down) ? d->N / d->lora_groups : 1;
     a.ld_res = d->ld_res; a.ldc = d->ldc; a.geglu = d->geglu;
     a.lora_rank = d->lora_rank > 0 ? d->lora_rank : 4; a.lora_up_rmajor = d->lora_up_rmajor;
+    a.w_packed = d->w_layout;
+    a.probe = d->reserved_;
+    a.store16 = (d->ldc % 8 == 0) && (((uintptr_t)d->c & 15) == 0);
     a.tiles_m = (d->M + 32 * MI * WM - 1) / (32 * MI * WM);
     a.tiles_n = (d->N + 64 * NI - 1) / (64 * NI);
+    a.group_m = pick_group_m(d, a.tiles_m);
     hipStream_t s = (hipStream_t)stream;
     const int stages = (d->tile >> 8) & 15;   // tile = (WM<<12)|(stages<<8)|(MI<<4)|NI ; stages 0/2 = double buffer
     if (WM == 4) {
         if (MI == 2) return launch_gemm<2, 2, 4>(a, d->mode, stages, s);   // 256 x 128, 8 waves
+        if (NI == 1) return launch_gemm<1, 1, 4>(a, d->mode, stages, s);   // 128 x 64, 8 waves
         return launch_gemm<1, 2, 4>(a, d->mode, stages, s);                // 128 x 128, 8 waves
     }
     if (MI == 2 && NI == 2) return launch_gemm<2, 2, 2>(a, d->mode, stages, s);

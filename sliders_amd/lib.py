@@ -32,7 +32,8 @@ GemmDesc = _struct("GemmDesc", _ptrs("a0", "a1", "w", "bias", "rowbias", "lora_t
                                      "residual", "c", "lora_down", "lora_t_out")
                    + _ints("lda0", "lda1", "ca0", "ca1", "mode", "batch", "hs", "ws", "src_xform", "stride",
                            "ho", "wo", "ldw", "M", "N", "K", "ld_rowbias", "rows_per_sample", "ld_t",
-                           "lora_groups", "ld_res", "ldc", "geglu", "tile", "lora_rank", "lora_up_rmajor"))
+                           "lora_groups", "ld_res", "ldc", "geglu", "tile", "lora_rank", "lora_up_rmajor", "w_layout",
+                           "reserved_"))
 SkinnyDesc = _struct("SkinnyDesc", _ptrs("a0", "a1", "w", "bias", "out")
                      + _ints("lda0", "lda1", "ca0", "ca1", "mode", "batch", "hs", "ws", "src_xform", "stride",
                              "ho", "wo", "M", "R", "K", "ldo", "out_kind", "w_kmajor"))

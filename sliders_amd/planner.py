@@ -196,7 +196,8 @@ class UNetPlan:
                          mode=0, stride=1, ldw=K, M=M, N=N, K=K,
                          ld_rowbias=rowbias[1] if rowbias else 0, rows_per_sample=Ho * Wo,
                          ld_t=(4 * len(grp)) if grp else 0, lora_groups=len(grp) if grp else 0,
-                         ld_res=residual.ld if residual else 0, ldc=out.ld, geglu=1 if geglu else 0, tile=0)
+                         ld_res=residual.ld if residual else 0, ldc=out.ld, geglu=1 if geglu else 0, tile=0,
+                         w_layout=1 if (w_ptr is None and self.w.packed) else 0)
         if conv is not None:
             self._conv_fields(d, x0, conv, Ho, Wo)
         d.tile = tuned_tile(d)
@@ -671,7 +672,8 @@ class BackwardPlan:
                 tb = self.arena.alloc((Ms, cin), torch.bfloat16, name + ".gxcat")
                 tgt, tacc = Act(tb.ptr, self.nb, x0.H, x0.W, cin, cin, tb), False
             d = lib.GemmDesc(a0=gy.ptr, w=wT, c=tgt.ptr, residual=tgt.ptr if tacc else 0, lda0=gy.ld, ca0=N, mode=0,
-                             stride=1, ldw=N, M=Ms, N=cin, K=N, ld_res=tgt.ld, ldc=tgt.ld, rows_per_sample=Ho * Wo)
+                             stride=1, ldw=N, M=Ms, N=cin, K=N, ld_res=tgt.ld, ldc=tgt.ld, rows_per_sample=Ho * Wo,
+                             w_layout=1 if self.w.packed else 0)
             if grp is not None:
                 d.lora_t, d.ld_t, d.lora_up, d.lora_scale = U.ptr, 4 * len(grp), self.lora.down_ptr(grp[0]), self.scale_ptr
                 d.lora_groups, d.lora_rank, d.lora_up_rmajor = 1, 4 * len(grp), 1
@@ -695,7 +697,7 @@ class BackwardPlan:
             d = lib.GemmDesc(a0=gy.ptr, w=wT, c=tgt.ptr, residual=tgt.ptr if tacc else 0, lda0=gy.ld, ca0=N, mode=1,
                              batch=self.nb, hs=Ho, ws=Wo, src_xform=2 if stride == 2 else 0, stride=1, ho=HL, wo=WL,
                              ldw=9 * N, M=self.nb * HL * WL, N=cin, K=9 * N, ld_res=tgt.ld, ldc=tgt.ld,
-                             rows_per_sample=HL * WL)
+                             rows_per_sample=HL * WL, w_layout=1 if self.w.packed else 0)
             d.tile = tuned_tile(d)
             self.prog.add(lib.OP_GEMM, d, name + ".dgrad")
             if grp is not None:

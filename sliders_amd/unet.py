@@ -219,6 +219,7 @@ class _VirtualWeights:
         self.temb_offsets = w.temb_offsets
         self.temb_total = w.temb_total
         self.resnet_paths = w.resnet_paths
+        self.packed = w.packed
 
     def ptr(self, name):
         return 0x1000

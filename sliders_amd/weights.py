@@ -8,12 +8,16 @@ the reference loads at trainscripts/textsliders/model_util.py:67-72 / 169-174). 
  - attn1 q/k/v       fused [3C][C];  attn2 k/v fused [2C][Dctx]
  - GEGLU proj        rows permuted into 64-row blocks [32 value rows | 32 gate rows] (fused GEGLU epilogue)
  - time_emb_proj     all ResnetBlock2D projections concatenated [sum(Cout)][temb] (one GEMV per UNet pass)
+ - every matrix slh_gemm streams is then tile-packed (`pack_gemm_w`, slh_gemm_desc.w_layout = 1): [N/64][K/64]
+   blocks of 64 rows x 64 k, 8 KB contiguous each, with the kernel's LDS swizzle already applied, so one
+   workgroup's K step reads whole DRAM pages instead of 64 row fragments 2*K bytes apart
 and, for the training pass only, the transposed / flipped copies that turn every backward-data product into
 the same forward kernel (weights are frozen, so this is paid once): Linear W^T, conv3x3 [Cin][tap'][Cout]
 with the taps flipped.
 """
 from __future__ import annotations
 
+import os
 from typing import Dict, List, Tuple
 
 import torch
@@ -40,12 +44,41 @@ def _geglu_perm(w: torch.Tensor) -> torch.Tensor:
     return torch.stack([a.reshape(n // 32, 32, *rest), g.reshape(n // 32, 32, *rest)], dim=1).reshape(n2, *rest).contiguous()
 
 
+def pack_gemm_w(w: torch.Tensor) -> torch.Tensor:
+    """[N][K] (K % 64 == 0) -> flat tile-packed layout of slh_gemm_desc.w_layout = 1 (include/sliders_hip.h):
+    block (n>>6, k>>6) is 64 rows x 8 slots x 8 elements, slot s of row r stored at physical slot s ^ ((r>>1)&7);
+    rows N..ceil64(N) are zero."""
+    n, k = w.shape
+    assert k % 64 == 0, k
+    npad = (n + 63) // 64 * 64
+    if npad != n:
+        w = torch.cat([w, w.new_zeros(npad - n, k)], 0)
+    t = w.reshape(npad // 64, 64, k // 64, 8, 8).permute(0, 2, 1, 3, 4)          # [nb][kb][r][slot][8]
+    r = torch.arange(64, device=w.device)
+    src = torch.arange(8, device=w.device)[None, :] ^ ((r >> 1) & 7)[:, None]     # physical slot p holds logical p ^ s(r)
+    idx = src.view(1, 1, 64, 8, 1).expand(t.shape)
+    return torch.gather(t, 3, idx).contiguous().reshape(-1)
+
+
+def unpack_gemm_w(flat: torch.Tensor, n: int, k: int) -> torch.Tensor:
+    """Inverse of pack_gemm_w (tests, checkpoint export)."""
+    npad = (n + 63) // 64 * 64
+    t = flat.reshape(npad // 64, k // 64, 64, 8, 8)
+    r = torch.arange(64, device=flat.device)
+    src = torch.arange(8, device=flat.device)[None, :] ^ ((r >> 1) & 7)[:, None]
+    t = torch.gather(t, 3, src.view(1, 1, 64, 8, 1).expand(t.shape))             # the swizzle is an involution
+    return t.permute(0, 2, 1, 3, 4).reshape(npad, k)[:n].contiguous()
+
+
 class WeightStore:
     def __init__(self, cfg: UNetConfig, state_dict: Dict[str, torch.Tensor], device, dtype=torch.bfloat16):
         self.cfg = cfg
         self.device = device
         self.dtype = dtype
         self.t: Dict[str, torch.Tensor] = {}
+        self.gemm_shape: Dict[str, Tuple[int, int]] = {}
+        # A/B switch for measurements only: SLIDERS_W_ROWMAJOR=1 keeps the GEMM matrices [N][K] (w_layout 0)
+        self.packed = os.environ.get("SLIDERS_W_ROWMAJOR") is None
         self._sd = state_dict
         self.temb_offsets: Dict[str, int] = {}
         self.resnet_paths: List[str] = []
@@ -55,6 +88,17 @@ class WeightStore:
     # -- helpers -----------------------------------------------------------------------------------
     def _put(self, name: str, t: torch.Tensor):
         self.t[name] = t.to(device=self.device, dtype=self.dtype).contiguous()
+
+    def _put_gemm(self, name: str, t: torch.Tensor):
+        """A matrix consumed by slh_gemm: stored tile-packed (shape kept in self.gemm_shape)."""
+        t = t.to(device=self.device, dtype=self.dtype)
+        self.gemm_shape[name] = tuple(t.shape)
+        self.t[name] = pack_gemm_w(t) if self.packed else t.contiguous()
+
+    def gemm_matrix(self, name: str) -> torch.Tensor:
+        """Row-major [N][K] view of a tile-packed matrix (copy)."""
+        n, k = self.gemm_shape[name]
+        return unpack_gemm_w(self.t[name], n, k) if self.packed else self.t[name]
 
     def ptr(self, name: str) -> int:
         return self.t[name].data_ptr()
@@ -86,46 +130,46 @@ class WeightStore:
                 self.resnet_paths.append(name)
                 self._put(f"{name}.norm1.g", sd[f"{name}.norm1.weight"])
                 self._put(f"{name}.norm1.b", sd[f"{name}.norm1.bias"])
-                self._put(f"{name}.conv1.w", _conv3_pack(sd[f"{name}.conv1.weight"]))
+                self._put_gemm(f"{name}.conv1.w", _conv3_pack(sd[f"{name}.conv1.weight"]))
                 self._put(f"{name}.conv1.b", sd[f"{name}.conv1.bias"])
                 self._put(f"{name}.norm2.g", sd[f"{name}.norm2.weight"])
                 self._put(f"{name}.norm2.b", sd[f"{name}.norm2.bias"])
-                self._put(f"{name}.conv2.w", _conv3_pack(sd[f"{name}.conv2.weight"]))
+                self._put_gemm(f"{name}.conv2.w", _conv3_pack(sd[f"{name}.conv2.weight"]))
                 self._put(f"{name}.conv2.b", sd[f"{name}.conv2.bias"])
                 if f"{name}.conv_shortcut.weight" in sd:
                     w = sd[f"{name}.conv_shortcut.weight"]
-                    self._put(f"{name}.conv_shortcut.w", w.reshape(w.shape[0], w.shape[1]))
+                    self._put_gemm(f"{name}.conv_shortcut.w", w.reshape(w.shape[0], w.shape[1]))
                     self._put(f"{name}.conv_shortcut.b", sd[f"{name}.conv_shortcut.bias"])
                 self.temb_offsets[name] = off
                 temb_w.append(sd[f"{name}.time_emb_proj.weight"])
                 temb_b.append(sd[f"{name}.time_emb_proj.bias"])
                 off += node.out_dim
             elif node.cls in ("Downsample2D", "Upsample2D"):
-                self._put(f"{name}.conv.w", _conv3_pack(sd[f"{name}.conv.weight"]))
+                self._put_gemm(f"{name}.conv.w", _conv3_pack(sd[f"{name}.conv.weight"]))
                 self._put(f"{name}.conv.b", sd[f"{name}.conv.bias"])
             elif node.cls == "Transformer2DModel":
                 self._put(f"{name}.norm.g", sd[f"{name}.norm.weight"])
                 self._put(f"{name}.norm.b", sd[f"{name}.norm.bias"])
                 for pj in ("proj_in", "proj_out"):
                     w = sd[f"{name}.{pj}.weight"]
-                    self._put(f"{name}.{pj}.w", w.reshape(w.shape[0], w.shape[1]))
+                    self._put_gemm(f"{name}.{pj}.w", w.reshape(w.shape[0], w.shape[1]))
                     self._put(f"{name}.{pj}.b", sd[f"{name}.{pj}.bias"])
             elif node.cls == "BasicTransformerBlock":
                 for nm in ("norm1", "norm2", "norm3"):
                     self._put(f"{name}.{nm}.g", sd[f"{name}.{nm}.weight"])
                     self._put(f"{name}.{nm}.b", sd[f"{name}.{nm}.bias"])
                 a1, a2 = f"{name}.attn1", f"{name}.attn2"
-                self._put(f"{a1}.qkv.w", torch.cat([sd[f"{a1}.to_q.weight"], sd[f"{a1}.to_k.weight"],
+                self._put_gemm(f"{a1}.qkv.w", torch.cat([sd[f"{a1}.to_q.weight"], sd[f"{a1}.to_k.weight"],
                                                     sd[f"{a1}.to_v.weight"]], 0))
-                self._put(f"{a1}.out.w", sd[f"{a1}.to_out.0.weight"])
+                self._put_gemm(f"{a1}.out.w", sd[f"{a1}.to_out.0.weight"])
                 self._put(f"{a1}.out.b", sd[f"{a1}.to_out.0.bias"])
-                self._put(f"{a2}.q.w", sd[f"{a2}.to_q.weight"])
-                self._put(f"{a2}.kv.w", torch.cat([sd[f"{a2}.to_k.weight"], sd[f"{a2}.to_v.weight"]], 0))
-                self._put(f"{a2}.out.w", sd[f"{a2}.to_out.0.weight"])
+                self._put_gemm(f"{a2}.q.w", sd[f"{a2}.to_q.weight"])
+                self._put_gemm(f"{a2}.kv.w", torch.cat([sd[f"{a2}.to_k.weight"], sd[f"{a2}.to_v.weight"]], 0))
+                self._put_gemm(f"{a2}.out.w", sd[f"{a2}.to_out.0.weight"])
                 self._put(f"{a2}.out.b", sd[f"{a2}.to_out.0.bias"])
-                self._put(f"{name}.ff1.w", _geglu_perm(sd[f"{name}.ff.net.0.proj.weight"]))
+                self._put_gemm(f"{name}.ff1.w", _geglu_perm(sd[f"{name}.ff.net.0.proj.weight"]))
                 self._put(f"{name}.ff1.b", _geglu_perm(sd[f"{name}.ff.net.0.proj.bias"]))
-                self._put(f"{name}.ff2.w", sd[f"{name}.ff.net.2.weight"])
+                self._put_gemm(f"{name}.ff2.w", sd[f"{name}.ff.net.2.weight"])
                 self._put(f"{name}.ff2.b", sd[f"{name}.ff.net.2.bias"])
         self.temb_total = off
         self._put("temb_proj.w", torch.cat(temb_w, 0))
@@ -138,25 +182,25 @@ class WeightStore:
         root = build_tree(self.cfg)
 
         def dg(key):  # packed [Cout][tap][Cin] -> [Cin][flipped tap][Cout]
-            w = self.t[key]
+            w = self.gemm_matrix(key)
             co = w.shape[0]
             ci = w.shape[1] // 9
             return w.view(co, 3, 3, ci).flip(1, 2).permute(3, 1, 2, 0).reshape(ci, 9 * co)
 
         for name, node in root.named_modules():
             if node.cls == "ResnetBlock2D":
-                self._put(f"{name}.conv1.wT", dg(f"{name}.conv1.w"))
-                self._put(f"{name}.conv2.wT", dg(f"{name}.conv2.w"))
+                self._put_gemm(f"{name}.conv1.wT", dg(f"{name}.conv1.w"))
+                self._put_gemm(f"{name}.conv2.wT", dg(f"{name}.conv2.w"))
                 if self.has(f"{name}.conv_shortcut.w"):
-                    self._put(f"{name}.conv_shortcut.wT", self.t[f"{name}.conv_shortcut.w"].t())
+                    self._put_gemm(f"{name}.conv_shortcut.wT", self.gemm_matrix(f"{name}.conv_shortcut.w").t())
             elif node.cls in ("Downsample2D", "Upsample2D"):
-                self._put(f"{name}.conv.wT", dg(f"{name}.conv.w"))
+                self._put_gemm(f"{name}.conv.wT", dg(f"{name}.conv.w"))
             elif node.cls == "Transformer2DModel":
                 for pj in ("proj_in", "proj_out"):
-                    self._put(f"{name}.{pj}.wT", self.t[f"{name}.{pj}.w"].t())
+                    self._put_gemm(f"{name}.{pj}.wT", self.gemm_matrix(f"{name}.{pj}.w").t())
             elif node.cls == "BasicTransformerBlock":
                 for k in ("attn1.qkv", "attn1.out", "attn2.q", "attn2.out", "ff1", "ff2"):
-                    self._put(f"{name}.{k}.wT", self.t[f"{name}.{k}.w"].t())
+                    self._put_gemm(f"{name}.{k}.wT", self.gemm_matrix(f"{name}.{k}.w").t())
         self._dgrad_ready = True
 
     def release_source(self):

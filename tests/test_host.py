@@ -71,6 +71,7 @@ class _FakeWeights:
                 self.temb_offsets[n] = off
                 off += m.out_dim
         self.temb_total = off
+        self.packed = True
 
     def ptr(self, name):
         return 0x1000
@@ -96,6 +97,7 @@ def test_planner_static_invariants(name, hw, method):
         assert all(spans[i][1] <= spans[i + 1][0] for i in range(len(spans) - 1))
         gemms = [d for o, d in ops if o == lib.OP_GEMM]
         assert all(d.K % 64 == 0 and d.N % 4 == 0 and d.ldc % 4 == 0 for d in gemms)
+        assert all(d.w_layout == 1 for d in gemms), "frozen weights are streamed tile-packed"
         if mode == "off":
             assert not any(d.lora_t or d.lora_down for d in gemms), "adapters off must not launch any LoRA work"
             assert not any(o == lib.OP_SKINNY for o, d in ops[:-1])
@@ -128,3 +130,23 @@ def test_checkpoint_file_is_reference_loadable(tmp_path):
     nw = LoRANetworkOracle(net, rank=4, multiplier=1.0, alpha=1.0, train_method="noxattn")
     nw.load_state_dict(sd, strict=True)
     assert list(nw.state_dict().keys()) == list(sd.keys())
+
+
+def test_gemm_weight_tile_packing_layout():
+    """pack_gemm_w must produce exactly the order include/sliders_hip.h documents for w_layout = 1 (the kernel
+    addresses it with plain pointer arithmetic), and unpack_gemm_w must invert it."""
+    import torch
+    from sliders_amd.weights import pack_gemm_w, unpack_gemm_w
+    n, k = 200, 320
+    w = torch.arange(n * k, dtype=torch.float32).reshape(n, k)
+    flat = pack_gemm_w(w)
+    npad = 256
+    assert flat.numel() == npad * k
+    g = torch.Generator().manual_seed(0)
+    for _ in range(200):
+        r = int(torch.randint(0, npad, (1,), generator=g))
+        c = int(torch.randint(0, k, (1,), generator=g))
+        rr, slot, e = r & 63, (c & 63) >> 3, c & 7
+        off = ((r >> 6) * (k // 64) + (c >> 6)) * 4096 + rr * 64 + ((slot ^ ((rr >> 1) & 7)) << 3) + e
+        assert flat[off].item() == (w[r, c].item() if r < n else 0.0)
+    assert torch.equal(unpack_gemm_w(flat, n, k), w)

@@ -40,7 +40,7 @@ def _pack_conv(w):
     return w.permute(0, 2, 3, 1).reshape(w.shape[0], -1).contiguous()
 
 
-@pytest.mark.parametrize("tile", [0x22, 0x21, 0x12, 0x11, 0x321, 0x312, 0x311, 0x4022, 0x4322, 0x4012, 0x4312])
+@pytest.mark.parametrize("tile", [0x22, 0x21, 0x12, 0x11, 0x321, 0x312, 0x311, 0x4022, 0x4322, 0x4012, 0x4312, 0x4011])
 @pytest.mark.parametrize("M,N,K", [(256, 128, 64), (300, 320, 320), (1024, 640, 1280), (154, 256, 2048)])
 def test_gemm_dense(dev, M, N, K, tile):
     torch.manual_seed(M + N + K)
@@ -55,6 +55,40 @@ def test_gemm_dense(dev, M, N, K, tile):
     torch.cuda.synchronize()
     ref = x.float() @ w.float().t() + bias.float() + res.float()
     report(f"gemm_dense M{M} N{N} K{K} tile{tile:x}", c, ref, TOL)
+
+
+@pytest.mark.parametrize("tile", [0x22, 0x21, 0x12, 0x11, 0x311, 0x4022, 0x4012, 0x4011, 0x4312])
+def test_gemm_packed_weights(dev, tile):
+    """w_layout = 1: the frozen weights in the tile-packed, pre-swizzled order (sliders_amd.weights.pack_gemm_w)."""
+    from sliders_amd.weights import pack_gemm_w
+    for M, N, K in ((300, 320, 320), (1024, 640, 1280), (154, 200, 2048), (70, 4, 64)):
+        torch.manual_seed(M + N + K)
+        x = bf(torch.randn(M, K, device=dev))
+        w = bf(torch.randn(N, K, device=dev) / math.sqrt(K))
+        bias = bf(torch.randn(N, device=dev))
+        c = torch.zeros(M, N, device=dev, dtype=torch.bfloat16)
+        wp = pack_gemm_w(w)
+        d = lib.GemmDesc(a0=p(x), w=p(wp), bias=p(bias), c=p(c), lda0=K, ca0=K, mode=0, stride=1, ldw=0, M=M, N=N, K=K,
+                         ldc=N, rows_per_sample=M, tile=tile, w_layout=1)
+        lib.call(lib.OP_GEMM, d, stream())
+        torch.cuda.synchronize()
+        report(f"gemm_packed M{M} N{N} K{K} tile{tile:x}", c, x.float() @ w.float().t() + bias.float(), TOL)
+    # 3x3 conv, stride 2, Cout not a multiple of 64
+    torch.manual_seed(5)
+    B, H, W, Ci, Co = 2, 12, 20, 128, 160
+    img = bf(torch.randn(B, Ci, H, W, device=dev))
+    w4 = bf(torch.randn(Co, Ci, 3, 3, device=dev) / math.sqrt(9 * Ci))
+    ref_img = _conv_ref(img.float(), w4.float(), 2)
+    Ho, Wo = ref_img.shape[2:]
+    M = B * Ho * Wo
+    c = torch.zeros(M, Co, device=dev, dtype=torch.bfloat16)
+    wp = pack_gemm_w(_pack_conv(w4))
+    d = lib.GemmDesc(a0=p(bf(_to_pix(img.float()))), w=p(wp), c=p(c), lda0=Ci, ca0=Ci, mode=1, batch=B, hs=H, ws=W,
+                     stride=2, ho=Ho, wo=Wo, ldw=0, M=M, N=Co, K=9 * Ci, ldc=Co, rows_per_sample=Ho * Wo, tile=tile,
+                     w_layout=1)
+    lib.call(lib.OP_GEMM, d, stream())
+    torch.cuda.synchronize()
+    report(f"conv_packed tile{tile:x}", c, _to_pix(ref_img), TOL)
 
 
 def test_gemm_two_source_rowbias_lora(dev):
@@ -129,7 +163,7 @@ def _perm_cols(g):
 
 
 @pytest.mark.parametrize("stride,xform", [(1, 0), (2, 0), (1, 1), (1, 2)])
-@pytest.mark.parametrize("tile", [0x22, 0x11, 0x312, 0x311, 0x4022, 0x4312])
+@pytest.mark.parametrize("tile", [0x22, 0x11, 0x312, 0x311, 0x4022, 0x4312, 0x4011])
 def test_gemm_conv3x3(dev, stride, xform, tile):
     torch.manual_seed(3 + stride + xform)
     B, H, W, Ci, Co = 2, 12, 20, 128, 192
@@ -440,7 +474,7 @@ def test_lora_wgrad(dev):
     report("wgrad_conv", out, 0.25 * wd.grad.permute(0, 2, 3, 1).reshape(4, -1), 1e-4)
 
 
-@pytest.mark.parametrize("tile", [0x22, 0x21, 0x12, 0x11, 0x311, 0x4022, 0x4322, 0x4012])
+@pytest.mark.parametrize("tile", [0x22, 0x21, 0x12, 0x11, 0x311, 0x4022, 0x4322, 0x4012, 0x4011])
 def test_gemm_fused_lora_down(dev, tile):
     """LoRAModule.forward fused into one launch: y = x W^T + b + s (x A^T) B^T, T = x A^T written for backward."""
     torch.manual_seed(31)
