@@ -22,7 +22,7 @@ __device__ __forceinline__ int lds_off(int row, int slot) {
 
 // NW waves per workgroup: 4 (128 queries) or 2 (64 queries, used when the grid would not fill the chip)
 template <int NW, int DT>
-__global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const slh_attn_desc p) {
+__global__ __launch_bounds__(64 * NW, DT == 1 ? (NW == 4 ? 4 : 3) : ((DT == 2 && NW == 4) ? 2 : 1)) void attn_fwd_kernel(const slh_attn_desc p) {
     __shared__ __attribute__((aligned(16))) char smem[4 * DT * 8192];
     char* sK = smem;                    // [2][DT][64 kv][128 B]
     char* sV = smem + 2 * DT * 8192;    // [2][DT][64 d ][128 B]
@@ -79,6 +79,7 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const slh_attn_desc p
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[dd][r] = 0.f;
     float m_run = -1e30f, l_run = 0.f;
+    const f32x16 kZero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     const float c = p.scale * 1.4426950408889634f;
     // permuted key row for the A operand of S^T (swap bits 2 and 3)
     const int prow = (lrow & 3) | (((lrow >> 3) & 1) << 2) | (((lrow >> 2) & 1) << 3) | (lrow & 16);
@@ -93,13 +94,13 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const slh_attn_desc p
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) s[kt][r] = 0.f;
-#pragma unroll
             for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
                 for (int ks = 0; ks < 4; ++ks) {
                     const bf16x8 kf = *(const bf16x8*)(cK + dt * 8192 + lds_off(kt * 32 + prow, ks * 2 + lhi));
-                    s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[dt * 4 + ks], s[kt], 0, 0, 0);
+                    // first product of the tile takes a literal-zero C operand instead of 16 zeroed registers
+                    if (dt == 0 && ks == 0) s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[0], kZero16, 0, 0, 0);
+                    else s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[dt * 4 + ks], s[kt], 0, 0, 0);
                 }
         }
         // s[kt][r] = S[q = lrow][kv = t*64 + kt*32 + 16*(r>>3) + 8*lhi + (r&7)]
@@ -119,24 +120,34 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const slh_attn_desc p
             for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kt][r]);
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
         const float m_new = fmaxf(m_run, mx);
-        const float alpha = exp2f((m_run - m_new) * c);
+        // raw v_exp_f32 (arguments <= 0; results below 2^-126 flush to 0, which is what a probability that small is
+        // worth) - the libm exp2f wraps every call in a denormal-range fixup that quadruples the VALU work here
+        const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
         const float mc = m_new * c;
         m_run = m_new;
-        float psum = 0.f;
+        f32x2 ps2 = {0.f, 0.f};
+        const f32x2 c2 = {c, c}, mc2 = {mc, mc};
         bf16x8 pb[2][2];
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float pv = exp2f(s[kt][r] * c - mc);
-                psum += pv;
-                pb[kt][r >> 3][r & 7] = (__bf16)pv;
+            for (int r = 0; r < 16; r += 2) {
+                const f32x2 sv = {s[kt][r], s[kt][r + 1]};
+                const f32x2 e = sv * c2 - mc2;
+                const f32x2 pv = {__builtin_amdgcn_exp2f(e[0]), __builtin_amdgcn_exp2f(e[1])};
+                ps2 += pv;
+                pb[kt][r >> 3][r & 7] = (__bf16)pv[0];
+                pb[kt][r >> 3][(r & 7) + 1] = (__bf16)pv[1];
             }
-        l_run = l_run * alpha + psum;
+        l_run = l_run * alpha + (ps2[0] + ps2[1]);
+        // the running maximum settles after the first tiles: rescale the accumulators only when some row of the
+        // wave actually moved (alpha == 1 exactly otherwise, so skipping is bit-identical)
+        if (__builtin_amdgcn_ballot_w64(alpha != 1.f) != 0) {
 #pragma unroll
-        for (int dd = 0; dd < 2 * DT; ++dd)
+            for (int dd = 0; dd < 2 * DT; ++dd)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) o[dd][r] *= alpha;
+                for (int r = 0; r < 16; ++r) o[dd][r] *= alpha;
+        }
 #pragma unroll
         for (int dd = 0; dd < 2 * DT; ++dd)
 #pragma unroll
