@@ -52,44 +52,68 @@ def gemm_flops(d):
 
 
 def measure_roofline(eng, plan):
-    """Replay every slh_gemm of one adapters-off UNet pass individually between HIP events on the stream the
-    kernels are launched on, grouped by kernel instantiation."""
+    """Time every slh_gemm launch of one LoRA-on UNet denoise pass IN SITU: the pass is replayed op by op in
+    program order on the launch stream with a HIP event pair around each GEMM, so every launch sees the cache
+    state it sees in the real pass (frozen weights cold in HBM, activations warm in L2/MALL).  Launches are
+    grouped by kernel instantiation under the name rocprofv3 prints; the instantiation with the largest share of
+    the pass is the roofline kernel.  achieved = sum of algorithmic FLOPs (2*M*N*K) / sum of event time."""
     from sliders_amd import lib
     stream = torch.cuda.current_stream()
     s = stream.cuda_stream
-    groups = {}
-    plan.prog.run(s)                      # make every input of every op valid
+
+    def launch(opcode, d):
+        if opcode in lib._ENTRY:
+            lib.call(opcode, d, s)
+        else:                                   # memset of the fp32 accumulator arena
+            one = lib.Program()
+            one.add(opcode, d)
+            one.run(s)
+
+    def name(d):     # template arguments <MI, NI, MODE, STAGES, LORA, WM> exactly as rocprofv3 prints them
+        v = lib.gemm_variant(d)
+        stages = 3 if ((d.tile >> 8) & 15) == 3 else 2
+        return (f"gemm_kernel<{(v >> 8) & 15}, {(v >> 4) & 15}, {v & 15}, {stages}, "
+                f"{'true' if d.lora_down else 'false'}, {v >> 12}>")
+
+    for _ in range(2):
+        plan.prog.run(s)                        # warm-up passes (also make every input of every op valid)
     torch.cuda.synchronize()
-    reps = 3
+    recs = []
     for opcode, d in plan.prog.ops:
-        if opcode != lib.OP_GEMM:
-            continue
-        var = lib.gemm_variant(d)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        lib.call(lib.OP_GEMM, d, s)      # warm
-        e0.record(stream)
-        for _ in range(reps):
-            lib.call(lib.OP_GEMM, d, s)
-        e1.record(stream)
-        e1.synchronize()
-        ms = e0.elapsed_time(e1) / reps
-        g = groups.setdefault(var, dict(ms=0.0, flops=0.0, calls=0))
-        g["ms"] += ms
+        if opcode == lib.OP_GEMM:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(stream)
+            launch(opcode, d)
+            e1.record(stream)
+            recs.append((d, e0, e1))
+        else:
+            launch(opcode, d)
+    torch.cuda.synchronize()
+    groups = {}
+    for d, e0, e1 in recs:
+        g = groups.setdefault(name(d), dict(ms=0.0, flops=0.0, calls=0))
+        g["ms"] += e0.elapsed_time(e1)
         g["flops"] += gemm_flops(d)
         g["calls"] += 1
-    var, g = max(groups.items(), key=lambda kv: kv[1]["ms"])
-    def name(v):   # template arguments <MI, NI, MODE, ..., WM> of the instantiation (WM*2 waves per workgroup)
-        return f"gemm_kernel<MI={(v >> 8) & 15},NI={(v >> 4) & 15},MODE={v & 15},WM={v >> 12}>"
+    kname, g = max(groups.items(), key=lambda kv: kv[1]["ms"])
     achieved = g["flops"] / (g["ms"] * 1e-3) / 1e12
-    table = {name(v): dict(
-        calls_per_pass=x["calls"], ms_per_pass=round(x["ms"], 3), tflops=round(x["flops"] / (x["ms"] * 1e-3) / 1e12, 1))
-        for v, x in sorted(groups.items())}
+    table = {k: dict(calls_per_pass=x["calls"], ms_per_pass=round(x["ms"], 3),
+                     tflops=round(x["flops"] / (x["ms"] * 1e-3) / 1e12, 1)) for k, x in sorted(groups.items())}
+    traffic, tsrc = None, None
+    tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")
+    if os.path.exists(tpath):                   # PMC counters cannot be read from inside the timed process: the
+        with open(tpath) as f:                  # per-launch HBM-side bytes come from the committed rocprofv3 --pmc passes
+            pm = json.load(f)["kernels"].get(kname.replace(", ", "; "))
+        if pm:
+            traffic = pm["fetch_bytes_per_launch"] + pm["write_bytes_per_launch"]
+            tsrc = "profiles/r01_pmc_traffic.json (FETCH_SIZE x2 + WRITE_SIZE per launch, LoRA-on forward pass)"
     return {
-        "bound": "mfma", "kernel": name(var),
+        "bound": "mfma", "kernel": kname,
         "achieved": round(achieved, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-        "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": None,
+        "frac": round(achieved / MFMA_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_source": tsrc,
         "flop_per_launch": g["flops"] / g["calls"], "avg_launch_us": round(1e3 * g["ms"] / g["calls"], 2),
-        "launches_per_unet_pass": g["calls"], "all_gemm_variants": table,
+        "launches_per_unet_pass": g["calls"], "timing": "in situ, HIP events on the launch stream, one LoRA-on pass",
+        "all_gemm_variants": table,
     }
 
 
@@ -107,6 +131,29 @@ def _mem_limit_gb():
         return 64.0
 
 
+def _usable_cpus():
+    """Cores this process may actually run on: affinity mask clipped by the cgroup CPU quota (the GPU boxes expose 256
+    hardware threads but grant 16 CPUs of quota; 256 OpenMP threads on that quota run ~500x slower than 16)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, q // per))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
+class _Deadline(Exception):
+    pass
+
+
 def cpu_baseline(model, hw):
     """UNet denoise steps on the host cores with the CPU oracle (PyTorch restatement of the reference's
     diffusers UNet).  Bounded to ~10-30 s of CPU work: the dtype (bf16 / fp32) is chosen with a GEMM
@@ -119,7 +166,8 @@ def cpu_baseline(model, hw):
     def log(msg):
         print(f"[cpu_baseline] {msg}", file=sys.stderr, flush=True)
 
-    torch.set_num_threads(os.cpu_count())
+    ncpu = _usable_cpus()
+    torch.set_num_threads(ncpu)
     cfg = CONFIGS[model]()
     a32, b32 = torch.randn(2048, 1280), torch.randn(1280, 1280)
     tm = {}
@@ -166,21 +214,39 @@ def cpu_baseline(model, hw):
         return dt
 
     # ladder 64px -> 128px -> ... : go one size up only while 4x the last step (area scaling) fits what is left of
-    # the ~30 s budget, so a slow host can never stretch the default bench run by minutes
+    # the ~30 s budget; a hard SIGALRM deadline bounds the whole measurement whatever the host does
+    import signal
+
+    def _alarm(signum, frame):
+        raise _Deadline()
+
     budget, spent = 30.0, 0.0
-    use_hw = min(8, hw)
-    dt = run(use_hw)
-    spent += dt
-    log(f"step at {use_hw * 8}px: {dt:.1f}s")
-    while use_hw < hw and 4.0 * dt <= budget - spent:
-        use_hw *= 2
-        dt = run(use_hw)
-        spent += dt
-        log(f"step at {use_hw * 8}px: {dt:.1f}s")
+    use_hw, dt = None, None
+    old = signal.signal(signal.SIGALRM, _alarm)
+    signal.alarm(90)
+    try:
+        h = min(8, hw)
+        run(h)                      # untimed: oneDNN primitive creation, first-touch of the weights
+        while True:
+            d = run(h)
+            spent += d
+            use_hw, dt = h, d
+            log(f"step at {h * 8}px: {d:.2f}s")
+            if h >= hw or 4.0 * d > budget - spent:
+                break
+            h *= 2
+    except _Deadline:
+        log("deadline hit, keeping the largest size that completed")
+    finally:
+        signal.alarm(0)
+        signal.signal(signal.SIGALRM, old)
+    if use_hw is None:
+        return {"value": None, "unit": "steps/s", "cores": ncpu, "kind": "port",
+                "sample": "CPU oracle did not finish one 64x64 step within the 90 s deadline on this host"}
     scale = (hw / use_hw) ** 2
     note = "" if use_hw == hw else (f"; timed at {use_hw * 8}x{use_hw * 8} ({dt:.1f} s) and EXTRAPOLATED x{scale:.0f} by "
                                     f"latent area to {hw * 8}x{hw * 8} (optimistic for the CPU: self-attention grows faster than area)")
-    return {"value": round(1.0 / (dt * scale), 5), "unit": "steps/s", "cores": os.cpu_count(), "kind": "port",
+    return {"value": round(1.0 / (dt * scale), 5), "unit": "steps/s", "cores": ncpu, "kind": "port",
             "sample": f"1 UNet denoise step (CFG pair B=2, {model}, {'fp32' if dtype == torch.float32 else 'bf16'} "
                       f"torch/oneDNN forward, {dt:.1f} s) with the CPU oracle = PyTorch restatement of the diffusers "
                       f"UNet{note}"}
@@ -266,10 +332,10 @@ def main():
     }
     if rank == 0:
         print("[bench] timed region done: " + json.dumps({k: res[k] for k in ("value", "ms_per_step")}), file=sys.stderr, flush=True)
+    if rank == 0 and not a.no_roofline:
+        eng.set_lora(True, 1.0)
+        res["roofline"] = measure_roofline(eng, eng.plan(2, hw, hw, "on"))
     if rank == 0 and world == 1:
-        if not a.no_roofline:
-            eng.set_lora(False)
-            res["roofline"] = measure_roofline(eng, eng.plan(2, hw, hw, "off"))
         if not a.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(a.model, hw)
     if rank == 0:

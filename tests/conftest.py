@@ -18,3 +18,19 @@ def dev():
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _cpu_threads():
+    """The CPU oracle runs on torch's OpenMP pool: size it to the cgroup CPU quota, not to the hardware thread count
+    (the GPU boxes show 256 threads but grant 16 CPUs; oversubscribed pools run orders of magnitude slower)."""
+    import torch
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    torch.set_num_threads(max(1, n))
+    yield
