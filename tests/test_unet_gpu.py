@@ -69,6 +69,26 @@ def test_unet_forward_parity_no_lora(dev, name, hw):
         check(f"unet {name} hw{hw} t{t} lora-off", got, e32, ebf)
 
 
+@pytest.mark.parametrize("name,B,h,w", [("tiny_sdxl", 4, 24, 16), ("tiny_sd1", 1, 16, 32), ("tiny_sdxl", 3, 12, 20)])
+def test_unet_forward_rectangular_and_odd_batches(dev, name, B, h, w):
+    """Shapes the reference reaches through `dynamic_resolution` / `batch_size` (prompt_util.py:44-68): non-square
+    latents, a single sample, the B=3 frozen-prediction batch, pixel counts that are not multiples of the GEMM tile."""
+    cfg = CONFIGS[name]()
+    net = build_unet(name, seed=0)
+    eng = UNetEngine(cfg, net.state_dict(), dev)
+    g = torch.Generator().manual_seed(77)
+    x = torch.randn(B, 4, h, w, generator=g)
+    ctx = torch.randn(B, 77, cfg.cross_attention_dim, generator=g)
+    kw = None
+    if cfg.addition_embed_type:
+        kw = {"text_embeds": torch.randn(B, cfg.pooled_dim, generator=g),
+              "time_ids": torch.tensor([[h * 8.0, w * 8.0, 0, 0, h * 8.0, w * 8.0]] * B)}
+    e32 = run_oracle(net, x, 321, ctx, kw, torch.float32)
+    ebf = run_oracle(build_unet(name, seed=0), x, 321, ctx, kw, torch.bfloat16)
+    got = run_engine(eng, x, 321, ctx, kw, dev)
+    check(f"unet {name} B{B} {h}x{w}", got, e32, ebf)
+
+
 @pytest.mark.parametrize("name,method", [("tiny_sdxl", "noxattn"), ("tiny_sdxl", "full"), ("tiny_sd1", "noxattn"),
                                          ("tiny_sdxl", "xattn")])
 def test_unet_forward_parity_with_lora(dev, name, method):
