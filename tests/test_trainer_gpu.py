@@ -26,27 +26,29 @@ def _setup(dev, name="tiny_sdxl", seed=5):
     for e in store.entries:
         store.params[e.up_off:e.up_off + e.up_numel] = (torch.randn(e.up_numel, generator=g) * 0.03).to(dev, torch.bfloat16)
     emb = {k: torch.randn(1, 77, cfg.cross_attention_dim, generator=g) for k in ("target", "positive", "neutral", "uncond")}
-    pool = {k: torch.randn(1, cfg.pooled_dim, generator=g) for k in emb}
+    pool = {k: (torch.randn(1, cfg.pooled_dim, generator=g) if cfg.is_xl else None) for k in emb}
     noise = torch.randn(1, 4, 16, 16, generator=g)
     return cfg, store, emb, pool, noise
 
 
-def _pair(emb, pool, dev):
+def _pair(emb, pool, dev, action="enhance"):
     cat = lambda x: torch.cat([emb["uncond"], x]).to(dev, torch.bfloat16).contiguous()
-    pc = lambda x: torch.cat([pool["uncond"], x]).to(dev, torch.bfloat16).contiguous()
+    pc = lambda x: None if x is None else torch.cat([pool["uncond"], x]).to(dev, torch.bfloat16).contiguous()
     return PairEmbeds(cat(emb["target"]), cat(emb["positive"]), cat(emb["neutral"]), cat(emb["uncond"]),
                       pc(pool["target"]), pc(pool["positive"]), pc(pool["neutral"]), pc(pool["uncond"]),
-                      guidance_scale=4.0, action="enhance")
+                      guidance_scale=4.0, action=action)
 
 
-def test_iteration_matches_reference_loop_on_oracle(dev):
-    name, k, hw = "tiny_sdxl", 3, 16
-    cfg, store, emb, pool, noise = _setup(dev)
+@pytest.mark.parametrize("name,action", [("tiny_sdxl", "enhance"), ("tiny_sd1", "erase")])
+def test_iteration_matches_reference_loop_on_oracle(dev, name, action):
+    """SDXL loop (train_lora_xl.py) with an `enhance` pair and SD-1.x loop (train_lora.py) with an `erase` pair."""
+    k, hw = 3, 16
+    cfg, store, emb, pool, noise = _setup(dev, name)
     sd = store.state_dict()
     params0 = store.params.clone()
     eng = UNetEngine(cfg, build_unet(name, seed=0).state_dict(), dev)
     tr = SliderTrainer(eng, store, hw, hw, lr=2e-4)
-    loss = tr.iteration(_pair(emb, pool, dev), k, noise.to(dev))
+    loss = tr.iteration(_pair(emb, pool, dev, action), k, noise.to(dev))
     torch.cuda.synchronize()
     assert tr.unet_passes == k + 4
     # ---- the reference loop on the oracle (fp32) ----
@@ -60,7 +62,7 @@ def test_iteration_matches_reference_loop_on_oracle(dev):
 
     def predict(x, which, t, g):
         ctx = torch.cat([emb["uncond"], emb[which]])
-        kw = {"text_embeds": torch.cat([pool["uncond"], pool[which]]), "time_ids": tid}
+        kw = {"text_embeds": torch.cat([pool["uncond"], pool[which]]), "time_ids": tid} if cfg.is_xl else None
         e = net(torch.cat([x] * 2), t, ctx, kw).sample
         u, c = e.chunk(2)
         return u + g * (c - u)
@@ -76,7 +78,8 @@ def test_iteration_matches_reference_loop_on_oracle(dev):
         pos, neu, unc = (predict(x, w, t_cur, 1) for w in ("positive", "neutral", "uncond"))
     with nw:
         tgt = predict(x, "target", t_cur, 1)
-    ref_loss = F.mse_loss(tgt, neu + 4.0 * (pos - unc))
+    sign = 1.0 if action == "enhance" else -1.0          # prompt_util.py:116-135
+    ref_loss = F.mse_loss(tgt, neu + sign * 4.0 * (pos - unc))
     ref_loss.backward()
     flat = torch.zeros(store.numel)
     mods = {m.lora_name: m for m in nw.unet_loras}
