@@ -78,7 +78,8 @@ typedef struct slh_gemm_desc {
                                 streams them: [ceil(N/64)][K/64] blocks of 64 rows x 64 k (8 KB contiguous, rows past N
                                 zero), 16-byte slot s of row r stored at slot s ^ ((r>>1)&7) (the LDS swizzle applied
                                 in memory, so every LDS-DMA instruction reads 1 KB of consecutive addresses); ldw unused */
-    int32_t reserved_;
+    int32_t reserved_;       /* 0.  Non-zero values are profiling ablations (scripts/probe_gemm.py): 1 skip tile refills,
+                                2 skip MFMA work, 4 skip the epilogue, 8 skip the first fill, 16 return at once */
 } slh_gemm_desc;
 int slh_gemm(const slh_gemm_desc* d, slh_stream_t stream);
 /* (WM<<12)|(MI<<8)|(NI<<4)|mode of the kernel instantiation gemm_kernel<MI,NI,mode,..,WM> slh_gemm would launch for d

@@ -35,7 +35,8 @@ struct GemmArgs {
     int lora_rank, lora_up_rmajor, w_packed;
     int tiles_m, tiles_n, group_m;
     int store16;  // c and ldc allow 16-byte row stores
-    int probe;   // diagnostics (slh_gemm_desc.reserved_): 1 skip tile refills, 2 skip MFMA work, 4 skip the epilogue
+    int probe;   // diagnostics (slh_gemm_desc.reserved_): 1 skip tile refills, 2 skip MFMA work, 4 skip the epilogue,
+                 // 8 skip the first tile fill, 16 return at once
 };
 
 constexpr int BK = 64;
@@ -74,6 +75,7 @@ __global__ __launch_bounds__(128 * WM, gemm_waves_per_simd(MI, NI, STAGES, LORA,
     char* sW = smem + STAGES * BM * 128;    // [STAGES][BN][128 B]
     char* sL = smem + STAGES * (BM + BN) * 128;   // [STAGES][32][128 B]
 
+    if (p.probe & 16) return;   // diagnostics: launch + dispatch cost only
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -238,7 +240,7 @@ __global__ __launch_bounds__(128 * WM, gemm_waves_per_simd(MI, NI, STAGES, LORA,
     };
 
     if constexpr (STAGES == 2) {
-        stage(0, 0);
+        if (!(p.probe & 8)) stage(0, 0);
         for (int kt = 0; kt < nk; ++kt) {
             __syncthreads();  // drains this wave's glds (vmcnt(0)) and orders all waves
             if (kt + 1 < nk && !(p.probe & 1)) stage((kt + 1) & 1, kt + 1);
