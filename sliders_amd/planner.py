@@ -201,6 +201,8 @@ class UNetPlan:
         if conv is not None:
             self._conv_fields(d, x0, conv, Ho, Wo)
         d.tile = tuned_tile(d)
+        if not d.tile and M <= 192 and N >= 4096:
+            d.tile = 0x12        # few rows, very wide: 64-row tiles waste the least of the short M
         self.prog.add(lib.OP_GEMM, d, name)
         if self.train:
             self.tape.append(dict(op="gemm", x=x, out=out, wname=wname, N=N, K=K, conv=conv, grp=grp, T=T,
@@ -347,7 +349,10 @@ class UNetPlan:
         h1 = self.gemm(o1, a1 + ".out", C, a1 + ".out", residual=h, lora_paths=[a1 + ".to_out.0"])
         n2 = self.layernorm(h1, path + ".norm2", path + ".norm2")
         q2 = self.gemm(n2, a2 + ".q", C, a2 + ".q", bias=False, lora_paths=[a2 + ".to_q"])
-        kv = self.gemm(ctx, a2 + ".kv", 2 * C, a2 + ".kv", bias=False, lora_paths=[a2 + ".to_k", a2 + ".to_v"])
+        if self.kv_all is not None:
+            kv = self.kv_all.cols(self.w.kv_all_offset[a2], 2 * C)
+        else:
+            kv = self.gemm(ctx, a2 + ".kv", 2 * C, a2 + ".kv", bias=False, lora_paths=[a2 + ".to_k", a2 + ".to_v"])
         if self._lora_group([a2 + ".to_k", a2 + ".to_v"]) is None:
             self.nograd_kv.add(kv.buf.ptr)      # text K/V carry no gradient unless they are adapted
         o2 = self.attention(q2, kv.cols(0, C), kv.cols(C, C), self.ctx_len, heads, a2 + ".sdpa")
@@ -379,6 +384,13 @@ class UNetPlan:
         self._embeddings()
         ctxb = self.io["ctx"]
         self.ctx = Act(ctxb.ptr, B, 1, self.ctx_len, cfg.cross_attention_dim, cfg.cross_attention_dim, ctxb, "ctx")
+        # every transformer block projects the same text embeddings to K/V: when those projections carry no adapter
+        # (and no tape is needed) they run as ONE GEMM over the concatenated weights at the head of the pass
+        self.kv_all = None
+        kvo = getattr(self.w, "kv_all_offset", None)
+        if kvo and not self.train and all(self._lora_group([a + ".to_k", a + ".to_v"]) is None for a in kvo):
+            n_all = self.w.gemm_shape["attn2_kv_all.w"][0]
+            self.kv_all = self.gemm(self.ctx, "attn2_kv_all", n_all, "attn2_kv_all", bias=False)
         h = self.act(B, H, W, boc[0], "conv_in")
         self.nograd = {ctxb.ptr, h.buf.ptr}     # nothing trainable upstream of these
         self.nograd_kv = set()

@@ -220,6 +220,8 @@ class _VirtualWeights:
         self.temb_total = w.temb_total
         self.resnet_paths = w.resnet_paths
         self.packed = w.packed
+        self.kv_all_offset = w.kv_all_offset
+        self.gemm_shape = w.gemm_shape
 
     def ptr(self, name):
         return 0x1000

@@ -171,6 +171,18 @@ class WeightStore:
                 self._put(f"{name}.ff1.b", _geglu_perm(sd[f"{name}.ff.net.0.proj.bias"]))
                 self._put_gemm(f"{name}.ff2.w", sd[f"{name}.ff.net.2.weight"])
                 self._put(f"{name}.ff2.b", sd[f"{name}.ff.net.2.bias"])
+        # all cross-attention K/V projections read the SAME text embeddings: one [sum(2C)][Dctx] matrix lets a UNet
+        # pass compute them in one full-chip launch instead of one 120-workgroup launch per transformer block
+        # (tile-packed blocks are row-block major, so the packed matrices simply concatenate)
+        self.kv_all_offset: Dict[str, int] = {}
+        kv_names = [n for n in self.t if n.endswith(".attn2.kv.w")]
+        if kv_names and self.packed and all(self.gemm_shape[n][0] % 64 == 0 for n in kv_names):
+            row = 0
+            for n in kv_names:
+                self.kv_all_offset[n[:-len(".kv.w")]] = row
+                row += self.gemm_shape[n][0]
+            self.t["attn2_kv_all.w"] = torch.cat([self.t[n] for n in kv_names])
+            self.gemm_shape["attn2_kv_all.w"] = (row, self.gemm_shape[kv_names[0]][1])
         self.temb_total = off
         self._put("temb_proj.w", torch.cat(temb_w, 0))
         self._put("temb_proj.b", torch.cat(temb_b, 0))

@@ -72,6 +72,8 @@ class _FakeWeights:
                 off += m.out_dim
         self.temb_total = off
         self.packed = True
+        self.kv_all_offset = {}
+        self.gemm_shape = {}
 
     def ptr(self, name):
         return 0x1000
