@@ -196,6 +196,9 @@ typedef struct slh_attn_desc {
     float scale;
     int32_t D;               /* head dim: 0/64 (SDXL) or 40 / 80 / 160 (SD-1.x); head h = columns [h*D, (h+1)*D);
                                 VT is [B][H][64*ceil(D/64)][ldvt] with zero rows for d >= D */
+    int32_t vt_batch_heads;  /* 0 = H.  Otherwise vt points into a wider [B][vt_batch_heads][..][ldvt] array (one transposed
+                                V for the cross-attention of every transformer block) at this layer's first head */
+    int32_t reserved_;
 } slh_attn_desc;
 int slh_attn_fwd(const slh_attn_desc* d, slh_stream_t stream);
 

@@ -33,6 +33,7 @@ __global__ __launch_bounds__(64 * NW, DT == 1 ? (NW == 4 ? 4 : 3) : ((DT == 2 &&
     const int h = blockIdx.y, b = blockIdx.z;
     const int q0 = blockIdx.x * (32 * NW) + wave * 32;
     const int D = p.D > 0 ? p.D : 64;
+    const int vt_heads = p.vt_batch_heads > 0 ? p.vt_batch_heads : p.H;
 
     const __bf16* Q = (const __bf16*)p.q;
     const __bf16* K = (const __bf16*)p.k;
@@ -67,7 +68,7 @@ __global__ __launch_bounds__(64 * NW, DT == 1 ? (NW == 4 ? 4 : 3) : ((DT == 2 &&
                 const __bf16* ksrc = col < D ? K + ((long)b * p.Tk + kv) * p.ldk + h * D + col
                                              : (const __bf16*)slh_zero_page;
                 glds16(ksrc, sK + (buf * DT + dt) * 8192 + (wave + NW * i) * 1024);
-                glds16(VT + (((long)b * p.H + h) * (64 * DT) + dt * 64 + row) * p.ldvt + t * 64 + ks * 8,
+                glds16(VT + (((long)b * vt_heads + h) * (64 * DT) + dt * 64 + row) * p.ldvt + t * 64 + ks * 8,
                        sV + (buf * DT + dt) * 8192 + (wave + NW * i) * 1024);
             }
         }

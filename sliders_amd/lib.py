@@ -50,7 +50,8 @@ LnDesc = _struct("LnDesc", _ptrs("x", "gamma", "beta", "y", "mean_rstd") + _ints
 LnBwdDesc = _struct("LnBwdDesc", _ptrs("x", "gamma", "dy", "mean_rstd", "dx")
                     + _ints("M", "C", "ldx", "lddy", "lddx", "accumulate"))
 AttnDesc = _struct("AttnDesc", _ptrs("q", "k", "vt", "o", "lse")
-                   + _ints("B", "H", "Tq", "Tk", "ldq", "ldk", "ldvt", "ldo") + [("scale", c_f32)] + _ints("D"))
+                   + _ints("B", "H", "Tq", "Tk", "ldq", "ldk", "ldvt", "ldo") + [("scale", c_f32)]
+                   + _ints("D", "vt_batch_heads", "reserved_"))
 TransposeDesc = _struct("TransposeDesc", _ptrs("src", "dst") + _ints("B", "H", "T", "ld", "ldt", "D"))
 AttnBwdDesc = _struct("AttnBwdDesc", _ptrs("q", "k", "v", "o", "d_o", "kt", "qt", "dot", "lse", "delta", "dq", "dk", "dv")
                       + _ints("B", "H", "Tq", "Tk", "ldq", "ldk", "ldv", "ldo", "lddo", "ldkt", "ldqt", "lddq", "lddk",

@@ -235,20 +235,25 @@ class UNetPlan:
             self.tape.append(dict(op="ln", x=x, out=y, wname=wname, mr=mr, name=name))
         return y
 
-    def attention(self, q: Act, k: Act, v: Act, Tk: int, heads: int, name: str) -> Act:
-        """q [B*Tq][C] view, k/v [B*Tk][C] views (any ld); returns [B*Tq][C]."""
+    def attention(self, q: Act, k: Act, v: Act, Tk: int, heads: int, name: str, vt_pre=None) -> Act:
+        """q [B*Tq][C] view, k/v [B*Tk][C] views (any ld); returns [B*Tq][C].  vt_pre = (pointer to this layer's first
+        head inside an already transposed [B][heads_total][Dp][ldt] array, heads_total)."""
         B, Tq, C = q.B, q.HW, q.C
         D = C // heads
         assert D * heads == C and D % 8 == 0 and D <= 192, f"unsupported head_dim {D}"
         Dp = (D + 63) // 64 * 64
         ldt = (Tk + 63) // 64 * 64
-        vt = self.arena.alloc((B, heads, Dp, ldt), torch.bfloat16, name + ".vt")
-        self.prog.add(lib.OP_TRANSPOSE_HEADS, lib.TransposeDesc(src=v.ptr, dst=vt.ptr, B=B, H=heads, T=Tk, ld=v.ld, ldt=ldt,
-                                                                D=D), name + ".vt")
+        if vt_pre is None:
+            vt = self.arena.alloc((B, heads, Dp, ldt), torch.bfloat16, name + ".vt")
+            self.prog.add(lib.OP_TRANSPOSE_HEADS, lib.TransposeDesc(src=v.ptr, dst=vt.ptr, B=B, H=heads, T=Tk, ld=v.ld,
+                                                                    ldt=ldt, D=D), name + ".vt")
+            vt_ptr, vt_heads = vt.ptr, 0
+        else:
+            vt_ptr, vt_heads = vt_pre
         o = self.act(q.B, q.H, q.W, C, name)
         lse = self.f32((B * heads * Tq + 64,), name + ".lse") if self.train else None   # padded: bwd reads by 64s
-        d = lib.AttnDesc(q=q.ptr, k=k.ptr, vt=vt.ptr, o=o.ptr, lse=lse.ptr if lse else 0, B=B, H=heads, Tq=Tq, Tk=Tk,
-                         ldq=q.ld, ldk=k.ld, ldvt=ldt, ldo=o.ld, scale=D ** -0.5, D=D)
+        d = lib.AttnDesc(q=q.ptr, k=k.ptr, vt=vt_ptr, o=o.ptr, lse=lse.ptr if lse else 0, B=B, H=heads, Tq=Tq, Tk=Tk,
+                         ldq=q.ld, ldk=k.ld, ldvt=ldt, ldo=o.ld, scale=D ** -0.5, D=D, vt_batch_heads=vt_heads)
         self.prog.add(lib.OP_ATTN_FWD, d, name)
         if self.train:
             self.tape.append(dict(op="attn", q=q, k=k, v=v, o=o, lse=lse, Tk=Tk, heads=heads, name=name))
@@ -349,13 +354,20 @@ class UNetPlan:
         h1 = self.gemm(o1, a1 + ".out", C, a1 + ".out", residual=h, lora_paths=[a1 + ".to_out.0"])
         n2 = self.layernorm(h1, path + ".norm2", path + ".norm2")
         q2 = self.gemm(n2, a2 + ".q", C, a2 + ".q", bias=False, lora_paths=[a2 + ".to_q"])
+        vt_pre = None
         if self.kv_all is not None:
-            kv = self.kv_all.cols(self.w.kv_all_offset[a2], 2 * C)
+            k_off, v_off = self.w.kv_all_offset[a2]
+            k2, v2, kv = self.kv_all.cols(k_off, C), self.kv_all.cols(v_off, C), self.kv_all
+            if self.vt_all is not None:
+                D = C // heads
+                Dp, ldt = (D + 63) // 64 * 64, (self.ctx_len + 63) // 64 * 64
+                vt_pre = (self.vt_all.ptr + 2 * ((v_off - self.w.kv_all_vbase) // D) * Dp * ldt, self.vt_all_heads)
         else:
             kv = self.gemm(ctx, a2 + ".kv", 2 * C, a2 + ".kv", bias=False, lora_paths=[a2 + ".to_k", a2 + ".to_v"])
+            k2, v2 = kv.cols(0, C), kv.cols(C, C)
         if self._lora_group([a2 + ".to_k", a2 + ".to_v"]) is None:
             self.nograd_kv.add(kv.buf.ptr)      # text K/V carry no gradient unless they are adapted
-        o2 = self.attention(q2, kv.cols(0, C), kv.cols(C, C), self.ctx_len, heads, a2 + ".sdpa")
+        o2 = self.attention(q2, k2, v2, self.ctx_len, heads, a2 + ".sdpa", vt_pre=vt_pre)
         h2 = self.gemm(o2, a2 + ".out", C, a2 + ".out", residual=h1, lora_paths=[a2 + ".to_out.0"])
         n3 = self.layernorm(h2, path + ".norm3", path + ".norm3")
         if self.train:
@@ -386,11 +398,24 @@ class UNetPlan:
         self.ctx = Act(ctxb.ptr, B, 1, self.ctx_len, cfg.cross_attention_dim, cfg.cross_attention_dim, ctxb, "ctx")
         # every transformer block projects the same text embeddings to K/V: when those projections carry no adapter
         # (and no tape is needed) they run as ONE GEMM over the concatenated weights at the head of the pass
-        self.kv_all = None
+        self.kv_all = self.vt_all = None
         kvo = getattr(self.w, "kv_all_offset", None)
         if kvo and not self.train and all(self._lora_group([a + ".to_k", a + ".to_v"]) is None for a in kvo):
             n_all = self.w.gemm_shape["attn2_kv_all.w"][0]
             self.kv_all = self.gemm(self.ctx, "attn2_kv_all", n_all, "attn2_kv_all", bias=False)
+            # one head dim everywhere (SDXL: 64) -> the V halves of all blocks are one [B*77][sum(C)] matrix whose
+            # heads transpose in ONE launch; each block's attention then points at its own heads of that array
+            dims = {boc[i] // cfg.attention_head_dim[i] for i, t in enumerate(cfg.down_block_types) if t != "DownBlock2D"}
+            dims.add(boc[-1] // cfg.attention_head_dim[-1])
+            if len(dims) == 1:
+                D = dims.pop()
+                vb = self.w.kv_all_vbase
+                self.vt_all_heads = vb // D
+                Dp, ldt = (D + 63) // 64 * 64, (self.ctx_len + 63) // 64 * 64
+                self.vt_all = self.arena.alloc((B, self.vt_all_heads, Dp, ldt), torch.bfloat16, "attn2_vt_all")
+                self.prog.add(lib.OP_TRANSPOSE_HEADS, lib.TransposeDesc(
+                    src=self.kv_all.ptr + 2 * vb, dst=self.vt_all.ptr, B=B, H=self.vt_all_heads, T=self.ctx_len,
+                    ld=self.kv_all.ld, ldt=ldt, D=D), "attn2_vt_all")
         h = self.act(B, H, W, boc[0], "conv_in")
         self.nograd = {ctxb.ptr, h.buf.ptr}     # nothing trainable upstream of these
         self.nograd_kv = set()

@@ -221,6 +221,7 @@ class _VirtualWeights:
         self.resnet_paths = w.resnet_paths
         self.packed = w.packed
         self.kv_all_offset = w.kv_all_offset
+        self.kv_all_vbase = w.kv_all_vbase
         self.gemm_shape = w.gemm_shape
 
     def ptr(self, name):

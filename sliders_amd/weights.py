@@ -171,18 +171,26 @@ class WeightStore:
                 self._put(f"{name}.ff1.b", _geglu_perm(sd[f"{name}.ff.net.0.proj.bias"]))
                 self._put_gemm(f"{name}.ff2.w", sd[f"{name}.ff.net.2.weight"])
                 self._put(f"{name}.ff2.b", sd[f"{name}.ff.net.2.bias"])
-        # all cross-attention K/V projections read the SAME text embeddings: one [sum(2C)][Dctx] matrix lets a UNet
-        # pass compute them in one full-chip launch instead of one 120-workgroup launch per transformer block
-        # (tile-packed blocks are row-block major, so the packed matrices simply concatenate)
-        self.kv_all_offset: Dict[str, int] = {}
+        # all cross-attention K/V projections read the SAME text embeddings: one [sum(C) K rows | sum(C) V rows][Dctx]
+        # matrix lets a UNet pass compute them in one full-chip launch instead of one 120-workgroup launch per
+        # transformer block, and transposes every V with one more (tile-packed blocks are row-block major, so packed
+        # sub-matrices simply concatenate)
+        self.kv_all_offset: Dict[str, Tuple[int, int]] = {}      # attn2 path -> (first K column, first V column)
+        self.kv_all_vbase = 0
         kv_names = [n for n in self.t if n.endswith(".attn2.kv.w")]
-        if kv_names and self.packed and all(self.gemm_shape[n][0] % 64 == 0 for n in kv_names):
-            row = 0
-            for n in kv_names:
-                self.kv_all_offset[n[:-len(".kv.w")]] = row
-                row += self.gemm_shape[n][0]
-            self.t["attn2_kv_all.w"] = torch.cat([self.t[n] for n in kv_names])
-            self.gemm_shape["attn2_kv_all.w"] = (row, self.gemm_shape[kv_names[0]][1])
+        if kv_names and self.packed and all(self.gemm_shape[n][0] % 128 == 0 for n in kv_names):
+            kdim = self.gemm_shape[kv_names[0]][1]
+            halves = [self.gemm_shape[n][0] // 2 for n in kv_names]
+            self.kv_all_vbase = sum(halves)
+            kparts, vparts, row = [], [], 0
+            for n, c in zip(kv_names, halves):
+                flat = self.t[n]
+                kparts.append(flat[: c * kdim])
+                vparts.append(flat[c * kdim:])
+                self.kv_all_offset[n[:-len(".kv.w")]] = (row, self.kv_all_vbase + row)
+                row += c
+            self.t["attn2_kv_all.w"] = torch.cat(kparts + vparts)
+            self.gemm_shape["attn2_kv_all.w"] = (2 * self.kv_all_vbase, kdim)
         self.temb_total = off
         self._put("temb_proj.w", torch.cat(temb_w, 0))
         self._put("temb_proj.b", torch.cat(temb_b, 0))

@@ -73,6 +73,7 @@ class _FakeWeights:
         self.temb_total = off
         self.packed = True
         self.kv_all_offset = {}
+        self.kv_all_vbase = 0
         self.gemm_shape = {}
 
     def ptr(self, name):
