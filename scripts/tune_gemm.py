@@ -44,8 +44,10 @@ eng(x, torch.tensor(500), ctx, kw, mode="train")
 eng.run_backward(d_eps=torch.randn(1, 4, hw, hw, device=dev) * 1e-3)
 torch.cuda.synchronize()
 
+eng(x, torch.tensor(500), ctx, kw, mode="on")      # the no-grad pass has its own shapes: fused GEGLU, batched text K/V
+p_on = eng.plan(2, hw, hw, "on")
 shapes = {}
-for prog in ((p.prog,) if args.fwd_only else (p.prog, p.backward.prog)):
+for prog in ((p.prog, p_on.prog) if args.fwd_only else (p.prog, p_on.prog, p.backward.prog)):
     for opcode, d in prog.ops:
         if opcode == lib.OP_GEMM:
             shapes.setdefault(gemm_key(d), []).append(d)
