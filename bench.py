@@ -341,6 +341,7 @@ def main():
     if rank == 0:
         print(json.dumps(res), flush=True)
     if world > 1:
+        torch.distributed.barrier()      # ranks > 0 wait for rank 0's (untimed) roofline replay before tearing down
         torch.distributed.destroy_process_group()
 
 

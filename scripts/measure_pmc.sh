@@ -1,4 +1,6 @@
 #!/bin/bash
+# PMC passes (FETCH_SIZE, then WRITE_SIZE + L2 hit/miss; separate runs, --kernel-trace only) over one LoRA-on UNet
+# pass, summarised per kernel by scripts/pmc_summary.py; also re-runs the bench line + kernel stats.
 mkdir -p gpurun_out
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT

@@ -1,4 +1,6 @@
 #!/bin/bash
+# Round measurement on the GPU box (gpurun -- 'bash scripts/measure_round.sh'): the contract bench line and the
+# rocprofv3 --kernel-trace --stats summary of the same command; copy gpurun_out/r01_* into profiles/ afterwards.
 mkdir -p gpurun_out
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT

@@ -1,4 +1,5 @@
 #!/bin/bash
+# Re-run the tile tuner, then the whole GPU test suite and the smoke test with the new table.
 mkdir -p gpurun_out
 cp sliders_amd/tuning/gfx950_sdxl_128.json gpurun_out/gfx950_sdxl_128.json
 timeout 900 python scripts/tune_gemm.py --out gpurun_out/gfx950_sdxl_128.json > gpurun_out/t17_tune.log 2>&1; tail -2 gpurun_out/t17_tune.log
