@@ -169,20 +169,11 @@ def cpu_baseline(model, hw):
     ncpu = _usable_cpus()
     torch.set_num_threads(ncpu)
     cfg = CONFIGS[model]()
-    a32, b32 = torch.randn(2048, 1280), torch.randn(1280, 1280)
-    tm = {}
-    for dt in (torch.float32, torch.bfloat16):
-        a, b = a32.to(dt), b32.to(dt)
-        a @ b
-        t0 = time.time()
-        for _ in range(5):
-            a @ b
-        tm[dt] = time.time() - t0
     need32 = 4 * 2.6e9 / 2 ** 30 * 1.3 if model == "sdxl" else 6.0
     # fp32 whenever it fits: oneDNN bf16 convolutions fall off a cliff on hosts whose bf16 GEMM probe looks fine
     # (measured: 261 s for one 256x256 step in bf16 vs 6.4 s in fp32 on the same class of EPYC host)
     dtype = torch.float32 if _mem_limit_gb() > need32 + 8 else torch.bfloat16
-    log(f"gemm probe fp32 {tm[torch.float32]:.3f}s bf16 {tm[torch.bfloat16]:.3f}s, mem limit {_mem_limit_gb():.0f} GB -> {dtype}")
+    log(f"{ncpu} usable cores, mem limit {_mem_limit_gb():.0f} GB -> {dtype}")
     net = build_unet(model, device="meta")
     g = torch.Generator().manual_seed(0)
     block = ((torch.rand(1 << 22, generator=g) - 0.5) * 0.05).to(dtype)

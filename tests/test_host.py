@@ -153,3 +153,41 @@ def test_gemm_weight_tile_packing_layout():
         off = ((r >> 6) * (k // 64) + (c >> 6)) * 4096 + rr * 64 + ((slot ^ ((rr >> 1) & 7)) << 3) + e
         assert flat[off].item() == (w[r, c].item() if r < n else 0.0)
     assert torch.equal(unpack_gemm_w(flat, n, k), w)
+
+
+def test_c_abi_rejects_bad_descriptors_before_any_launch():
+    """Argument validation runs before the first HIP call, so it is testable without a GPU: every unsupported shape,
+    alignment or flag combination returns non-zero and names the entry point (no silent fallback, no launch)."""
+    one = 0x1000          # any non-null pointer: validation never dereferences device memory
+
+    def gemm(**kw):
+        base = dict(a0=one, w=one, c=one, lda0=64, ca0=64, mode=0, stride=1, ldw=64, M=64, N=64, K=64, ldc=64,
+                    rows_per_sample=64)
+        base.update(kw)
+        return lib.GemmDesc(**base)
+
+    bad = {
+        "K multiple of 64": gemm(K=96, ca0=96, lda0=96, ldw=96),
+        "N multiple of 4": gemm(N=66),
+        "dense K": gemm(ca0=128, lda0=128),                            # K != ca0 + ca1
+        "a1/ca1": gemm(ca1=64, K=128),                                 # second source declared but a1 null
+        "bad tile": gemm(tile=0x33),
+        "8-wave": gemm(tile=0x4021),
+        "bad mode": gemm(mode=2),
+        "conv K": gemm(mode=1, batch=1, hs=8, ws=8, ho=8, wo=8, K=64 * 8),
+        "geglu": gemm(geglu=1, residual=one, ld_res=64),
+        "fused lora": gemm(lora_down=one, lora_up=one, lora_scale=one, lora_groups=1, lora_rank=8, ld_t=4),
+        "w_layout": gemm(w_layout=3),
+    }
+    for what, d in bad.items():
+        with pytest.raises(lib.SlidersHipError, match="slh_gemm"):
+            lib.call(lib.OP_GEMM, d, 0)
+    with pytest.raises(lib.SlidersHipError, match="slh_layernorm"):
+        lib.call(lib.OP_LAYERNORM, lib.LnDesc(x=one, y=one, gamma=one, beta=one, M=4, C=2048, ldx=2048, ldy=2048), 0)
+    with pytest.raises(lib.SlidersHipError, match="slh_attn"):
+        lib.call(lib.OP_ATTN_FWD, lib.AttnDesc(q=one, k=one, vt=one, o=one, B=1, H=1, Tq=64, Tk=64, ldq=64, ldk=64,
+                                               ldvt=64, ldo=64, scale=1.0, D=200), 0)
+    # a malformed command buffer is refused as a whole
+    buf = ctypes.create_string_buffer(b"\x63\x00\x00\x00\x08\x00\x00\x00" + b"\0" * 8, 16)
+    assert lib.load().slh_run_program(ctypes.cast(buf, ctypes.c_void_p), 16, None) != 0
+    assert b"slh_run_program" in lib.load().slh_last_error()
