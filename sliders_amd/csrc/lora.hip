@@ -331,9 +331,15 @@ extern "C" int slh_lora_wgrad(const slh_wgrad_desc* d, slh_stream_t stream) {
     p.vgroup_cols = d->vgroup_cols;
     const int C = d->c0 + d->c1;
     const int gx = (C / 8 + 31) / 32;
-    int splits = (d->M + 1023) / 1024;
+    // a rank-4 gradient is a reduction over M with only C/256 (x9 taps) independent column blocks: split M until the
+    // launch has ~768 workgroups (3 per CU), at least 64 rows each; partial sums meet in the fp32 atomics below
+    const int blocks_xz = gx * (d->mode == 1 ? 9 : 1);
+    int splits = (768 + blocks_xz - 1) / blocks_xz;
+    const int max_splits = (d->M + 63) / 64, min_splits = (d->M + 1023) / 1024;
+    if (splits > max_splits) splits = max_splits;
+    if (splits < min_splits) splits = min_splits;
     if (splits < 1) splits = 1;
-    p.rows_per_block = (d->M + splits - 1) / splits;
+    p.rows_per_block = ((d->M + splits - 1) / splits + 7) / 8 * 8;
     dim3 grid(gx, splits, d->mode == 1 ? 9 : 1);
     hipStream_t s = (hipStream_t)stream;
     if (d->R == 4) hipLaunchKernelGGL(wgrad_kernel<4>, grid, dim3(256), 0, s, p);
