@@ -54,7 +54,7 @@ constexpr int gemm_waves_per_simd(int MI, int NI, int STAGES, bool LORA, int WM)
     const int lds = STAGES * (32 * MI * WM + 64 * NI + (LORA ? 32 : 0)) * 128;
     int blocks = (160 * 1024) / lds;
     int w = blocks * 2 * WM / 4;
-    if (LORA && MI * NI == 1 && WM == 2) w = 4;   // 64x64 + fused LoRA needs ~110 registers: 4 waves, not 5
+    if (LORA && MI * NI == 1 && WM == 2 && w > 4) w = 4;   // 64x64 + fused LoRA needs ~110 registers: 4 waves, not 5
     return w < 1 ? 1 : (w > 8 ? 8 : w);
 }
 
