@@ -461,10 +461,16 @@ static void pick_tile(const slh_gemm_desc* d, int& MI, int& NI, int& WM) {
         if (MI) return;
         MI = 2; NI = 2; WM = 2;
     }
-    auto tiles = [&](int mi, int ni) { return ((d->M + 64 * mi - 1) / (64 * mi)) * ((d->N + 64 * ni - 1) / (64 * ni)); };
-    if (tiles(2, 2) < 384) { MI = 2; NI = 1; }
-    if (!d->geglu && tiles(2, 2) < 192) { MI = 1; NI = 1; }
-    if (d->geglu) { NI = 2; if (tiles(2, 2) < 256) MI = 1; }
+    // untuned shape: the pattern of the measured table (sliders_amd/tuning/gfx950_sdxl_128.json) - the 8-wave 128x128
+    // tile once it yields enough workgroups (or fewer, but with a long K loop to amortise them), 64x64 otherwise
+    const long t128 = (long)((d->M + 127) / 128) * ((d->N + 127) / 128);
+    if (d->geglu) {
+        NI = 2; MI = 1; WM = t128 >= 192 ? 4 : 2;
+    } else if (t128 >= 256 || (t128 >= 160 && d->K >= 5760)) {
+        MI = 1; NI = 2; WM = 4;
+    } else {
+        MI = 1; NI = 1; WM = 2;
+    }
 }
 
 // L2 blocking: number of m-tile groups G (see the kernel's tile mapping).  An XCD's chunk of the grouped sequence reads
