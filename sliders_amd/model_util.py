@@ -29,7 +29,8 @@ def create_noise_scheduler(scheduler_name: str = "ddim", prediction_type: str = 
     return DDIMScheduler()
 
 
-def load_unet_engine(name_or_path: str, device="cuda:0") -> UNetEngine:
+def load_unet_state(name_or_path: str):
+    """(UNetConfig, state dict) of a diffusers-format model directory; no device work."""
     unet_dir = os.path.join(name_or_path, "unet")
     cfg_path = os.path.join(unet_dir, "config.json")
     if not os.path.isfile(cfg_path):
@@ -41,7 +42,11 @@ def load_unet_engine(name_or_path: str, device="cuda:0") -> UNetEngine:
     wpath = os.path.join(unet_dir, "diffusion_pytorch_model.safetensors")
     if not os.path.isfile(wpath):
         wpath = os.path.join(unet_dir, "diffusion_pytorch_model.fp16.safetensors")
-    sd = load_file(wpath)
+    return cfg, load_file(wpath)
+
+
+def load_unet_engine(name_or_path: str, device="cuda:0") -> UNetEngine:
+    cfg, sd = load_unet_state(name_or_path)
     return UNetEngine(cfg, sd, device)
 
 

@@ -191,3 +191,50 @@ def test_c_abi_rejects_bad_descriptors_before_any_launch():
     buf = ctypes.create_string_buffer(b"\x63\x00\x00\x00\x08\x00\x00\x00" + b"\0" * 8, 16)
     assert lib.load().slh_run_program(ctypes.cast(buf, ctypes.c_void_p), 16, None) != 0
     assert b"slh_run_program" in lib.load().slh_last_error()
+
+
+def test_diffusers_directory_loader_and_weight_packing(tmp_path):
+    """model_util.load_unet_state reads the layout the reference loads through diffusers (model_util.py:67-72,
+    169-174: <dir>/unet/config.json + diffusion_pytorch_model.safetensors), and WeightStore repacks every matrix the
+    GEMM streams losslessly (the tile-packed form unpacks to the fused / permuted source rows)."""
+    from safetensors.torch import save_file
+    from oracle.unet_oracle import build_unet
+    from sliders_amd.model_util import load_unet_state
+    from sliders_amd.weights import WeightStore
+
+    net = build_unet("tiny_sdxl", seed=3)
+    sd = {k: v.contiguous() for k, v in net.state_dict().items()}
+    cfg0 = CONFIGS["tiny_sdxl"]()
+    unet_dir = tmp_path / "model" / "unet"
+    unet_dir.mkdir(parents=True)
+    raw = {k: (list(v) if isinstance(v, tuple) else v) for k, v in cfg0.__dict__.items()}
+    raw.update({"_class_name": "UNet2DConditionModel", "_diffusers_version": "0.20.2", "act_fn": "silu"})   # extra keys ignored
+    (unet_dir / "config.json").write_text(json.dumps(raw))
+    save_file(sd, str(unet_dir / "diffusion_pytorch_model.safetensors"))
+    cfg, loaded = load_unet_state(str(tmp_path / "model"))
+    assert cfg == cfg0
+    assert loaded.keys() == sd.keys() and all(torch.equal(loaded[k], sd[k]) for k in sd)
+
+    ws = WeightStore(cfg, loaded, "cpu", dtype=torch.float32)
+    p = "down_blocks.1.attentions.0.transformer_blocks.0"
+    qkv = torch.cat([sd[f"{p}.attn1.to_{x}.weight"] for x in "qkv"], 0)
+    assert torch.equal(ws.gemm_matrix(f"{p}.attn1.qkv.w"), qkv)
+    conv = sd["down_blocks.0.resnets.0.conv1.weight"]
+    assert torch.equal(ws.gemm_matrix("down_blocks.0.resnets.0.conv1.w"), conv.permute(0, 2, 3, 1).reshape(conv.shape[0], -1))
+    # batched text K/V: [all K rows | all V rows], each block's slice at the recorded offsets
+    k_off, v_off = ws.kv_all_offset[f"{p}.attn2"]
+    allkv = ws.gemm_matrix("attn2_kv_all.w")
+    wk, wv = sd[f"{p}.attn2.to_k.weight"], sd[f"{p}.attn2.to_v.weight"]
+    assert torch.equal(allkv[k_off:k_off + wk.shape[0]], wk) and torch.equal(allkv[v_off:v_off + wv.shape[0]], wv)
+    assert allkv.shape[0] == 2 * ws.kv_all_vbase
+    with pytest.raises(FileNotFoundError):
+        load_unet_state(str(tmp_path / "nope"))
+
+
+def test_cli_keeps_the_reference_flags():
+    """train_lora.py / train_lora_xl.py flags (train_lora_xl.py:419-470) parse unchanged."""
+    from sliders_amd.cli import build_parser
+    a = build_parser(True).parse_args(["--config_file", "c.yaml", "--prompts_file", "p.yaml", "--alpha", "1.0", "--rank", "4",
+                                       "--device", "0", "--name", "ageslider", "--attributes", "male, female"])
+    got = (a.config_file, a.prompts_file, a.alpha, a.rank, a.device, a.name, a.attributes)
+    assert got == ("c.yaml", "p.yaml", 1.0, 4, 0, "ageslider", "male, female")
