@@ -238,3 +238,36 @@ def test_cli_keeps_the_reference_flags():
                                        "--device", "0", "--name", "ageslider", "--attributes", "male, female"])
     got = (a.config_file, a.prompts_file, a.alpha, a.rank, a.device, a.name, a.attributes)
     assert got == ("c.yaml", "p.yaml", 1.0, 4, 0, "ageslider", "male, female")
+
+
+def test_encode_prompts_xl_contract_with_tiny_clip():
+    """train_util.py:77-133: per prompt the penultimate hidden states of both CLIP text encoders concatenated on the
+    feature axis, and the pooled (projected) output of the SECOND encoder.  Tiny random-init CLIP models and a stub
+    tokenizer stand in for the checkpoints the build image does not have."""
+    from transformers import CLIPTextConfig, CLIPTextModel, CLIPTextModelWithProjection
+    from sliders_amd.model_util import encode_prompts_xl
+
+    class Tok:
+        model_max_length = 77
+
+        def __call__(self, prompts, padding, max_length, truncation, return_tensors):
+            g = torch.Generator().manual_seed(len(prompts))
+            ids = torch.randint(1, 90, (len(prompts), max_length), generator=g)
+            ids[:, -1] = 99                      # eos = highest id: CLIP pools at argmax(input_ids)
+            return type("Enc", (), {"input_ids": ids})()
+
+    torch.manual_seed(0)
+    c1 = CLIPTextConfig(vocab_size=100, hidden_size=32, intermediate_size=64, num_hidden_layers=3, num_attention_heads=2,
+                        max_position_embeddings=77, eos_token_id=99)
+    c2 = CLIPTextConfig(vocab_size=100, hidden_size=48, intermediate_size=64, num_hidden_layers=3, num_attention_heads=2,
+                        max_position_embeddings=77, projection_dim=40, eos_token_id=99)
+    e1, e2 = CLIPTextModel(c1).eval(), CLIPTextModelWithProjection(c2).eval()
+    prompts = ["a person", "an old person"]
+    text, pooled = encode_prompts_xl([Tok(), Tok()], [e1, e2], prompts, num_images_per_prompt=2)
+    assert text.shape == (4, 77, 32 + 48) and pooled.shape == (4, 40)
+    ids = Tok()(prompts, "max_length", 77, True, "pt").input_ids
+    with torch.no_grad():
+        h1 = e1(ids, output_hidden_states=True).hidden_states[-2]
+        o2 = e2(ids, output_hidden_states=True)
+    want = torch.cat([h1, o2.hidden_states[-2]], -1).repeat_interleave(2, dim=0)
+    assert torch.allclose(text, want) and torch.allclose(pooled, o2.text_embeds.repeat_interleave(2, dim=0))
