@@ -31,11 +31,6 @@ def _conv3_pack(w: torch.Tensor) -> torch.Tensor:
     return w.permute(0, 2, 3, 1).reshape(co, kh * kw * ci).contiguous()
 
 
-def _conv3_dgrad_pack(w: torch.Tensor) -> torch.Tensor:
-    co, ci, kh, kw = w.shape
-    return w.flip(2, 3).permute(1, 2, 3, 0).reshape(ci, kh * kw * co).contiguous()
-
-
 def _geglu_perm(w: torch.Tensor) -> torch.Tensor:
     n2 = w.shape[0]
     n = n2 // 2
@@ -105,9 +100,6 @@ class WeightStore:
 
     def has(self, name: str) -> bool:
         return name in self.t
-
-    def _w(self, key: str) -> torch.Tensor:
-        return self._sd[key]
 
     # -- forward layouts ---------------------------------------------------------------------------
     def _pack(self):
