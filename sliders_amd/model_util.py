@@ -2,8 +2,8 @@
 pipelines for this; here only the pieces the hot path needs).
 
  * `load_unet_engine(name_or_path)`: a diffusers-format directory (`unet/config.json` +
-   `unet/diffusion_pytorch_model.safetensors`) -> UNetEngine.  Single-file `.ckpt/.safetensors` checkpoints
-   need the diffusers key conversion and are not supported yet.
+   `unet/diffusion_pytorch_model.safetensors`) or a single-file `.ckpt/.safetensors` checkpoint in the LDM key
+   layout (renamed by `ldm_convert.py`) -> UNetEngine.
  * `load_text_encoders_xl / encode_prompts_xl`: CLIP text encoders through the installed `transformers`
    (they run once before the loop - train_lora_xl.py:121-156 - and are not on the hot path).
  * `create_noise_scheduler`: DDIM as configured at model_util.py:237-246; the other schedulers are out of scope.
@@ -30,7 +30,23 @@ def create_noise_scheduler(scheduler_name: str = "ddim", prediction_type: str = 
 
 
 def load_unet_state(name_or_path: str):
-    """(UNetConfig, state dict) of a diffusers-format model directory; no device work."""
+    """(UNetConfig, diffusers-layout state dict) of a diffusers-format model directory or of a single-file
+    `.safetensors` / `.ckpt` checkpoint in the LDM key layout (model_util.py:104-129, 200-227); no device work."""
+    if os.path.isfile(name_or_path):
+        from .ldm_convert import LDM_PREFIX, convert_ldm_unet_state_dict
+        if name_or_path.endswith(".safetensors"):
+            from safetensors.torch import load_file
+            raw = load_file(name_or_path)
+        else:
+            raw = torch.load(name_or_path, map_location="cpu", weights_only=True)
+            raw = raw.get("state_dict", raw)
+        is_xl = any(k.startswith(LDM_PREFIX + "label_emb.") for k in raw)
+        probe = raw.get(LDM_PREFIX + "input_blocks.1.1.proj_in.weight")
+        if not is_xl and probe is not None and probe.ndim == 2:
+            raise NotImplementedError("Stable Diffusion 2.x single-file checkpoints (linear projections, 1024-d "
+                                      "context, v-prediction) are outside the implemented configs")
+        cfg = CONFIGS["sdxl" if is_xl else "sd1"]()
+        return cfg, convert_ldm_unet_state_dict(raw, cfg)
     unet_dir = os.path.join(name_or_path, "unet")
     cfg_path = os.path.join(unet_dir, "config.json")
     if not os.path.isfile(cfg_path):
