@@ -38,17 +38,16 @@ def build_parser(xl: bool) -> argparse.ArgumentParser:
     return p
 
 
-def _synthetic_pairs(cfg, prompts, dev, seed):
-    """One PairEmbeds per PromptSettings; embeddings are seeded randn keyed by the prompt string, so equal
-    prompts share an embedding like the reference's PromptEmbedsCache (train_lora_xl.py:121-151)."""
+def build_pairs(cfg, prompts, encode, dev):
+    """One PairEmbeds per PromptSettings.  `encode(text) -> (embeds (1,77,D), pooled (1,P) | None)` is called once per
+    distinct prompt string, like the reference's PromptEmbedsCache (train_lora_xl.py:121-151); every ctx tensor is
+    cat([unconditional, X]) repeated batch_size times, as concat_embeddings builds it (train_util.py:136-141)."""
     cache = {}
 
     def emb(text):
         if text not in cache:
-            g = torch.Generator().manual_seed(seed + (hash(text) & 0xFFFFFF))
-            e = torch.randn(1, 77, cfg.cross_attention_dim, generator=g).to(dev, torch.bfloat16)
-            p = torch.randn(1, cfg.pooled_dim, generator=g).to(dev, torch.bfloat16) if cfg.is_xl else None
-            cache[text] = (e, p)
+            e, p = encode(text)
+            cache[text] = (e.to(dev, torch.bfloat16), p.to(dev, torch.bfloat16) if p is not None else None)
         return cache[text]
 
     pairs = []
@@ -58,6 +57,29 @@ def _synthetic_pairs(cfg, prompts, dev, seed):
         pc = (lambda x: torch.cat([un[1], x[1]]).repeat_interleave(s.batch_size, dim=0).contiguous()) if cfg.is_xl else (lambda x: None)
         pairs.append((s, PairEmbeds(cat(t), cat(po), cat(ne), cat(un), pc(t), pc(po), pc(ne), pc(un),
                                     guidance_scale=s.guidance_scale, action=s.action)))
+    return pairs
+
+
+def _synthetic_pairs(cfg, prompts, dev, seed):
+    """Seeded randn embeddings keyed by the prompt string (no text-encoder weights in the build image)."""
+    def encode(text):
+        g = torch.Generator().manual_seed(seed + (hash(text) & 0xFFFFFF))
+        e = torch.randn(1, 77, cfg.cross_attention_dim, generator=g)
+        return e, (torch.randn(1, cfg.pooled_dim, generator=g) if cfg.is_xl else None)
+    return build_pairs(cfg, prompts, encode, dev)
+
+
+def _encoded_pairs(cfg, prompts, name_or_path, dev, dtype):
+    """Real checkpoints: CLIP text encoder(s) through `transformers`, run once before the loop (not on the hot path)."""
+    from . import model_util
+    if cfg.is_xl:
+        toks, encs = model_util.load_text_encoders_xl(name_or_path, dev, dtype)
+        encode = lambda text: model_util.encode_prompts_xl(toks, encs, [text])
+    else:
+        tok, enc = model_util.load_text_encoder(name_or_path, dev, dtype)
+        encode = lambda text: (model_util.encode_prompts(tok, enc, [text]), None)
+    pairs = build_pairs(cfg, prompts, encode, dev)
+    torch.cuda.empty_cache()                    # the encoders are dropped here, as the reference does (train_lora_xl.py:153-156)
     return pairs
 
 
@@ -71,8 +93,9 @@ def train(config: config_util.RootConfig, prompts, device: int, xl: bool, synthe
         eng = synthetic_engine("sdxl" if xl else "sd1", dev, seed)
     else:
         eng = load_unet_engine(config.pretrained_model.name_or_path, dev)
-        raise NotImplementedError("real-checkpoint runs need the CLIP prompt encoders wired in "
-                                  "(sliders_amd.model_util.encode_prompts_xl); use --synthetic in this image")
+        if eng.cfg.is_xl != xl:
+            raise ValueError(f"{config.pretrained_model.name_or_path} is {'an SDXL' if eng.cfg.is_xl else 'an SD-1.x'} "
+                             f"UNet but the {'XL' if xl else 'SD-1.x'} entry point was used")
     torch.manual_seed(seed)
     store = LoraStore(eng.cfg, rank=config.network.rank, alpha=config.network.alpha,
                       train_method=config.network.training_method, network_type=config.network.type, device=dev)
@@ -80,7 +103,11 @@ def train(config: config_util.RootConfig, prompts, device: int, xl: bool, synthe
     hw = res // 8
     tr = SliderTrainer(eng, store, hw, hw, batch_size=prompts[0].batch_size, lr=config.train.lr,
                        max_denoising_steps=config.train.max_denoising_steps)
-    pairs = _synthetic_pairs(eng.cfg, prompts, dev, seed)
+    if synthetic:
+        pairs = _synthetic_pairs(eng.cfg, prompts, dev, seed)
+    else:
+        pairs = _encoded_pairs(eng.cfg, prompts, config.pretrained_model.name_or_path, dev,
+                               config_util.parse_precision(config.train.precision))
     samp = StepSampler(seed, rank, world, len(pairs), config.train.max_denoising_steps)
     save_path = Path(config.save.path)
     dtype = config_util.parse_precision(config.train.precision)   # the reference ignores save.precision (quirk D.7)

@@ -71,6 +71,22 @@ def synthetic_engine(model: str = "sdxl", device="cuda:0", seed: int = 0) -> UNe
     return UNetEngine(cfg, random_state_dict(cfg, device, seed), device)
 
 
+def load_text_encoder(name_or_path: str, device, dtype=torch.bfloat16):
+    """SD-1.x: one CLIP tokenizer + text encoder (model_util.py:48-66)."""
+    from transformers import CLIPTextModel, CLIPTokenizer
+    tok = CLIPTokenizer.from_pretrained(name_or_path, subfolder="tokenizer")
+    enc = CLIPTextModel.from_pretrained(name_or_path, subfolder="text_encoder").to(device, dtype).eval()
+    return tok, enc
+
+
+@torch.no_grad()
+def encode_prompts(tokenizer, text_encoder, prompts) -> torch.Tensor:
+    """train_util.py:60-74: last hidden state of the CLIP text encoder, (n, 77, 768)."""
+    ids = tokenizer(prompts, padding="max_length", max_length=tokenizer.model_max_length, truncation=True,
+                    return_tensors="pt").input_ids.to(text_encoder.device)
+    return text_encoder(ids)[0]
+
+
 def load_text_encoders_xl(name_or_path: str, device, dtype=torch.bfloat16):
     from transformers import CLIPTextModel, CLIPTextModelWithProjection, CLIPTokenizer
     toks = [CLIPTokenizer.from_pretrained(name_or_path, subfolder="tokenizer"),

@@ -271,3 +271,31 @@ def test_encode_prompts_xl_contract_with_tiny_clip():
         o2 = e2(ids, output_hidden_states=True)
     want = torch.cat([h1, o2.hidden_states[-2]], -1).repeat_interleave(2, dim=0)
     assert torch.allclose(text, want) and torch.allclose(pooled, o2.text_embeds.repeat_interleave(2, dim=0))
+
+
+def test_build_pairs_caches_prompts_and_concatenates_like_the_reference():
+    """cli.build_pairs: one encoder call per distinct prompt (PromptEmbedsCache, train_lora_xl.py:121-151) and ctx =
+    cat([unconditional, X]).repeat_interleave(batch_size) (concat_embeddings, train_util.py:136-141)."""
+    from sliders_amd.cli import build_pairs
+    cfg = CONFIGS["tiny_sdxl"]()
+    calls = []
+
+    def encode(text):
+        calls.append(text)
+        g = torch.Generator().manual_seed(len(text))
+        return torch.randn(1, 77, cfg.cross_attention_dim, generator=g), torch.randn(1, cfg.pooled_dim, generator=g)
+
+    prompts = [PromptSettings(target="person", positive="old person", unconditional="young person", neutral="person",
+                              action="enhance", guidance_scale=4, batch_size=2),
+               PromptSettings(target="person", positive="smiling person", unconditional="", neutral="person",
+                              action="erase", guidance_scale=2, batch_size=1)]
+    pairs = build_pairs(cfg, prompts, encode, "cpu")
+    assert sorted(calls) == sorted({"person", "old person", "young person", "smiling person", ""})
+    (s0, p0), (s1, p1) = pairs
+    assert p0.ctx_target.shape == (4, 77, cfg.cross_attention_dim) and p0.pooled_positive.shape == (4, cfg.pooled_dim)
+    assert p1.ctx_target.shape == (2, 77, cfg.cross_attention_dim)
+    unc, tgt = encode("young person")[0].bfloat16(), encode("person")[0].bfloat16()
+    assert torch.equal(p0.ctx_target, torch.cat([unc, tgt]).repeat_interleave(2, dim=0))
+    assert torch.equal(p0.ctx_uncond, torch.cat([unc, unc]).repeat_interleave(2, dim=0))
+    assert (p0.guidance_scale, p0.action, p1.guidance_scale, p1.action) == (4, "enhance", 2, "erase")
+    assert p0.ctx_target.dtype == torch.bfloat16
