@@ -100,13 +100,15 @@ def measure_roofline(eng, plan):
     table = {k: dict(calls_per_pass=x["calls"], ms_per_pass=round(x["ms"], 3),
                      tflops=round(x["flops"] / (x["ms"] * 1e-3) / 1e12, 1)) for k, x in sorted(groups.items())}
     traffic, tsrc = None, None
-    tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")
-    if os.path.exists(tpath):                   # PMC counters cannot be read from inside the timed process: the
-        with open(tpath) as f:                  # per-launch HBM-side bytes come from the committed rocprofv3 --pmc passes
+    import glob
+    cands = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r*_pmc_traffic.json")))
+    if cands:                                   # PMC counters cannot be read from inside the timed process: the
+        tpath = cands[-1]                       # per-launch HBM-side bytes come from the newest committed --pmc passes
+        with open(tpath) as f:
             pm = json.load(f)["kernels"].get(kname.replace(", ", "; "))
         if pm:
             traffic = pm["fetch_bytes_per_launch"] + pm["write_bytes_per_launch"]
-            tsrc = "profiles/r01_pmc_traffic.json (FETCH_SIZE x2 + WRITE_SIZE per launch, LoRA-on forward pass)"
+            tsrc = f"profiles/{os.path.basename(tpath)} (FETCH_SIZE x2 + WRITE_SIZE per launch, LoRA-on forward pass)"
     return {
         "bound": "mfma", "kernel": kname,
         "achieved": round(achieved, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
