@@ -281,14 +281,13 @@ def main():
         pcat = (lambda x: torch.cat([pl[3], x]).contiguous()) if cfg.is_xl else (lambda x: None)
         pairs.append(PairEmbeds(cat(tgt), cat(pos), cat(neu), cat(unc), pcat(pl[0]), pcat(pl[1]), pcat(pl[2]),
                                 pcat(pl[3]), guidance_scale=4.0, action="enhance"))
-    krng = torch.Generator(device="cpu").manual_seed(4321)           # shared across ranks
-    nrng = torch.Generator(device="cpu").manual_seed(1000 + rank)    # per-rank noise
+    from sliders_amd.parallel import StepSampler
+    samp = StepSampler(4321, rank, world, len(pairs))   # k shared by all ranks, pair index and noise rank-local (tests/test_dp_gloo.py)
 
     def one_step(step_idx):
-        k = int(torch.randint(1, 50, (1,), generator=krng).item())
-        pair = pairs[(step_idx * world + rank) % len(pairs)]
-        noise = torch.randn(1, 4, hw, hw, generator=nrng).to(dev)
-        tr.iteration(pair, k, noise)
+        k, pi = samp.next()
+        noise = samp.noise((1, 4, hw, hw)).to(dev)
+        tr.iteration(pairs[pi], k, noise)
         return k
 
     def barrier():

@@ -12,7 +12,9 @@ LoRA gradient once per step (sliders_amd/parallel.py).
 from __future__ import annotations
 
 import argparse
+import ast
 import os
+import zlib
 from pathlib import Path
 
 import torch
@@ -29,7 +31,7 @@ def build_parser(xl: bool) -> argparse.ArgumentParser:
     p.add_argument("--config_file", required=True, help="Config file for training.")
     p.add_argument("--prompts_file", required=False, help="Prompts file for training.", default=None)
     p.add_argument("--alpha", type=float, required=False, default=None, help="LoRA weight.")
-    p.add_argument("--rank", type=int, required=False, help="Rank of LoRA.", default=4)
+    p.add_argument("--rank", type=int, required=False, help="Rank of LoRA.", default=None)
     p.add_argument("--device", type=int, required=False, default=0, help="Device to train on.")
     p.add_argument("--name", type=str, required=False, default=None, help="name of the slider")
     p.add_argument("--attributes", type=str, required=False, default=None, help="attritbutes to disentangle")
@@ -63,7 +65,7 @@ def build_pairs(cfg, prompts, encode, dev):
 def _synthetic_pairs(cfg, prompts, dev, seed):
     """Seeded randn embeddings keyed by the prompt string (no text-encoder weights in the build image)."""
     def encode(text):
-        g = torch.Generator().manual_seed(seed + (hash(text) & 0xFFFFFF))
+        g = torch.Generator().manual_seed(seed + (zlib.crc32(text.encode("utf-8")) & 0xFFFFFF))   # stable across processes / ranks
         e = torch.randn(1, 77, cfg.cross_attention_dim, generator=g)
         return e, (torch.randn(1, cfg.pooled_dim, generator=g) if cfg.is_xl else None)
     return build_pairs(cfg, prompts, encode, dev)
@@ -83,7 +85,80 @@ def _encoded_pairs(cfg, prompts, name_or_path, dev, dtype):
     return pairs
 
 
+class LrSchedule:
+    """Per-iteration learning rate of `train.lr_scheduler` (train_util.py:376-404, stepped once per iteration at
+    train_lora_xl.py:347), evaluated on the host with torch's own scheduler classes over a dummy optimizer; the fused
+    AdamW kernel takes the value as an argument of each launch."""
+
+    def __init__(self, name: str, lr: float, iterations: int):
+        from .train_util import get_lr_scheduler
+        if name == "linear":
+            raise NotImplementedError("lr_scheduler 'linear': the reference passes factor=0.5 to torch's LinearLR, which "
+                                      "has no such argument (train_util.py:397-400 raises TypeError); pick another one")
+        self._opt = torch.optim.SGD([torch.nn.Parameter(torch.zeros(1))], lr=lr)
+        self._sched = get_lr_scheduler(name, self._opt, max_iterations=iterations, lr_min=lr / 100)
+
+    def current(self) -> float:
+        return float(self._opt.param_groups[0]["lr"])
+
+    def step(self):
+        self._opt.step()
+        self._sched.step()
+
+
+def optimizer_options(train_cfg) -> dict:
+    """`train.optimizer` + `train.optimizer_args` ("k=v k=v", train_lora_xl.py:92-101) -> arguments of the fused flat AdamW
+    (slh_adamw).  Anything that kernel does not implement is an error, never silently ignored."""
+    name = (train_cfg.optimizer or "adamw").lower()
+    if name not in ("adamw", "adam"):
+        raise NotImplementedError(f"train.optimizer '{train_cfg.optimizer}': the fused MI355X path implements adam / adamw "
+                                  f"(lion, prodigy, dadapt*, *8bit need packages that are not in this image)")
+    kw = {}
+    if train_cfg.optimizer_args:
+        for arg in train_cfg.optimizer_args.split(" "):
+            if not arg:
+                continue
+            key, value = arg.split("=")
+            kw[key] = ast.literal_eval(value)
+    out = {"betas": (0.9, 0.999), "eps": 1e-8, "weight_decay": 0.01 if name == "adamw" else 0.0}
+    for key, value in kw.items():
+        if key not in out:
+            raise NotImplementedError(f"train.optimizer_args '{key}' is not implemented by the fused AdamW")
+        out[key] = value
+    if name == "adam" and out["weight_decay"] != 0:
+        raise NotImplementedError("adam with weight_decay != 0 is L2-coupled decay; only decoupled (adamw) decay is implemented")
+    out["betas"] = (float(out["betas"][0]), float(out["betas"][1]))
+    return out
+
+
+def check_supported(config: config_util.RootConfig):
+    """Reject, before any model is loaded, every config value the fused path would otherwise have to ignore."""
+    t = config.train
+    if config_util.parse_precision(t.precision) != torch.bfloat16:
+        raise NotImplementedError(f"train.precision '{t.precision}': the MI355X hot path computes in bf16 (the reference's default)")
+    if t.noise_scheduler != "ddim":
+        raise NotImplementedError(f"train.noise_scheduler '{t.noise_scheduler}': only DDIM (model_util.py:237-246) is implemented")
+    if config.pretrained_model.v2 or config.pretrained_model.v_pred:
+        raise NotImplementedError("pretrained_model.v2 / v_pred (SD-2.x, v-prediction) are outside the implemented configs")
+    optimizer_options(t)
+    LrSchedule(t.lr_scheduler, t.lr, t.iterations)
+
+
+def check_model_files(name_or_path: str):
+    """Single-file checkpoints carry the text encoders in an LDM layout this loader does not convert: fail before the
+    UNet is loaded and repacked, and say what works."""
+    if os.path.isfile(name_or_path):
+        raise NotImplementedError(
+            f"{name_or_path}: single-file checkpoints are accepted for the UNet only (sliders_amd.model_util."
+            f"load_unet_engine); the training CLI also needs the tokenizer and text encoder(s), which it loads from a "
+            f"diffusers-format model directory - pass that directory as pretrained_model.name_or_path")
+
+
 def train(config: config_util.RootConfig, prompts, device: int, xl: bool, synthetic: bool, seed: int = 0):
+    from .train_util import get_add_time_ids, get_random_resolution_in_bucket
+    check_supported(config)
+    if not synthetic:
+        check_model_files(config.pretrained_model.name_or_path)
     rank, world = world_info()
     dev = torch.device("cuda", device)
     torch.cuda.set_device(dev)
@@ -99,25 +174,56 @@ def train(config: config_util.RootConfig, prompts, device: int, xl: bool, synthe
     torch.manual_seed(seed)
     store = LoraStore(eng.cfg, rank=config.network.rank, alpha=config.network.alpha,
                       train_method=config.network.training_method, network_type=config.network.type, device=dev)
-    res = prompts[0].resolution
-    hw = res // 8
-    tr = SliderTrainer(eng, store, hw, hw, batch_size=prompts[0].batch_size, lr=config.train.lr,
-                       max_denoising_steps=config.train.max_denoising_steps)
+    opt = optimizer_options(config.train)
+    hw0 = prompts[0].resolution // 8
+    tr = SliderTrainer(eng, store, hw0, hw0, batch_size=prompts[0].batch_size, lr=config.train.lr, betas=opt["betas"],
+                       eps=opt["eps"], weight_decay=opt["weight_decay"],
+                       max_denoising_steps=config.train.max_denoising_steps,
+                       process_group=torch.distributed.group.WORLD if world > 1 else None)
     if synthetic:
         pairs = _synthetic_pairs(eng.cfg, prompts, dev, seed)
     else:
         pairs = _encoded_pairs(eng.cfg, prompts, config.pretrained_model.name_or_path, dev,
                                config_util.parse_precision(config.train.precision))
     samp = StepSampler(seed, rank, world, len(pairs), config.train.max_denoising_steps)
+    sched = LrSchedule(config.train.lr_scheduler, config.train.lr, config.train.iterations)
+    wandb = None
+    if config.logging.use_wandb and rank == 0:     # optional, as in train_lora_xl.py:57-58
+        try:
+            import wandb
+            wandb.init(project=f"LECO_{config.save.name}", config=config.model_dump())
+        except ImportError:
+            print("logging.use_wandb: the wandb package is not installed; continuing without it")
+            wandb = None
     save_path = Path(config.save.path)
     dtype = config_util.parse_precision(config.train.precision)   # the reference ignores save.precision (quirk D.7)
     for i in range(config.train.iterations):
         k, pi = samp.next()
         s, pair = pairs[pi]
-        noise = samp.noise((s.batch_size, 4, hw, hw)).to(dev)
-        loss = tr.iteration(pair, k, noise)
+        # per-pair resolution / dynamic_resolution / batch_size / dynamic_crops (train_lora_xl.py:179-203); the draws
+        # come from the rank-shared stream so that every rank does the same amount of work in a step
+        height = width = s.resolution
+        gshared = samp.shared
+        if s.dynamic_resolution:
+            st = torch.random.get_rng_state()
+            torch.manual_seed(int(torch.randint(0, 2 ** 31 - 1, (1,), generator=gshared).item()))
+            height, width = get_random_resolution_in_bucket(s.resolution)
+            torch.random.set_rng_state(st)
+        time_ids = None
+        if eng.cfg.is_xl and s.dynamic_crops:
+            st = torch.random.get_rng_state()
+            torch.manual_seed(int(torch.randint(0, 2 ** 31 - 1, (1,), generator=gshared).item()))
+            ids = get_add_time_ids(height, width, dynamic_crops=True, dtype=torch.bfloat16)   # bf16 like the reference (quirk D.8)
+            torch.random.set_rng_state(st)
+            time_ids = ids.float().repeat(2 * s.batch_size, 1)
+        noise = samp.noise((s.batch_size, 4, height // 8, width // 8)).to(dev)
+        lr = sched.current()
+        loss = tr.iteration(pair, k, noise, lr=lr, time_ids=time_ids)
+        sched.step()
         if rank == 0 and (i % 10 == 0 or config.logging.verbose):
-            print(f"it {i} k={k} Loss*1k: {loss.item() * 1000:.4f}")
+            print(f"it {i} k={k} {height}x{width} lr={lr:.3e} Loss*1k: {loss.item() * 1000:.4f}")
+        if wandb is not None:
+            wandb.log({"loss": loss.item(), "iteration": i, "lr": lr})
         if rank == 0 and i % config.save.per_steps == 0 and i != 0 and i != config.train.iterations - 1:
             save_path.mkdir(parents=True, exist_ok=True)
             torch.save(store.state_dict(dtype), save_path / f"{config.save.name}_{i}steps.pt")
@@ -127,23 +233,31 @@ def train(config: config_util.RootConfig, prompts, device: int, xl: bool, synthe
         print("Done.")
 
 
-def main(xl: bool, argv=None):
-    args = build_parser(xl).parse_args(argv)
-    config = config_util.load_config_from_yaml(args.config_file)
+def apply_cli_overrides(config: config_util.RootConfig, args):
+    """CLI flags override the YAML only when given (train_lora_xl.py:394-410)."""
     if args.name is not None:
         config.save.name = args.name
-    attributes = []
-    if args.attributes is not None:
-        attributes = [a.strip() for a in args.attributes.split(",")]
-    config.network.alpha = args.alpha if args.alpha is not None else config.network.alpha
-    config.network.rank = args.rank
+    if args.alpha is not None:
+        config.network.alpha = args.alpha
+    if args.rank is not None:
+        config.network.rank = args.rank
     config.save.name += f"_alpha{config.network.alpha}"
     config.save.name += f"_rank{config.network.rank}"
     config.save.name += f"_{config.network.training_method}"
     config.save.path += f"/{config.save.name}"
     if args.prompts_file is not None:
         config.prompts_file = args.prompts_file
+    return config
+
+
+def main(xl: bool, argv=None):
+    args = build_parser(xl).parse_args(argv)
+    config = apply_cli_overrides(config_util.load_config_from_yaml(args.config_file), args)
+    attributes = []
+    if args.attributes is not None:
+        attributes = [a.strip() for a in args.attributes.split(",")]
     prompts = prompt_util.load_prompts_from_yaml(config.prompts_file, attributes)
+    check_supported(config)
     if int(os.environ.get("WORLD_SIZE", "1")) > 1:
         torch.distributed.init_process_group("nccl")
         args.device = int(os.environ.get("LOCAL_RANK", "0"))

@@ -52,9 +52,11 @@ class StepSampler:
 
 
 def allreduce_sum_(flat: torch.Tensor, group=None) -> float:
-    """In-place SUM all-reduce of the flat gradient buffer; returns the factor the optimizer must scale by."""
+    """In-place SUM all-reduce of the flat gradient buffer; returns the factor the optimizer must scale by.
+    With an explicit `group` the collective is issued even for a single rank (an identity there), so the RCCL path
+    can be exercised on a one-GPU box."""
     rank, world = world_info(group)
-    if world > 1:
+    if world > 1 or (group is not None and dist.is_available() and dist.is_initialized()):
         dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
     return 1.0 / world
 

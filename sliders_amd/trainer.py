@@ -51,13 +51,27 @@ def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
 
 
+class _ShapeState:
+    """Per-(batch, H, W) device buffers of the trainer: prompts may carry their own resolution / batch_size /
+    dynamic_resolution (prompt_util.py:44-68, train_lora_xl.py:170-203), so nothing is sized once and for all."""
+
+    def __init__(self, cfg, bs: int, H: int, W: int, dev):
+        shape = (bs, cfg.out_channels, H, W)
+        z = lambda: torch.zeros(shape, dtype=torch.bfloat16, device=dev)
+        self.denoised, self.e_pos, self.e_neu, self.e_unc, self.e_tgt = z(), z(), z(), z(), z()
+        self.chw = cfg.out_channels * H * W
+        self.time_ids = None
+        if cfg.is_xl:   # [orig_h, orig_w, crop_top, crop_left, target_h, target_w], train_util.py:298-333
+            self.time_ids = torch.tensor([[H * 8.0, W * 8.0, 0.0, 0.0, H * 8.0, W * 8.0]] * (2 * bs),
+                                         dtype=torch.float32, device=dev)
+
+
 class SliderTrainer:
     def __init__(self, engine: UNetEngine, store: LoraStore, H: int, W: int, batch_size: int = 1,
                  lr: float = 2e-4, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.01,
                  max_denoising_steps: int = 50, denoise_guidance: float = 3.0, process_group=None,
                  dedup_frozen: bool = True):
         self.eng, self.store = engine, store
-        self.H, self.W, self.bs = H, W, batch_size
         self.lr, self.betas, self.eps, self.wd = lr, betas, eps, weight_decay
         self.nsteps = max_denoising_steps
         self.denoise_guidance = denoise_guidance
@@ -65,22 +79,24 @@ class SliderTrainer:
         self.pg = process_group
         self.rank, self.world = world_info(process_group)
         self.grad_scale = 1.0
-        dev = engine.device
-        cfg = engine.cfg
         engine.attach_lora(store) if engine.lora is not store else None
-        shape = (batch_size, cfg.out_channels, H, W)
-        z = lambda: torch.zeros(shape, dtype=torch.bfloat16, device=dev)
-        self.denoised, self.e_pos, self.e_neu, self.e_unc, self.e_tgt = z(), z(), z(), z(), z()
-        self.loss = torch.zeros(1, dtype=torch.float32, device=dev)
-        self.time_ids = None
-        if cfg.is_xl:
-            self.time_ids = torch.tensor([[H * 8.0, W * 8.0, 0.0, 0.0, H * 8.0, W * 8.0]] * (2 * batch_size),
-                                         dtype=torch.float32, device=dev)
-        self.chw = cfg.out_channels * H * W
+        self.loss = torch.zeros(1, dtype=torch.float32, device=engine.device)
         self.t50 = self.sched.make_timesteps(max_denoising_steps)
         self.t1000 = self.sched.make_timesteps(1000)
         self.unet_passes = 0
         self.dedup_frozen = dedup_frozen
+        self._states = {}
+        self._use(batch_size, H, W)
+
+    def _use(self, bs: int, H: int, W: int):
+        """Select (and lazily create) the buffers of one (batch, H, W); `iteration` calls it from the noise shape."""
+        key = (bs, H, W)
+        st = self._states.get(key)
+        if st is None:
+            st = self._states[key] = _ShapeState(self.eng.cfg, bs, H, W, self.eng.device)
+        self.H, self.W, self.bs = H, W, bs
+        self.denoised, self.e_pos, self.e_neu, self.e_unc, self.e_tgt = st.denoised, st.e_pos, st.e_neu, st.e_unc, st.e_tgt
+        self.chw, self.time_ids = st.chw, st.time_ids
 
     # ---- helpers ------------------------------------------------------------------------------------
     def _load_cond(self, p, ctx, pooled):
@@ -139,8 +155,17 @@ class SliderTrainer:
         self._cfg(p3, self.e_unc.data_ptr(), 1.0, eps_text=e)
 
     # ---- one iteration ------------------------------------------------------------------------------
-    def iteration(self, pair: PairEmbeds, k: int, noise: torch.Tensor) -> torch.Tensor:
-        """noise: (bs,4,H,W) already scaled by init_noise_sigma (=1).  Returns the device loss scalar."""
+    def iteration(self, pair: PairEmbeds, k: int, noise: torch.Tensor, lr: Optional[float] = None,
+                  time_ids: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """noise: (bs,4,H,W) already scaled by init_noise_sigma (=1); its shape selects the resolution and batch of
+        this iteration.  lr: this step's learning rate (the host evaluates the LR schedule, train_lora_xl.py:346-347).
+        time_ids: (2*bs, 6) SDXL micro-conditioning when it is not the default [H,W,0,0,H,W] (dynamic_crops).
+        Returns the device loss scalar."""
+        self._use(noise.shape[0], noise.shape[2], noise.shape[3])
+        if time_ids is not None:
+            self.time_ids = time_ids.to(device=self.eng.device, dtype=torch.float32).reshape(2 * self.bs, 6)
+        if lr is not None:
+            self.lr = float(lr)
         eng, st, bs = self.eng, self.store, self.bs
         B = 2 * bs
         s = _stream()

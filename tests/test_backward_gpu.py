@@ -4,7 +4,7 @@ autograd through the CPU oracle + oracle LoRA (= what loss.backward() does in th
 trainscripts/textsliders/train_lora_xl.py:345).
 
 Tolerances: bf16 gradients chained through ~100 layers; the engine must be as close to the fp32 oracle as
-the reference-precision arm (oracle run in torch bf16): rel_l2(engine) <= 1.5 * rel_l2(bf16 arm) + 5e-3 on the
+the reference-precision arm (oracle run in torch bf16): rel_l2(engine) <= rel_l2(bf16 arm) + 1e-3 on the
 flat gradient vector, and cosine similarity with the fp32 gradient >= 0.999.
 """
 import math
@@ -202,4 +202,4 @@ def test_unet_lora_gradients(dev, name, method):
         print(f"   worst: {nm} rel_l2={r:.3e}")
     assert torch.isfinite(got).all()
     assert cos >= 0.999, f"gradient direction off: cos={cos}"
-    assert r_eng <= 1.5 * r_ref + 5e-3
+    assert r_eng <= r_ref + 1e-3      # measured 2.6e-2 (engine) vs 3.1e-2 (bf16 arm)

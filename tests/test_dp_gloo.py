@@ -42,7 +42,21 @@ def _worker(rank, world, port, q):
         grad = (w - data).float()                 # d/dw 0.5*|w - data|^2 on this rank
         scale = allreduce_sum_(grad)
         w_new = w - 0.1 * grad * scale
-        q.put((rank, list(ks), list(pairs), noise.sum().item(), grad.clone(), scale, w_new.clone()))
+        # the real exchange: LoraStore's flat fp32 gradient buffer (what SliderTrainer.iteration all-reduces), then the
+        # replicated AdamW update with the 1/N scale folded in (torch.optim.AdamW stands in for slh_adamw on the CPU;
+        # tests/test_kernels_gpu.py::test_adamw_bit_exact ties the two together)
+        from sliders_amd.config import CONFIGS
+        from sliders_amd.lora_store import LoraStore
+        torch.manual_seed(3)
+        store = LoraStore(CONFIGS["tiny_sdxl"](), rank=4, alpha=1.0, train_method="noxattn", device="cpu")
+        store.grads.copy_(torch.randn(store.numel, generator=torch.Generator().manual_seed(200 + rank)))
+        gscale = allreduce_sum_(store.grads)
+        prm = torch.nn.Parameter(store.params.float().clone())
+        opt = torch.optim.AdamW([prm], lr=2e-4)
+        prm.grad = store.grads * gscale
+        opt.step()
+        q.put((rank, list(ks), list(pairs), noise.sum().item(), grad.numpy().copy(), scale, w_new.numpy().copy(),
+               store.grads.numpy().copy(), prm.detach().numpy().copy(), store.numel))
         dist.barrier()
     finally:
         dist.destroy_process_group()
@@ -74,7 +88,9 @@ def test_dp_world2_gloo():
         res = _run_world(world)
     except Exception:           # the probed rendezvous port can be taken between probe and bind: one retry
         res = _run_world(world)
-    (r0, k0, p0, n0, g0, s0, w0), (r1, k1, p1, n1, g1, s1, w1) = res
+    (r0, k0, p0, n0, g0, s0, w0, lg0, lp0, numel), (r1, k1, p1, n1, g1, s1, w1, lg1, lp1, _) = res
+    # payloads travel as numpy arrays (pickled by value; tensors travel by fd and need the sender alive)
+    g0, g1, w0, w1, lg0, lg1, lp0, lp1 = (torch.from_numpy(a) for a in (g0, g1, w0, w1, lg0, lg1, lp0, lp1))
     assert k0 == k1, "denoise length must be shared across ranks"
     assert all(1 <= k <= 49 for k in k0)
     assert all(a != b for a, b in zip(p0, p1)), "ranks must train different prompt pairs in a step"
@@ -87,6 +103,11 @@ def test_dp_world2_gloo():
     d1 = torch.randn(1000, generator=torch.Generator().manual_seed(101))
     assert torch.allclose(g0, (w - d0) + (w - d1))
     assert torch.equal(w0, w1), "replicated parameters diverged"
+    # LoraStore-shaped buffer: sum of the two ranks' gradients on both ranks, identical AdamW result
+    e0 = torch.randn(numel, generator=torch.Generator().manual_seed(200))
+    e1 = torch.randn(numel, generator=torch.Generator().manual_seed(201))
+    assert numel > 100000 and torch.equal(lg0, lg1) and torch.allclose(lg0, e0 + e1)
+    assert torch.equal(lp0, lp1), "replicated adapter parameters diverged after the optimizer step"
 
 
 def test_single_process_is_identity():

@@ -299,3 +299,95 @@ def test_build_pairs_caches_prompts_and_concatenates_like_the_reference():
     assert torch.equal(p0.ctx_uncond, torch.cat([unc, unc]).repeat_interleave(2, dim=0))
     assert (p0.guidance_scale, p0.action, p1.guidance_scale, p1.action) == (4, "enhance", 2, "erase")
     assert p0.ctx_target.dtype == torch.bfloat16
+
+
+# ---- config surface: honoured or rejected, never silently ignored (train_lora_xl.py:92-107, 170-203, 394-410) ----
+def _cfg(**train):
+    from sliders_amd import config_util
+    base = dict(prompts_file="p.yaml", pretrained_model=dict(name_or_path="x"), network=dict(type="c3lier", rank=8, alpha=2.0,
+                                                                                           training_method="noxattn"),
+                train=dict(precision="bfloat16", noise_scheduler="ddim", iterations=1000, lr=2e-4, optimizer="AdamW",
+                           lr_scheduler="constant", max_denoising_steps=50),
+                save=dict(name="s", path="./models", per_steps=500, precision="bfloat16"),
+                logging=dict(use_wandb=False, verbose=False), other=dict(use_xformers=True))
+    base["train"].update(train)
+    return config_util.RootConfig(**base)
+
+
+def test_cli_rank_and_alpha_override_only_when_given():
+    from sliders_amd.cli import apply_cli_overrides, build_parser
+    a = build_parser(True).parse_args(["--config_file", "c.yaml"])
+    assert a.rank is None and a.alpha is None
+    c = apply_cli_overrides(_cfg(), a)
+    assert c.network.rank == 8 and c.network.alpha == 2.0                 # the YAML's values survive
+    assert c.save.name == "s_alpha2.0_rank8_noxattn" and c.save.path == "./models/s_alpha2.0_rank8_noxattn"
+    a = build_parser(True).parse_args(["--config_file", "c.yaml", "--rank", "4", "--alpha", "1", "--name", "age"])
+    c = apply_cli_overrides(_cfg(), a)
+    assert c.network.rank == 4 and c.network.alpha == 1.0 and c.save.name == "age_alpha1.0_rank4_noxattn"
+
+
+def test_optimizer_options_and_rejections():
+    from sliders_amd.cli import check_supported, optimizer_options
+    assert optimizer_options(_cfg().train) == {"betas": (0.9, 0.999), "eps": 1e-8, "weight_decay": 0.01}
+    o = optimizer_options(_cfg(optimizer="adamw", optimizer_args="weight_decay=0.1 betas=(0.8,0.99) eps=1e-6").train)
+    assert o == {"betas": (0.8, 0.99), "eps": 1e-6, "weight_decay": 0.1}
+    assert optimizer_options(_cfg(optimizer="adam").train)["weight_decay"] == 0.0
+    for bad in (dict(optimizer="lion"), dict(optimizer="prodigy"), dict(optimizer="adam8bit"),
+                dict(optimizer="adam", optimizer_args="weight_decay=0.01"), dict(optimizer_args="amsgrad=True"),
+                dict(precision="float32"), dict(precision="fp16"), dict(noise_scheduler="euler_a"),
+                dict(lr_scheduler="linear")):
+        with pytest.raises(NotImplementedError):
+            check_supported(_cfg(**bad))
+    with pytest.raises(ValueError):
+        check_supported(_cfg(lr_scheduler="nope"))
+    c = _cfg()
+    c.pretrained_model.v_pred = True
+    with pytest.raises(NotImplementedError):
+        check_supported(c)
+    check_supported(_cfg(lr_scheduler="cosine", optimizer="adam"))
+
+
+@pytest.mark.parametrize("name", ["constant", "cosine", "cosine_with_restarts", "step"])
+def test_lr_schedule_follows_the_torch_scheduler(name):
+    """The host-side schedule hands slh_adamw, at iteration i, the lr torch's scheduler would have set after i calls of
+    lr_scheduler.step() (train_lora_xl.py:346-347)."""
+    from sliders_amd.cli import LrSchedule
+    from sliders_amd.train_util import get_lr_scheduler
+    lr0, n = 2e-4, 300
+    sch = LrSchedule(name, lr0, n)
+    prm = torch.nn.Parameter(torch.zeros(3))
+    opt = torch.optim.AdamW([prm], lr=lr0)
+    ref = get_lr_scheduler(name, opt, max_iterations=n, lr_min=lr0 / 100)
+    seen = []
+    for i in range(n):
+        assert sch.current() == pytest.approx(opt.param_groups[0]["lr"], rel=1e-12)
+        seen.append(sch.current())
+        opt.step()
+        ref.step()
+        sch.step()
+    if name != "constant":
+        assert min(seen) < lr0
+    else:
+        assert all(v == lr0 for v in seen)
+
+
+def test_synthetic_prompt_embeddings_are_stable_across_processes():
+    """Seeded by a stable digest of the prompt text, not by Python's per-process salted hash()."""
+    import subprocess
+    import sys
+    code = ("import sys, zlib, torch; sys.path.insert(0, %r); from sliders_amd import cli; "
+            "print(zlib.crc32('a photo of a person'.encode()) & 0xFFFFFF)" % ROOT)
+    outs = {subprocess.check_output([sys.executable, "-c", code], env=dict(os.environ, PYTHONHASHSEED=str(s))).strip()
+            for s in (1, 2)}
+    assert len(outs) == 1
+    src = open(os.path.join(ROOT, "sliders_amd", "cli.py")).read()
+    assert "hash(text)" not in src
+
+
+def test_single_file_checkpoint_is_rejected_before_loading(tmp_path):
+    from sliders_amd.cli import check_model_files
+    f = tmp_path / "model.safetensors"
+    f.write_bytes(b"\0")
+    with pytest.raises(NotImplementedError, match="diffusers-format model directory"):
+        check_model_files(str(f))
+    check_model_files(str(tmp_path))      # a directory passes this gate (the loader then validates its contents)

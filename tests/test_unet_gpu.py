@@ -6,9 +6,10 @@ Tolerance.  BASELINE.json asks for "within 1e-3 bf16".  A literal 1e-3 absolute 
 resolution of the output itself (ulp(0.5) = 2e-3) and below the error of the reference's own bf16 arithmetic:
 the oracle run in torch bf16 (the reference's precision) differs from the fp32 oracle by rel-L2 ~1e-2 on these
 nets.  The test therefore measures BOTH arms against the fp32 oracle and requires
-    rel_l2(engine, fp32) <= 1.5 * rel_l2(torch_bf16, fp32) + 2e-3
-i.e. the HIP path is at least as close to exact arithmetic as the reference's own bf16 path (it is usually
-closer: fused epilogues round once where the reference rounds per op).  Mean-abs error is printed too.
+    rel_l2(engine, fp32) <= rel_l2(torch_bf16, fp32) + 3e-4          (3e-4 = run-to-run noise of either arm)
+    max|engine - fp32|   <= 2.8e-2                                    (1.3 x the largest value measured on MI355X)
+i.e. the HIP path is at least as close to exact arithmetic as the reference's own bf16 path (it is closer in
+every measured case: fused epilogues round once where the reference rounds per op).
 """
 import pytest
 import torch
@@ -53,7 +54,8 @@ def check(name, got, e32, ebf):
     print(f"[parity] {name}: engine rel_l2={r_eng:.3e} mean_abs={(got - e32).abs().mean():.3e} max_abs={(got - e32).abs().max():.3e}"
           f" | torch-bf16 arm rel_l2={r_ref:.3e} max_abs={(ebf - e32).abs().max():.3e} | eps rms={e32.pow(2).mean().sqrt():.3f}")
     assert torch.isfinite(got).all()
-    assert r_eng <= 1.5 * r_ref + 2e-3, f"{name}: engine error {r_eng:.3e} vs reference-precision arm {r_ref:.3e}"
+    assert r_eng <= r_ref + 3e-4, f"{name}: engine error {r_eng:.3e} vs reference-precision arm {r_ref:.3e}"
+    assert (got - e32).abs().max().item() <= 2.8e-2, f"{name}: max abs error {(got - e32).abs().max().item():.3e}"
 
 
 @pytest.mark.parametrize("name,hw", [("tiny_sdxl", 16), ("tiny_sd1", 16), ("tiny_sdxl", 24)])
@@ -170,4 +172,4 @@ def test_full_size_forward_parity(dev, name):
     print(f"[parity] full-size {name} 256x256: engine rel_l2={r:.3e} max_abs={(got - e32).abs().max():.3e} "
           f"eps rms={e32.pow(2).mean().sqrt():.3f} (fp32 oracle forward {time.time() - t0:.1f}s on {os.cpu_count()} cores)")
     assert torch.isfinite(got).all()
-    assert r < 3e-2
+    assert r < 1.1e-2 and (got - e32).abs().max().item() < 1.9e-2      # measured 7.9e-3 / 8.3e-3 and 1.25e-2 / 1.41e-2
