@@ -146,7 +146,7 @@ def get_timestep_embedding(timesteps: torch.Tensor, embedding_dim: int,
                            max_period: int = 10000) -> torch.Tensor:
     """Sinusoidal embedding, computed in fp32."""
     half_dim = embedding_dim // 2
-    exponent = -math.log(max_period) * torch.arange(0, half_dim, dtype=torch.float32)
+    exponent = -math.log(max_period) * torch.arange(0, half_dim, dtype=torch.float32, device=timesteps.device)
     exponent = exponent / (half_dim - downscale_freq_shift)
     emb = torch.exp(exponent)
     emb = timesteps[:, None].float() * emb[None, :]

@@ -1,0 +1,141 @@
+"""In-situ tile tuner for slh_gemm: every candidate tile is timed INSIDE the pass it will run in (the whole program is
+replayed op by op with a HIP event pair around every GEMM, so weights are cold and activations warm exactly as in
+production), for the LoRA-on pass, the B=3 frozen pass, the training forward and the backward.  Writes
+sliders_amd/tuning/<name>.json (keys: sliders_amd.tuning.gemm_key(d, with_lora=True)).  Development tool; GPU box."""
+import argparse
+import json
+import os
+import sys
+from collections import defaultdict
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ["SLIDERS_NO_TUNING"] = "1"          # plans are built with the library heuristic; tiles are set here
+import torch
+
+from sliders_amd import lib
+from sliders_amd.config import CONFIGS
+from sliders_amd.lora_store import LoraStore
+from sliders_amd.random_init import random_state_dict
+from sliders_amd.tuning import gemm_key
+from sliders_amd.unet import UNetEngine
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--model", default="sdxl")
+ap.add_argument("--hw", type=int, default=128)
+ap.add_argument("--out", default=None)
+ap.add_argument("--reps", type=int, default=2)
+ap.add_argument("--tiles", default="11,12,21,22,4011,4012,4022,322,422,412,421,4412,4322,4411")
+ap.add_argument("--fwd-only", action="store_true")
+args = ap.parse_args()
+
+dev = torch.device("cuda:0")
+cfg = CONFIGS[args.model]()
+eng = UNetEngine(cfg, random_state_dict(cfg, dev, 0), dev)
+store = LoraStore(cfg, device=dev)
+store.params.add_(0.01)
+eng.attach_lora(store)
+hw = args.hw
+stream = torch.cuda.current_stream()
+s = stream.cuda_stream
+
+
+def inputs(B):
+    x = torch.randn(B, 4, hw, hw, device=dev)
+    ctx = torch.randn(B, 77, cfg.cross_attention_dim, device=dev)
+    kw = {"text_embeds": torch.randn(B, cfg.pooled_dim, device=dev),
+          "time_ids": torch.tensor([[hw * 8.0, hw * 8.0, 0, 0, hw * 8.0, hw * 8.0]] * B, device=dev)} if cfg.is_xl else None
+    return x, ctx, kw
+
+
+def launch(op, d):
+    if op in lib._ENTRY:
+        lib.call(op, d, s)
+    else:
+        one = lib.Program()
+        one.add(op, d)
+        one.run(s)
+
+
+def valid(d, tile):
+    mi, ni, wm = (tile >> 4) & 15, tile & 15, (tile >> 12) & 15
+    if d.geglu and ni != 2:
+        return False
+    if wm == 4 and d.M * d.N < 256 * 128 * 32:
+        return False
+    return True
+
+
+programs = []
+eng.set_lora(True, 1.0)
+x, ctx, kw = inputs(2)
+eng(x, torch.tensor(500), ctx, kw, mode="on")
+programs.append(("on", eng.plan(2, hw, hw, "on").prog))
+if not args.fwd_only:
+    eng(x, torch.tensor(500), ctx, kw, mode="train")
+    eng.run_backward(d_eps=torch.randn(1, 4, hw, hw, device=dev) * 1e-3)
+    ptr = eng.plan(2, hw, hw, "train")
+    programs.append(("train", ptr.prog))
+    programs.append(("backward", ptr.backward.prog))
+eng.set_lora(False)
+x3, ctx3, kw3 = inputs(3)
+eng(x3, torch.tensor(500), ctx3, kw3, mode="off")
+programs.append(("off3", eng.plan(3, hw, hw, "off").prog))
+torch.cuda.synchronize()
+
+tiles = [int(t, 16) for t in args.tiles.split(",")]
+best_table = {}
+for pname, prog in programs:
+    eng.set_lora(pname != "off3", 1.0)
+    if pname == "off3":
+        eng(x3, torch.tensor(500), ctx3, kw3, mode="off")
+    elif pname in ("train", "backward"):
+        eng(x, torch.tensor(500), ctx, kw, mode="train")
+    else:
+        eng(x, torch.tensor(500), ctx, kw, mode="on")
+    gemms = [(i, d) for i, (op, d) in enumerate(prog.ops) if op == lib.OP_GEMM]
+    orig = {i: d.tile for i, d in gemms}
+    times = defaultdict(lambda: defaultdict(float))      # key -> tile -> total us over the program
+    counts = defaultdict(int)
+    for i, d in gemms:
+        counts[gemm_key(d, True)] += 1
+    for tile in [None] + tiles:
+        for i, d in gemms:
+            d.tile = orig[i] if (tile is None or not valid(d, tile)) else tile
+        for rep in range(args.reps + 1):
+            recs = []
+            for op, d in prog.ops:
+                if op == lib.OP_GEMM:
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record(stream)
+                    launch(op, d)
+                    e1.record(stream)
+                    recs.append((d, e0, e1))
+                else:
+                    launch(op, d)
+            torch.cuda.synchronize()
+            if rep == 0:
+                continue                        # first replay with a new tile set: warm-up
+            for d, e0, e1 in recs:
+                if tile is None or valid(d, tile):
+                    times[gemm_key(d, True)][tile if tile is not None else -1] += e0.elapsed_time(e1) * 1e3 / args.reps
+    for i, d in gemms:
+        d.tile = orig[i]
+    tot_h = tot_b = 0.0
+    print(f"== {pname}: {len(gemms)} GEMM launches, {len(counts)} shapes")
+    for key, tt in sorted(times.items(), key=lambda kv: -kv[1][-1]):
+        cand = {t: v for t, v in tt.items() if t != -1}
+        bt = min(cand, key=cand.get)
+        tot_h += tt[-1]
+        tot_b += cand[bt]
+        best_table[key] = bt if key not in best_table else best_table[key]
+        line = "  ".join(f"{t:x}:{v / counts[key]:.1f}" for t, v in sorted(cand.items(), key=lambda kv: kv[1])[:5])
+        print(f"  {key:48s} x{counts[key]:4d}  heur {tt[-1] / counts[key]:7.1f}us | {line}")
+        best_table[key] = bt
+    print(f"  total: heuristic {tot_h / 1e3:.2f} ms, best-per-shape {tot_b / 1e3:.2f} ms", flush=True)
+
+out = args.out or os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "sliders_amd", "tuning",
+                               f"gfx950_{args.model}_{hw}_insitu.json")
+os.makedirs(os.path.dirname(out), exist_ok=True)
+with open(out, "w") as f:
+    json.dump(best_table, f, indent=0, sort_keys=True)
+print("wrote", out)

@@ -51,6 +51,21 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
+// The same copy issued from inline asm, i.e. INVISIBLE to hipcc's s_waitcnt bookkeeping.  An LDS-DMA that the compiler
+// can see makes it treat the LGKM counter as out-of-order ("pending flat"), and every ds_read consumer in the loop
+// then waits lgkmcnt(0) - which drains the fragment reads a software-pipelined K loop wants to keep in flight
+// (checked in the ISA: counted lgkmcnt(4/5) appear only once the LDS-DMA is hidden).  The caller owns the vmcnt
+// accounting (counted s_waitcnt vmcnt(N) + s_barrier before the data is read).  M0 (the LDS destination base) is
+// written and consumed inside the one statement; kernels that use this helper must not ALSO use the compiler-visible
+// glds16 in the same loop (the compiler assumes it owns M0 between its own LDS-DMA instructions).
+// lds_byte_addr must be wave-uniform.
+__device__ __forceinline__ void glds16_hidden(const void* gsrc, unsigned lds_byte_addr) {
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gsrc), "s"(lds_byte_addr) : "memory");
+}
+__device__ __forceinline__ unsigned lds_addr_of(const void* p) {
+    return (unsigned)(uintptr_t)(const __attribute__((address_space(3))) char*)p;
+}
+
 // ---- host side -------------------------------------------------------------------------------
 void slh_set_error(const char* fmt, ...);
 #define SLH_CHECK(cond, ...)            \

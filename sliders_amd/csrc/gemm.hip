@@ -19,6 +19,7 @@
 #include "common.h"
 #include <cstdlib>
 #include <cstdint>
+#include <type_traits>
 #include "../../include/sliders_hip.h"
 
 namespace {
@@ -248,21 +249,204 @@ __global__ __launch_bounds__(128 * WM, gemm_waves_per_simd(MI, NI, STAGES, LORA,
         }
         if (p.probe & 4) return;
     } else {
-        // 3-deep ring: tile kt+1 stays in flight across the barrier (counted vmcnt, raw s_barrier), tile kt+2
-        // is issued right after it.  A wave's own glds for tile kt are retired by vmcnt(L); the barrier then
-        // guarantees every wave's share has landed and that nobody still reads the slot being refilled.
-        constexpr int L = XI + WI + (LORA ? 1 : 0);   // LDS-DMA instructions per wave per stage
-        stage(0, 0);
-        if (nk > 1) stage(1, 1);
-        int cur = 0;
-        for (int kt = 0; kt < nk; ++kt) {
-            if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(L) : "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            if (kt + 2 < nk) stage(cur >= 1 ? cur - 1 : 2, kt + 2);
-            compute(cur);
-            cur = cur == 2 ? 0 : cur + 1;
+        // ---- deep LDS ring (STAGES = 3 or 4 slots), for launches that leave ONE workgroup per CU -----------------
+        // A CU with a single resident workgroup hides nothing behind other workgroups: with the 2-slot loop above
+        // every K tile pays a full L2/HBM round trip (measured: fill alone = 1340 clk per 32 KB tile, i.e. 24 B/clk
+        // of the 64 B/clk the CU can pull) and the first ds_read latency of each tile.  Here
+        //   * S-2 whole K tiles are kept in flight (LDS-DMA outstanding across barriers, counted vmcnt),
+        //   * the MFMA fragments are software-pipelined across k-steps AND across K tiles (the fragments of step
+        //     ks+1 - or of the next tile's step 0 - are requested before the MFMAs of step ks issue),
+        //   * ONE raw s_barrier per K tile sits in the middle of the tile (after k-step 1).
+        // Protocol for K tile g (slot g % S), all counts per wave:
+        //   ks0, ks1 : MFMAs of (g,0), (g,1); fragment reads of (g,1), (g,2)
+        //   sync     : s_waitcnt vmcnt((S-3)*L) -> this wave's share of tile g+1 has landed (tiles g+2.. stay in
+        //              flight); s_barrier -> every wave's share has, and every wave is past its last read of tile g-1
+        //   ks2, ks3 : MFMAs of (g,2), (g,3); fragment reads of (g,3), (g+1,0); LDS-DMA of tile g+S-1 into the slot
+        //              tile g-1 occupied, half of the pieces behind each k-step's reads
+        // The source pointers of the L pieces are running pointers (advanced once per K tile; re-based when the
+        // implicit GEMM moves to the next filter tap or the second concat source), so a piece costs one 64-bit add.
+        constexpr int S = STAGES;
+        constexpr int L = XI + WI + (LORA ? 1 : 0);   // LDS-DMA instructions per wave per K tile
+        constexpr int H0 = (L + 1) / 2;               // pieces issued behind k-step 2 (the rest behind k-step 3)
+        const char* xsrc[XI];
+        int xadv[XI];
+        const char* wsrc[WI];
+        const char* lsrc = nullptr;
+        int ladv = 0;
+#pragma unroll
+        for (int i = 0; i < WI; ++i) wsrc[i] = (const char*)wptr[i];
+        if (LORA) {
+            const int row = (wave & 3) * 8 + frow;
+            const bool ok = row < p.lora_rank;
+            lsrc = ok ? (const char*)(p.lora_down + (long)row * p.K + ((fslot ^ ((row >> 1) & 7)) << 3))
+                      : (const char*)slh_zero_page;
+            ladv = ok ? 128 : 0;
         }
+        int i_kt = 0, i_c0 = 0, i_tap = 0;             // K tile the next issue belongs to; its channel offset / filter tap
+        const unsigned lds0 = lds_addr_of(smem);
+        const int wkbytes = wkstep * 2;
+
+        // (re)base the X pointers of the tile at (i_tap, i_c0); called when a tap or a concat source begins
+        auto rebase_x = [&]() {
+            const bool s1 = i_c0 >= p.ca0;
+            const __bf16* base = s1 ? p.a1 : p.a0;
+            const int cc = s1 ? i_c0 - p.ca0 : i_c0;
+            if (MODE == 0) {
+#pragma unroll
+                for (int i = 0; i < XI; ++i) {
+                    xsrc[i] = (const char*)(base + (s1 ? xrow_off1[i] : xrow_off0[i]) + cc + (xks[i] << 3));
+                    xadv[i] = 128;
+                }
+            } else {
+                const int ld = s1 ? p.lda1 : p.lda0;
+                const int ky = i_tap / 3, kx = i_tap - ky * 3;
+                const int sh = p.src_xform ? 1 : 0;
+                const int HL = p.hs << sh, WL = p.ws << sh;
+#pragma unroll
+                for (int i = 0; i < XI; ++i) {
+                    const int iy = xoy[i] * p.stride + ky - 1;
+                    const int ix = xox[i] * p.stride + kx - 1;
+                    bool ok = (iy >= 0) & (iy < HL) & (ix >= 0) & (ix < WL);
+                    if (p.src_xform == 2) ok = ok & (((iy | ix) & 1) == 0);
+                    const int sy = iy >> sh, sx = ix >> sh;
+                    const long pix = ((long)xb[i] * p.hs + sy) * p.ws + sx;
+                    xsrc[i] = ok ? (const char*)(base + pix * ld + cc + (xks[i] << 3)) : (const char*)slh_zero_page;
+                    xadv[i] = ok ? 128 : 0;
+                }
+            }
+        };
+        // LDS-DMA piece j (order: X, W, LoRA) of K tile i_kt into ring slot `slot`
+        auto piece = [&](const int j, const int slot) {
+#if defined(SLH_RING_PROBE) && (SLH_RING_PROBE & 1)
+            if (i_kt >= S - 1) return;                 // ablation: no LDS-DMA after the prologue
+#endif
+            if (j < XI) {
+                glds16_hidden(xsrc[j], lds0 + slot * (BM * 128) + (wave + NW * j) * 1024);
+                xsrc[j] += xadv[j];
+            } else if (j < XI + WI) {
+                const int i = j - XI;
+                glds16_hidden(wsrc[i], lds0 + STAGES * BM * 128 + slot * (BN * 128) + (wave + NW * i) * 1024);
+                wsrc[i] += wkbytes;
+            } else {
+                glds16_hidden(lsrc, lds0 + STAGES * (BM + BN) * 128 + slot * (32 * 128) + (wave & 3) * 1024);
+                lsrc += ladv;
+            }
+        };
+        auto tile_begin = [&]() { if (i_c0 == 0 || i_c0 == p.ca0) rebase_x(); };
+        auto tile_end = [&]() {
+            ++i_kt;
+            i_c0 += BK;
+            if (MODE == 1 && i_c0 == cin) { i_c0 = 0; ++i_tap; }
+        };
+        auto issue_all = [&](const int slot) {
+            tile_begin();
+#pragma unroll
+            for (int j = 0; j < L; ++j) piece(j, slot);
+            tile_end();
+        };
+
+        bf16x8 xf[2][MI], wf[2][NI], lf[2];
+        auto load_frags = [&](const int set, const int slot, const int ks) {
+#if defined(SLH_RING_PROBE) && (SLH_RING_PROBE & 4)
+            return;                                    // ablation: no fragment reads
+#endif
+            const char* cX = sX + slot * (BM * 128);
+            const char* cW = sW + slot * (BN * 128);
+            if (LORA) lf[set] = *(const bf16x8*)(sL + slot * (32 * 128) + lds_off(lrow, ks * 2 + lhi));
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+                xf[set][i] = *(const bf16x8*)(cX + lds_off(wm * (32 * MI) + i * 32 + lrow, ks * 2 + lhi));
+#pragma unroll
+            for (int j = 0; j < NI; ++j)
+                wf[set][j] = *(const bf16x8*)(cW + lds_off(wn * (32 * NI) + j * 32 + lrow, ks * 2 + lhi));
+        };
+        // the MFMAs of one k-step; with ISSUE, the LDS-DMA pieces [p0, p1) of the tile being staged are dealt out behind
+        // them one at a time, so each piece's ~7 scalar/vector instructions issue in the shadow of a 32-cycle MFMA
+        constexpr int NMF = MI * NI + (LORA ? MI : 0);
+        auto mfmas = [&](const int set, const bool with_pieces, const int p0, const int p1, const int slot) {
+            const int per = with_pieces ? (p1 - p0 + NMF - 1) / NMF : 0;
+            int m = 0;
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+#pragma unroll
+                for (int j = 0; j < NI + (LORA ? 1 : 0); ++j) {
+#if defined(SLH_RING_PROBE) && (SLH_RING_PROBE & 2)
+                    if (j < NI) asm volatile("" ::"v"(wf[set][j]), "v"(xf[set][i]));      // ablation: no MFMA (fragments stay live)
+                    else asm volatile("" ::"v"(lf[set]), "v"(xf[set][i]));
+#else
+                    if (j < NI) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[set][j], xf[set][i], acc[i][j], 0, 0, 0);
+                    else accl[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lf[set], xf[set][i], accl[i], 0, 0, 0);
+#endif
+                    if (with_pieces) {
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int q = 0; q < per; ++q)
+                            if (p0 + m * per + q < p1) piece(p0 + m * per + q, slot);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    ++m;
+                }
+            }
+        };
+
+        // prologue: tiles 0 .. S-2 in flight, tile 0 landed, its first fragments requested
+        for (int t = 0; t < S - 1; ++t) {
+            if (t < nk) issue_all(t);
+        }
+        if (nk >= S - 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((S - 2) * L) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        load_frags(0, 0, 0);
+        __builtin_amdgcn_s_waitcnt(0xC07F);            // lgkmcnt(0): nothing pending when the loop is entered
+        int cur = 0;
+        // one K tile; MORE: a next tile exists, ISSUE: tile g+S-1 exists, KEEP: tile g+2 exists (its LDS-DMA may stay in
+        // flight across the barrier).  The flags are compile-time so that the steady-state body is straight-line code:
+        // hipcc's waitcnt insertion falls back to lgkmcnt(0) at control-flow joins, which would expose the latency of
+        // the fragment reads it was asked to keep in flight.
+        auto body = [&](auto more_c, auto issue_c, auto keep_c) {
+            constexpr bool MORE = decltype(more_c)::value, ISSUE = decltype(issue_c)::value, KEEP = decltype(keep_c)::value;
+            const int nxt = cur == S - 1 ? 0 : cur + 1;
+            const int prv = cur == 0 ? S - 1 : cur - 1;
+            __builtin_amdgcn_sched_barrier(0);
+            load_frags(1, cur, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            mfmas(0, false, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            load_frags(0, cur, 2);
+            __builtin_amdgcn_sched_barrier(0);
+            mfmas(1, false, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (MORE) {
+                if constexpr (S >= 4 && KEEP) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((S - 3) * L) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            load_frags(1, cur, 3);
+            if constexpr (ISSUE) tile_begin();
+            __builtin_amdgcn_sched_barrier(0);
+            mfmas(0, ISSUE, 0, H0, prv);
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (MORE) load_frags(0, nxt, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            mfmas(1, ISSUE, H0, L, prv);
+            if constexpr (ISSUE) tile_end();
+            __builtin_amdgcn_sched_barrier(0);
+            // the fragments requested before the last four MFMAs have landed long before those MFMAs have issued; saying
+            // so here leaves nothing pending across the loop edge (where the compiler would otherwise wait lgkmcnt(0)
+            // AFTER the next k-step's reads have been issued)
+            __builtin_amdgcn_s_waitcnt(0xC07F);
+            cur = nxt;
+        };
+        using T_ = std::true_type;
+        using F_ = std::false_type;
+        int g = 0;
+        for (; g + S - 1 < nk; ++g) body(T_{}, T_{}, T_{});
+        if constexpr (S >= 4) {
+            if (g + 2 < nk) { body(T_{}, F_{}, T_{}); ++g; }
+        }
+        if (g + 1 < nk) { body(T_{}, F_{}, F_{}); ++g; }
+        if (g < nk) body(F_{}, F_{}, F_{});
     }
 
     // ---- epilogue ---------------------------------------------------------------------------------
@@ -433,9 +617,14 @@ __global__ __launch_bounds__(128 * WM, gemm_waves_per_simd(MI, NI, STAGES, LORA,
 template <int MI, int NI, int MODE, bool LORA, int WM>
 int launch_gemm3(const GemmArgs& a, int stages, hipStream_t s) {
     const int grid = a.tiles_m * a.tiles_n;
-    constexpr int lds3 = 3 * (32 * MI * WM + 64 * NI + (LORA ? 32 : 0)) * 128;
-    constexpr bool can3 = lds3 <= 160 * 1024 && (WM == 4 || MI + NI <= 3);
-    if (stages == 3 && can3)
+    constexpr int stage_bytes = (32 * MI * WM + 64 * NI + (LORA ? 32 : 0)) * 128;
+    constexpr bool can3 = 3 * stage_bytes <= 160 * 1024;
+    constexpr bool can4 = 4 * stage_bytes <= 160 * 1024;
+    if (stages == 4 && !can4) stages = 3;          // the deepest ring that fits the 160 KB of LDS
+    if (stages == 3 && !can3) stages = 2;
+    if (stages == 4)
+        hipLaunchKernelGGL((gemm_kernel<MI, NI, MODE, (can4 ? 4 : 2), LORA, WM>), dim3(grid), dim3(128 * WM), 0, s, a);
+    else if (stages == 3)
         hipLaunchKernelGGL((gemm_kernel<MI, NI, MODE, (can3 ? 3 : 2), LORA, WM>), dim3(grid), dim3(128 * WM), 0, s, a);
     else
         hipLaunchKernelGGL((gemm_kernel<MI, NI, MODE, 2, LORA, WM>), dim3(grid), dim3(128 * WM), 0, s, a);

@@ -11,7 +11,7 @@ import os
 from typing import Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsliders_hip.so")
+LIB_PATH = os.environ.get("SLIDERS_HIP_LIB") or os.path.join(_HERE, "libsliders_hip.so")   # override: development builds
 
 c_i32, c_i64, c_f32, c_f64, c_vp = C.c_int32, C.c_int64, C.c_float, C.c_double, C.c_void_p
 

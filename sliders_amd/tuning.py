@@ -13,8 +13,11 @@ from typing import Dict, Optional
 _TABLE: Optional[Dict[str, int]] = None
 
 
-def gemm_key(d) -> str:
-    return f"{d.M},{d.N},{d.K},m{d.mode},s{d.stride},x{d.src_xform},g{d.geglu}"
+def gemm_key(d, with_lora: bool = False) -> str:
+    k = f"{d.M},{d.N},{d.K},m{d.mode},s{d.stride},x{d.src_xform},g{d.geglu}"
+    if with_lora:     # the fused adapter changes the LDS footprint and the MFMA count per k-step: tuned separately
+        k += f",l{1 if d.lora_down else 0}"
+    return k
 
 
 def table() -> Dict[str, int]:
@@ -32,7 +35,8 @@ def tuned_tile(d) -> int:
     """0 = no entry (library heuristic)."""
     if os.environ.get("SLIDERS_NO_TUNING"):
         return 0
-    t = table().get(gemm_key(d), 0)
+    tb = table()
+    t = tb.get(gemm_key(d, True), tb.get(gemm_key(d), 0))
     force = os.environ.get("SLIDERS_FORCE_STAGES")     # experiment knob: 2 or 3 for every non-128x128 tile
     if force and t and (t & 0xFF) != 0x22:
         t = (t & 0xFF) | (int(force) << 8 if force == "3" else 0)

@@ -49,7 +49,8 @@ class UNetEngine:
         self.dtype = torch.bfloat16
         self.lora: Optional[LoraStore] = None
         self.lora_active = False
-        self.lora_scale = torch.zeros(1, dtype=torch.float32, device=self.device)
+        self.lora_scale = torch.zeros(1, dtype=torch.float32, device=self.device)   # multiplier * alpha / rank, read by the kernels
+        self.lora_scale_host = 0.0
         self._plans: Dict[Tuple, UNetPlan] = {}
         self._arena_bytes = arena_bytes
         self.arena: Optional[Arena] = None
@@ -80,7 +81,8 @@ class UNetEngine:
     def set_lora(self, active: bool, multiplier: float = 1.0):
         self.lora_active = bool(active) and self.lora is not None
         if self.lora is not None:
-            self.lora_scale.fill_(float(multiplier) * self.lora.scale if active else 0.0)
+            self.lora_scale_host = float(multiplier) * self.lora.scale if active else 0.0
+            self.lora_scale.fill_(self.lora_scale_host)
 
     # ---- planning ---------------------------------------------------------------------------------
     def _virtual_size(self, B, H, W, mode) -> int:
@@ -196,6 +198,10 @@ class _EpsBridge(torch.autograd.Function):
     @staticmethod
     def forward(ctx, flat_param, eps, engine, plan):
         ctx.engine, ctx.plan = engine, plan
+        # the adapter scale is an input of the backward kernels too (dA, dB carry a factor multiplier*alpha/rank); the
+        # reference calls loss.backward() AFTER leaving `with network:` (train_lora_xl.py:302-345), where the live
+        # multiplier is 0 again, so the value of the forward is recorded here like autograd records it
+        ctx.scale = engine.lora_scale_host
         return eps.view_as(eps)
 
     @staticmethod
@@ -207,7 +213,10 @@ class _EpsBridge(torch.autograd.Function):
             raise RuntimeError("non-zero gradient on the unconditional half: build the engine plan with "
                                "engine.grad_all_samples = True")
         eng.lora.grads.zero_()
+        live = eng.lora_scale_host
+        eng.lora_scale.fill_(ctx.scale)
         eng.run_backward(p, d_eps=g[b0:b0 + nb])
+        eng.lora_scale.fill_(live)
         return eng.lora.grads.to(torch.bfloat16), None, None, None
 
 

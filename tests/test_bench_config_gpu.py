@@ -71,7 +71,7 @@ def _fwd(net, x, t, ctx, kw, dtype, device):
     kwd = {k: v.to(torch.bfloat16).to(device=device, dtype=dtype) for k, v in kw.items()} if kw else None
     r = lambda a: a.to(torch.bfloat16).to(device=device, dtype=dtype)     # every arm sees the same bf16-rounded inputs
     with torch.no_grad():
-        return net(r(x), torch.tensor(t), r(ctx), kwd).sample.float().cpu()
+        return net(r(x), torch.tensor(t, device=device), r(ctx), kwd).sample.float().cpu()
 
 
 def _check(name, got, e32, ebf, max_abs_bound):
@@ -84,9 +84,10 @@ def _check(name, got, e32, ebf, max_abs_bound):
     assert m_eng <= max_abs_bound, f"{name}: max abs error {m_eng:.3e} > {max_abs_bound:.1e}"
 
 
-@pytest.mark.parametrize("name,hw,need_gb,bound", [("sdxl", 128, 30, 3.0e-2), ("sd1", 64, 12, 3.0e-2)])
+@pytest.mark.parametrize("name,hw,need_gb,bound", [("sdxl", 128, 30, 1.85e-2), ("sd1", 64, 12, 2.0e-2)])
 def test_bench_config_forward_parity(dev, name, hw, need_gb, bound):
-    """BASELINE configs[2] (SDXL 1024^2) and configs[1] (SD-1.x 512^2): adapters off and adapters on."""
+    """BASELINE configs[2] (SDXL 1024^2) and configs[1] (SD-1.x 512^2): adapters off and adapters on.
+    Measured on MI355X: SDXL rel_l2 8.3e-3 (bf16 arm 1.04e-2), max abs 1.42e-2; SD-1.x 9.6e-3 (1.13e-2), 1.54e-2."""
     if _host_ram_gb() < need_gb:
         pytest.skip(f"fp32 oracle needs ~{need_gb} GB of host RAM")
     cfg = CONFIGS[name]()
@@ -180,7 +181,7 @@ def test_full_width_lora_gradients(dev, name, hw, need_gb):
         r = lambda a: a.to(torch.bfloat16).to(device=device, dtype=dtype)
         kk = {k: r(v) for k, v in kw.items()} if kw else None
         with nw:
-            eps = net(r(x), torch.tensor(600), r(ctx), kk).sample
+            eps = net(r(x), torch.tensor(600, device=device), r(ctx), kk).sample
         (eps[1:].float() * G.to(device)).sum().backward()
         return _flat_grads(store, nw)
 

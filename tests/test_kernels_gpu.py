@@ -40,7 +40,8 @@ def _pack_conv(w):
     return w.permute(0, 2, 3, 1).reshape(w.shape[0], -1).contiguous()
 
 
-@pytest.mark.parametrize("tile", [0x22, 0x21, 0x12, 0x11, 0x321, 0x312, 0x311, 0x4022, 0x4322, 0x4012, 0x4312, 0x4011])
+@pytest.mark.parametrize("tile", [0x22, 0x21, 0x12, 0x11, 0x321, 0x312, 0x311, 0x4022, 0x4322, 0x4012, 0x4312, 0x4011,
+                                  0x322, 0x422, 0x421, 0x412, 0x411, 0x4422, 0x4412, 0x4411])
 @pytest.mark.parametrize("M,N,K", [(256, 128, 64), (300, 320, 320), (1024, 640, 1280), (154, 256, 2048)])
 def test_gemm_dense(dev, M, N, K, tile):
     torch.manual_seed(M + N + K)
@@ -57,7 +58,7 @@ def test_gemm_dense(dev, M, N, K, tile):
     report(f"gemm_dense M{M} N{N} K{K} tile{tile:x}", c, ref, TOL)
 
 
-@pytest.mark.parametrize("tile", [0x22, 0x21, 0x12, 0x11, 0x311, 0x4022, 0x4012, 0x4011, 0x4312])
+@pytest.mark.parametrize("tile", [0x22, 0x21, 0x12, 0x11, 0x311, 0x4022, 0x4012, 0x4011, 0x4312, 0x422, 0x412, 0x4412, 0x4322])
 def test_gemm_packed_weights(dev, tile):
     """w_layout = 1: the frozen weights in the tile-packed, pre-swizzled order (sliders_amd.weights.pack_gemm_w)."""
     from sliders_amd.weights import pack_gemm_w
@@ -91,7 +92,8 @@ def test_gemm_packed_weights(dev, tile):
     report(f"conv_packed tile{tile:x}", c, _to_pix(ref_img), TOL)
 
 
-def test_gemm_two_source_rowbias_lora(dev):
+@pytest.mark.parametrize("tile", [0, 0x422, 0x4412, 0x4322, 0x312])
+def test_gemm_two_source_rowbias_lora(dev, tile):
     torch.manual_seed(1)
     B, HW, C0, C1, N = 2, 160, 128, 64, 320
     M, K = B * HW, C0 + C1
@@ -108,7 +110,7 @@ def test_gemm_two_source_rowbias_lora(dev):
         d = lib.GemmDesc(a0=p(x0), a1=x1.data_ptr(), w=p(w), rowbias=rb.data_ptr() + 2 * 64, lora_t=p(T),
                          lora_up=p(up), lora_scale=p(scale), c=p(c), lda0=C0, lda1=2 * C1, ca0=C0, ca1=C1, mode=0,
                          stride=1, ldw=K, M=M, N=N, K=K, ld_rowbias=512, rows_per_sample=HW, ld_t=4 * groups,
-                         lora_groups=groups, ldc=N, tile=0)
+                         lora_groups=groups, ldc=N, tile=tile)
         lib.call(lib.OP_GEMM, d, stream())
         torch.cuda.synchronize()
         xcat = torch.cat([x0.float(), x1.float()], 1)
@@ -129,7 +131,7 @@ def test_gemm_geglu(dev):
     b = bf(torch.randn(N, device=dev))
     from sliders_amd.weights import _geglu_perm
     wp, bp = _geglu_perm(w), _geglu_perm(b)
-    for tile in (0x22, 0x12, 0x4022, 0x4312):
+    for tile in (0x22, 0x12, 0x4022, 0x4312, 0x422, 0x412, 0x4412, 0x4322):
         c = torch.zeros(M, n_out, device=dev, dtype=torch.bfloat16)
         d = lib.GemmDesc(a0=p(x), w=p(wp), bias=p(bp), c=p(c), lda0=K, ca0=K, mode=0, stride=1, ldw=K, M=M, N=N, K=K,
                          ldc=n_out, geglu=1, rows_per_sample=M, tile=tile)
@@ -163,7 +165,7 @@ def _perm_cols(g):
 
 
 @pytest.mark.parametrize("stride,xform", [(1, 0), (2, 0), (1, 1), (1, 2)])
-@pytest.mark.parametrize("tile", [0x22, 0x11, 0x312, 0x311, 0x4022, 0x4312, 0x4011])
+@pytest.mark.parametrize("tile", [0x22, 0x11, 0x312, 0x311, 0x4022, 0x4312, 0x4011, 0x422, 0x411, 0x4412, 0x4322])
 def test_gemm_conv3x3(dev, stride, xform, tile):
     torch.manual_seed(3 + stride + xform)
     B, H, W, Ci, Co = 2, 12, 20, 128, 192
@@ -184,7 +186,8 @@ def test_gemm_conv3x3(dev, stride, xform, tile):
     report(f"gemm_conv s{stride} x{xform} tile{tile:x}", c, _to_pix(ref_img), TOL)
 
 
-def test_gemm_conv_two_source_and_skinny(dev):
+@pytest.mark.parametrize("tile", [0, 0x422, 0x4412, 0x4322])
+def test_gemm_conv_two_source_and_skinny(dev, tile):
     torch.manual_seed(5)
     B, H, W, C0, C1, Co = 2, 16, 16, 128, 64, 128
     i0 = bf(torch.randn(B, C0, H, W, device=dev))
@@ -196,7 +199,7 @@ def test_gemm_conv_two_source_and_skinny(dev):
     c = torch.zeros(M, Co, device=dev, dtype=torch.bfloat16)
     d = lib.GemmDesc(a0=p(x0), a1=p(x1), w=p(_pack_conv(w4)), c=p(c), lda0=C0, lda1=C1, ca0=C0, ca1=C1, mode=1,
                      batch=B, hs=H, ws=W, stride=1, ho=H, wo=W, ldw=9 * (C0 + C1), M=M, N=Co, K=9 * (C0 + C1),
-                     ldc=Co, rows_per_sample=H * W)
+                     ldc=Co, rows_per_sample=H * W, tile=tile)
     lib.call(lib.OP_GEMM, d, stream())
     torch.cuda.synchronize()
     report("gemm_conv_2src", c, ref, TOL)
@@ -474,7 +477,7 @@ def test_lora_wgrad(dev):
     report("wgrad_conv", out, 0.25 * wd.grad.permute(0, 2, 3, 1).reshape(4, -1), 1e-4)
 
 
-@pytest.mark.parametrize("tile", [0x22, 0x21, 0x12, 0x11, 0x311, 0x4022, 0x4322, 0x4012, 0x4011])
+@pytest.mark.parametrize("tile", [0x22, 0x21, 0x12, 0x11, 0x311, 0x4022, 0x4322, 0x4012, 0x4011, 0x422, 0x421, 0x4412, 0x4411])
 def test_gemm_fused_lora_down(dev, tile):
     """LoRAModule.forward fused into one launch: y = x W^T + b + s (x A^T) B^T, T = x A^T written for backward."""
     torch.manual_seed(31)
