@@ -338,6 +338,64 @@ typedef struct slh_adamw_desc {
 int slh_adamw(const slh_adamw_desc* d, slh_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Image sliders: AutoencoderKL encoder + posterior sample + add_noise in fp32 on the GPU.
+ * Replaces trainscripts/imagesliders/train_util.py:200-235 `get_noisy_image` (vae.encode(...).latent_dist.sample()
+ * * scaling_factor -> scheduler.add_noise); the VAE arithmetic itself is diffusers' AutoencoderKL.encode.
+ * Activations are pixel-major fp32 [B*H*W][C]; 3x3 weights are [Cout][ky][kx][Cin] fp32.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct slh_sgemm_desc {
+    const void* x;          /* [M][ldx] fp32 (mode 0) or the [batch*hs*ws][ldx] source image of an implicit 3x3 GEMM (mode 1) */
+    const void* w;          /* [N][ldw] fp32 */
+    const void* bias;       /* [N] (or [M] if bias_per_row) fp32, may be NULL */
+    const void* residual;   /* [M][ldr] fp32, may be NULL */
+    void* c;                /* [M][ldc] fp32 */
+    int32_t ldx, ldw, ldr, ldc;
+    int32_t M, N, K;
+    int32_t mode;           /* 0 dense, 1 implicit 3x3 (K = 9*cin) */
+    int32_t cin, batch, hs, ws, ho, wo, stride, pad;   /* pad 1: symmetric; pad 0 with stride 2: zero pad right/bottom (Downsample2D(padding=0)) */
+    int32_t bias_per_row;
+    float alpha;            /* C = alpha * (X W^T) + bias + residual */
+} slh_sgemm_desc;
+int slh_sgemm(const slh_sgemm_desc* d, slh_stream_t stream);
+
+typedef struct slh_gn32_desc {
+    const void* x; const void* gamma; const void* beta;   /* fp32 */
+    float* stats;           /* [batch][groups][2] fp32, zeroed by the caller before slh_gn32_stats */
+    void* y;                /* [batch*hw][ldy] fp32 */
+    int32_t ldx, ldy, C, batch, hw, groups;
+    float eps;
+    int32_t act;            /* 0 none, 1 SiLU */
+} slh_gn32_desc;
+int slh_gn32_stats(const slh_gn32_desc* d, slh_stream_t stream);
+int slh_gn32_apply(const slh_gn32_desc* d, slh_stream_t stream);
+
+typedef struct slh_softmax32_desc { float* x; int64_t ld; int32_t rows, cols; } slh_softmax32_desc;   /* in place */
+int slh_softmax32(const slh_softmax32_desc* d, slh_stream_t stream);
+
+typedef struct slh_vae_conv_desc {
+    const void* x;          /* conv_in: image [batch][h*wd][3] fp32; moments: [batch*h*wd][cin] fp32 */
+    const void* w; const void* bias;      /* conv_in: [cout][3][3][3]; moments: conv_out [8][3][3][cin], [8] */
+    const void* qw; const void* qb;       /* moments only: quant_conv [8][8], [8] */
+    void* y;                /* conv_in: [batch*h*wd][cout]; moments: [batch*h*wd][8] = mean | logvar */
+    int32_t batch, h, wd, cin, cout, pad_;
+} slh_vae_conv_desc;
+int slh_vae_conv_in(const slh_vae_conv_desc* d, slh_stream_t stream);
+int slh_vae_moments(const slh_vae_conv_desc* d, slh_stream_t stream);
+
+typedef struct slh_vae_sample_desc {
+    const float* moments;       /* [batch*hw][8] */
+    const float* post_noise;    /* [batch][4][hw] NCHW: the draw of DiagonalGaussianDistribution.sample */
+    const float* noise;         /* [batch][4][hw] NCHW: the diffusion noise of add_noise */
+    float* latent_f32;          /* optional: scaling_factor * sample, NCHW */
+    float* noisy_f32;           /* optional: add_noise result, NCHW fp32 */
+    void* noisy_bf16;           /* optional: the same in bf16 (the UNet's input dtype) */
+    int32_t batch, hw;
+    float scaling, sqrt_alpha, sqrt_one_minus_alpha;
+    int32_t pad_;
+} slh_vae_sample_desc;
+int slh_vae_sample(const slh_vae_sample_desc* d, slh_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
  * program executor: a whole UNet forward / backward is a flat command buffer built once by the host
  * planner (sliders_amd/plan.py) and replayed with ONE call.  Record layout: {int32 opcode; int32
  * nbytes; desc bytes (8-byte aligned)}.
@@ -348,7 +406,8 @@ enum {
     SLH_OP_CONV_IN = 10, SLH_OP_ELEMENTWISE = 11, SLH_OP_CFG_DDIM = 12, SLH_OP_LOSS = 13,
     SLH_OP_WGRAD = 14, SLH_OP_ADAMW = 15, SLH_OP_GN_BWD_STATS = 16, SLH_OP_GN_BWD_APPLY = 17,
     SLH_OP_LAYERNORM_BWD = 18, SLH_OP_ATTN_BWD = 19, SLH_OP_MEMSET = 20, SLH_OP_LORA_CONV_DGRAD = 21,
-    SLH_OP_TEMB_LORA_BWD = 22
+    SLH_OP_TEMB_LORA_BWD = 22, SLH_OP_SGEMM = 23, SLH_OP_GN32_STATS = 24, SLH_OP_GN32_APPLY = 25, SLH_OP_SOFTMAX32 = 26,
+    SLH_OP_VAE_CONV_IN = 27, SLH_OP_VAE_MOMENTS = 28, SLH_OP_VAE_SAMPLE = 29
 };
 typedef struct slh_memset_desc { void* ptr; int64_t nbytes; int32_t value; int32_t pad; } slh_memset_desc;
 int slh_run_program(const void* program, int64_t nbytes, slh_stream_t stream);

@@ -64,6 +64,13 @@ extern "C" int slh_run_program(const void* program, int64_t nbytes, slh_stream_t
                 rc = run_desc<slh_lora_cdgrad_desc>(p, sz, slh_lora_conv_dgrad, stream, "lora_conv_dgrad"); break;
             case SLH_OP_TEMB_LORA_BWD:
                 rc = run_desc<slh_temb_lora_bwd_desc>(p, sz, slh_temb_lora_bwd, stream, "temb_lora_bwd"); break;
+            case SLH_OP_SGEMM: rc = run_desc<slh_sgemm_desc>(p, sz, slh_sgemm, stream, "sgemm"); break;
+            case SLH_OP_GN32_STATS: rc = run_desc<slh_gn32_desc>(p, sz, slh_gn32_stats, stream, "gn32_stats"); break;
+            case SLH_OP_GN32_APPLY: rc = run_desc<slh_gn32_desc>(p, sz, slh_gn32_apply, stream, "gn32_apply"); break;
+            case SLH_OP_SOFTMAX32: rc = run_desc<slh_softmax32_desc>(p, sz, slh_softmax32, stream, "softmax32"); break;
+            case SLH_OP_VAE_CONV_IN: rc = run_desc<slh_vae_conv_desc>(p, sz, slh_vae_conv_in, stream, "vae_conv_in"); break;
+            case SLH_OP_VAE_MOMENTS: rc = run_desc<slh_vae_conv_desc>(p, sz, slh_vae_moments, stream, "vae_moments"); break;
+            case SLH_OP_VAE_SAMPLE: rc = run_desc<slh_vae_sample_desc>(p, sz, slh_vae_sample, stream, "vae_sample"); break;
             case SLH_OP_MEMSET: {
                 if (sz != (int32_t)sizeof(slh_memset_desc)) { slh_set_error("slh_run_program: memset desc size"); return -3; }
                 slh_memset_desc d;
@@ -91,7 +98,9 @@ extern "C" int slh_desc_sizes(int32_t* out, int32_t cap) {
         (int32_t)sizeof(slh_attn_bwd_desc), (int32_t)sizeof(slh_tembed_desc),   (int32_t)sizeof(slh_convin_desc),
         (int32_t)sizeof(slh_ew_desc),       (int32_t)sizeof(slh_cfg_ddim_desc), (int32_t)sizeof(slh_loss_desc),
         (int32_t)sizeof(slh_wgrad_desc),    (int32_t)sizeof(slh_adamw_desc),    (int32_t)sizeof(slh_memset_desc),
-        (int32_t)sizeof(slh_lora_cdgrad_desc), (int32_t)sizeof(slh_temb_lora_bwd_desc)};
+        (int32_t)sizeof(slh_lora_cdgrad_desc), (int32_t)sizeof(slh_temb_lora_bwd_desc),
+        (int32_t)sizeof(slh_sgemm_desc),    (int32_t)sizeof(slh_gn32_desc),     (int32_t)sizeof(slh_softmax32_desc),
+        (int32_t)sizeof(slh_vae_conv_desc), (int32_t)sizeof(slh_vae_sample_desc)};
     const int n = (int)(sizeof(sizes) / sizeof(sizes[0]));
     for (int i = 0; i < n && i < cap; ++i) out[i] = sizes[i];
     return n;

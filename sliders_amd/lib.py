@@ -76,17 +76,29 @@ MemsetDesc = _struct("MemsetDesc", _ptrs("ptr") + [("nbytes", c_i64)] + _ints("v
 LoraCdgradDesc = _struct("LoraCdgradDesc", _ptrs("u", "a_down", "scale", "gx")
                          + _ints("batch", "hl", "wl", "ho", "wo", "stride", "cin", "ldu", "ldgx", "accumulate"))
 TembLoraBwdDesc = _struct("TembLoraBwdDesc", _ptrs("g", "t", "up", "emb", "d_up", "d_down", "scale") + _ints("C", "ted"))
+# image sliders: fp32 AutoencoderKL encoder (csrc/vae.hip)
+SgemmDesc = _struct("SgemmDesc", _ptrs("x", "w", "bias", "residual", "c")
+                    + _ints("ldx", "ldw", "ldr", "ldc", "M", "N", "K", "mode", "cin", "batch", "hs", "ws", "ho", "wo", "stride",
+                            "pad", "bias_per_row") + [("alpha", c_f32)])
+Gn32Desc = _struct("Gn32Desc", _ptrs("x", "gamma", "beta", "stats", "y") + _ints("ldx", "ldy", "C", "batch", "hw", "groups")
+                   + [("eps", c_f32)] + _ints("act"))
+Softmax32Desc = _struct("Softmax32Desc", _ptrs("x") + [("ld", c_i64)] + _ints("rows", "cols"))
+VaeConvDesc = _struct("VaeConvDesc", _ptrs("x", "w", "bias", "qw", "qb", "y") + _ints("batch", "h", "wd", "cin", "cout", "pad_"))
+VaeSampleDesc = _struct("VaeSampleDesc", _ptrs("moments", "post_noise", "noise", "latent_f32", "noisy_f32", "noisy_bf16")
+                        + _ints("batch", "hw") + [("scaling", c_f32), ("sqrt_alpha", c_f32), ("sqrt_one_minus_alpha", c_f32)]
+                        + _ints("pad_"))
 
 # order of slh_desc_sizes()
 _SIZE_ORDER = [GemmDesc, SkinnyDesc, GemvDesc, GnDesc, GnBwdDesc, LnDesc, LnBwdDesc, AttnDesc, TransposeDesc,
                AttnBwdDesc, TembedDesc, ConvInDesc, EwDesc, CfgDdimDesc, LossDesc, WgradDesc, AdamwDesc, MemsetDesc,
-               LoraCdgradDesc, TembLoraBwdDesc]
+               LoraCdgradDesc, TembLoraBwdDesc, SgemmDesc, Gn32Desc, Softmax32Desc, VaeConvDesc, VaeSampleDesc]
 
 # opcodes (enum in sliders_hip.h)
 OP_GEMM, OP_SKINNY, OP_GEMV, OP_GN_STATS, OP_GN_APPLY, OP_LAYERNORM, OP_ATTN_FWD, OP_TRANSPOSE_HEADS = range(1, 9)
 OP_TEMBED, OP_CONV_IN, OP_ELEMENTWISE, OP_CFG_DDIM, OP_LOSS, OP_WGRAD, OP_ADAMW = range(9, 16)
 OP_GN_BWD_STATS, OP_GN_BWD_APPLY, OP_LAYERNORM_BWD, OP_ATTN_BWD, OP_MEMSET = range(16, 21)
 OP_LORA_CONV_DGRAD, OP_TEMB_LORA_BWD = 21, 22
+OP_SGEMM, OP_GN32_STATS, OP_GN32_APPLY, OP_SOFTMAX32, OP_VAE_CONV_IN, OP_VAE_MOMENTS, OP_VAE_SAMPLE = range(23, 30)
 
 EW_COPY, EW_ADD, EW_GEGLU_FWD, EW_GEGLU_BWD, EW_UPSAMPLE_BWD, EW_COLSUM = range(6)
 
@@ -102,6 +114,9 @@ _ENTRY = {
     OP_GN_BWD_STATS: ("slh_gn_bwd_stats", GnBwdDesc), OP_GN_BWD_APPLY: ("slh_gn_bwd_apply", GnBwdDesc),
     OP_LAYERNORM_BWD: ("slh_layernorm_bwd", LnBwdDesc), OP_ATTN_BWD: ("slh_attn_bwd", AttnBwdDesc),
     OP_LORA_CONV_DGRAD: ("slh_lora_conv_dgrad", LoraCdgradDesc), OP_TEMB_LORA_BWD: ("slh_temb_lora_bwd", TembLoraBwdDesc),
+    OP_SGEMM: ("slh_sgemm", SgemmDesc), OP_GN32_STATS: ("slh_gn32_stats", Gn32Desc), OP_GN32_APPLY: ("slh_gn32_apply", Gn32Desc),
+    OP_SOFTMAX32: ("slh_softmax32", Softmax32Desc), OP_VAE_CONV_IN: ("slh_vae_conv_in", VaeConvDesc),
+    OP_VAE_MOMENTS: ("slh_vae_moments", VaeConvDesc), OP_VAE_SAMPLE: ("slh_vae_sample", VaeSampleDesc),
 }
 
 EXPORTS = ["slh_version", "slh_last_error", "slh_run_program", "slh_desc_sizes"] + [v[0] for v in _ENTRY.values()]

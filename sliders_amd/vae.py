@@ -1,0 +1,256 @@
+"""AutoencoderKL encoder on the MI355X for the image sliders (trainscripts/imagesliders/train_util.py:200-235
+`get_noisy_image`): VaeImageProcessor.preprocess -> vae.encode(...).latent_dist.sample() -> * scaling_factor ->
+scheduler.add_noise, all on the GPU in fp32 (the reference keeps the VAE in fp32,
+trainscripts/imagesliders/train_lora-scale-xl.py:96).
+
+The encoder is a static command buffer over the fp32 kernels of csrc/vae.hip (slh_sgemm implicit-GEMM convolutions on
+the exact-fp32 MFMA, slh_gn32_*, slh_softmax32, slh_vae_conv_in, slh_vae_moments); the posterior sample + add_noise is
+one more launch (slh_vae_sample) whose coefficients change every iteration.  Activations are pixel-major fp32
+[B*H*W][C]; weights are repacked once from the diffusers AutoencoderKL state dict (`encoder.*`, `quant_conv.*`).
+There is no CPU fallback.
+"""
+from __future__ import annotations
+
+from typing import Dict, Optional, Tuple
+
+import torch
+
+from . import lib
+from .arena import Arena, Buf
+
+VAE_SCALING = {"sd1": 0.18215, "sdxl": 0.13025}       # vae.config.scaling_factor of the SD-1.x / SDXL checkpoints
+
+
+def random_vae_state_dict(boc=(128, 256, 512, 512), device="cpu", seed: int = 0) -> Dict[str, torch.Tensor]:
+    """Seeded random-init ENCODER weights with the diffusers key names (no checkpoints exist offline): PyTorch default
+    init bounds, norms 1/0."""
+    g = torch.Generator(device=device).manual_seed(seed)
+    sd: Dict[str, torch.Tensor] = {}
+
+    def u(shape, fan_in):
+        b = 1.0 / fan_in ** 0.5
+        return (torch.rand(shape, generator=g, device=device) * 2 - 1) * b
+
+    def conv(name, co, ci, k):
+        sd[name + ".weight"] = u((co, ci, k, k), ci * k * k)
+        sd[name + ".bias"] = u((co,), ci * k * k)
+
+    def lin(name, co, ci):
+        sd[name + ".weight"] = u((co, ci), ci)
+        sd[name + ".bias"] = u((co,), ci)
+
+    def norm(name, c):
+        sd[name + ".weight"] = torch.ones(c, device=device)
+        sd[name + ".bias"] = torch.zeros(c, device=device)
+
+    def resnet(name, ci, co):
+        norm(name + ".norm1", ci)
+        conv(name + ".conv1", co, ci, 3)
+        norm(name + ".norm2", co)
+        conv(name + ".conv2", co, co, 3)
+        if ci != co:
+            conv(name + ".conv_shortcut", co, ci, 1)
+
+    conv("encoder.conv_in", boc[0], 3, 3)
+    c = boc[0]
+    for i, co in enumerate(boc):
+        resnet(f"encoder.down_blocks.{i}.resnets.0", c, co)
+        resnet(f"encoder.down_blocks.{i}.resnets.1", co, co)
+        if i != len(boc) - 1:
+            conv(f"encoder.down_blocks.{i}.downsamplers.0.conv", co, co, 3)
+        c = co
+    resnet("encoder.mid_block.resnets.0", c, c)
+    resnet("encoder.mid_block.resnets.1", c, c)
+    a = "encoder.mid_block.attentions.0"
+    norm(a + ".group_norm", c)
+    for nm in ("to_q", "to_k", "to_v", "to_out.0"):
+        lin(f"{a}.{nm}", c, c)
+    norm("encoder.conv_norm_out", c)
+    conv("encoder.conv_out", 8, c, 3)
+    conv("quant_conv", 8, 8, 1)
+    return sd
+
+
+class _Plan:
+    def __init__(self, prog, io, arena):
+        self.prog, self.io, self.arena = prog, io, arena
+
+
+class VaeEncoder:
+    def __init__(self, state_dict: Dict[str, torch.Tensor], device="cuda:0", scaling_factor: float = VAE_SCALING["sdxl"]):
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError("VaeEncoder needs a ROCm GPU (there is no CPU fallback)")
+        lib.load()
+        self.scaling_factor = float(scaling_factor)
+        self.w: Dict[str, torch.Tensor] = {}
+        sd = state_dict
+        self.boc = []
+        i = 0
+        while f"encoder.down_blocks.{i}.resnets.0.conv1.weight" in sd:
+            self.boc.append(int(sd[f"encoder.down_blocks.{i}.resnets.0.conv1.weight"].shape[0]))
+            i += 1
+        if not self.boc:
+            raise KeyError("state dict has no encoder.down_blocks.*: expected the diffusers AutoencoderKL layout")
+        f = lambda t: t.to(device=self.device, dtype=torch.float32).contiguous()
+        c3 = lambda t: f(t.permute(0, 2, 3, 1).reshape(t.shape[0], -1))        # [Cout][Cin][3][3] -> [Cout][ky][kx][Cin]
+        for k, v in sd.items():
+            if not (k.startswith("encoder.") or k.startswith("quant_conv.")):
+                continue
+            if k.endswith(".weight") and v.ndim == 4 and v.shape[2] == 3:
+                self.w[k] = c3(v)
+            elif k.endswith(".weight") and v.ndim == 4:
+                self.w[k] = f(v.reshape(v.shape[0], v.shape[1]))
+            else:
+                self.w[k] = f(v)
+        self._plans: Dict[Tuple[int, int, int], _Plan] = {}
+
+    def nbytes(self) -> int:
+        return sum(t.numel() * 4 for t in self.w.values())
+
+    # ---- planner ------------------------------------------------------------------------------------------------
+    def _build(self, B: int, H: int, W: int, arena: Arena, zarena: Arena) -> _Plan:
+        prog = lib.Program()
+        wp = (lambda k: self.w[k].data_ptr()) if not arena.virtual else (lambda k: 0x1000)
+        f32 = torch.float32
+
+        def act(rows, C, name):
+            return arena.alloc((rows, C), f32, name)
+
+        def gn(x: Buf, C, hw, name, silu):
+            stats = zarena.alloc((B, 32, 2), f32, name + ".stats")
+            y = act(B * hw, C, name)
+            d = lib.Gn32Desc(x=x.ptr, gamma=wp(name + ".weight"), beta=wp(name + ".bias"), stats=stats.ptr, y=y.ptr, ldx=C,
+                             ldy=C, C=C, batch=B, hw=hw, groups=32, eps=1e-6, act=1 if silu else 0)
+            prog.add(lib.OP_GN32_STATS, d, name + ".stats")
+            prog.add(lib.OP_GN32_APPLY, d, name + ".apply")
+            return y
+
+        def conv3(x: Buf, ci, co, h, w, name, stride=1, residual: Optional[Buf] = None):
+            ho, wo = (h, w) if stride == 1 else ((h - 2) // 2 + 1, (w - 2) // 2 + 1)     # stride 2: pad (0,1,0,1) then k3 s2
+            y = act(B * ho * wo, co, name)
+            d = lib.SgemmDesc(x=x.ptr, w=wp(name + ".weight"), bias=wp(name + ".bias"), residual=residual.ptr if residual else 0,
+                              c=y.ptr, ldx=ci, ldw=9 * ci, ldr=co, ldc=co, M=B * ho * wo, N=co, K=9 * ci, mode=1, cin=ci,
+                              batch=B, hs=h, ws=w, ho=ho, wo=wo, stride=stride, pad=1 if stride == 1 else 0, alpha=1.0)
+            prog.add(lib.OP_SGEMM, d, name)
+            return y, ho, wo
+
+        def dense(x_ptr, M, K, w_ptr, N, bias_ptr, name, residual: Optional[Buf] = None, out: Optional[Buf] = None,
+                  ldx=None, ldw=None, alpha=1.0, bias_per_row=0):
+            y = out or act(M, N, name)
+            d = lib.SgemmDesc(x=x_ptr, w=w_ptr, bias=bias_ptr, residual=residual.ptr if residual else 0, c=y.ptr,
+                              ldx=ldx or K, ldw=ldw or K, ldr=N, ldc=N, M=M, N=N, K=K, mode=0, alpha=alpha,
+                              bias_per_row=bias_per_row)
+            prog.add(lib.OP_SGEMM, d, name)
+            return y
+
+        def resnet(x: Buf, ci, co, h, w, name):
+            a1 = gn(x, ci, h * w, name + ".norm1", True)
+            h1, _, _ = conv3(a1, ci, co, h, w, name + ".conv1")
+            a2 = gn(h1, co, h * w, name + ".norm2", True)
+            sc = x
+            if ci != co:
+                sc = dense(x.ptr, B * h * w, ci, wp(name + ".conv_shortcut.weight"), co, wp(name + ".conv_shortcut.bias"),
+                           name + ".conv_shortcut")
+            out, _, _ = conv3(a2, co, co, h, w, name + ".conv2", residual=sc)
+            return out
+
+        img = arena.alloc((B, H * W, 3), f32, "in.image")
+        boc = self.boc
+        x = act(B * H * W, boc[0], "encoder.conv_in")
+        prog.add(lib.OP_VAE_CONV_IN, lib.VaeConvDesc(x=img.ptr, w=wp("encoder.conv_in.weight"), bias=wp("encoder.conv_in.bias"),
+                                                     y=x.ptr, batch=B, h=H, wd=W, cin=3, cout=boc[0]), "encoder.conv_in")
+        c, h, w = boc[0], H, W
+        for i, co in enumerate(boc):
+            p = f"encoder.down_blocks.{i}"
+            x = resnet(x, c, co, h, w, p + ".resnets.0")
+            x = resnet(x, co, co, h, w, p + ".resnets.1")
+            c = co
+            if i != len(boc) - 1:
+                x, h, w = conv3(x, c, c, h, w, p + ".downsamplers.0.conv", stride=2)
+        x = resnet(x, c, c, h, w, "encoder.mid_block.resnets.0")
+        # mid-block attention: GroupNorm, ONE head of c channels, biased projections, residual
+        a = "encoder.mid_block.attentions.0"
+        T = h * w
+        t = gn(x, c, T, a + ".group_norm", False)
+        q = dense(t.ptr, B * T, c, wp(a + ".to_q.weight"), c, wp(a + ".to_q.bias"), a + ".to_q")
+        k = dense(t.ptr, B * T, c, wp(a + ".to_k.weight"), c, wp(a + ".to_k.bias"), a + ".to_k")
+        o = act(B * T, c, a + ".pv")
+        for b in range(B):
+            off = 4 * b * T * c
+            # V^T [c][T] = Wv . t_b^T (+ bias per row): the P.V product then reads it as an [N][K] operand
+            vt = dense(wp(a + ".to_v.weight"), c, c, t.ptr + off, T, wp(a + ".to_v.bias"), f"{a}.to_v_T.{b}", bias_per_row=1)
+            s = dense(q.ptr + off, T, c, k.ptr + off, T, 0, f"{a}.scores.{b}", alpha=float(c) ** -0.5)
+            prog.add(lib.OP_SOFTMAX32, lib.Softmax32Desc(x=s.ptr, ld=T, rows=T, cols=T), f"{a}.softmax.{b}")
+            ob = Buf(o.ptr + off, 4 * T * c, (T, c), f32, None, "")
+            dense(s.ptr, T, T, vt.ptr, c, 0, f"{a}.pv.{b}", out=ob)
+        x = dense(o.ptr, B * T, c, wp(a + ".to_out.0.weight"), c, wp(a + ".to_out.0.bias"), a + ".to_out.0", residual=x)
+        x = resnet(x, c, c, h, w, "encoder.mid_block.resnets.1")
+        g = gn(x, c, h * w, "encoder.conv_norm_out", True)
+        mom = arena.alloc((B * h * w, 8), f32, "moments")
+        prog.add(lib.OP_VAE_MOMENTS, lib.VaeConvDesc(x=g.ptr, w=wp("encoder.conv_out.weight"), bias=wp("encoder.conv_out.bias"),
+                                                     qw=wp("quant_conv.weight"), qb=wp("quant_conv.bias"), y=mom.ptr,
+                                                     batch=B, h=h, wd=w, cin=c, cout=8), "conv_out+quant_conv")
+        io = {"image": img, "moments": mom, "h": h, "w": w,
+              "post_noise": arena.alloc((B, 4, h * w), f32, "in.post_noise"),
+              "noise": arena.alloc((B, 4, h * w), f32, "in.noise"),
+              "latent": arena.alloc((B, 4, h, w), f32, "out.latent"),
+              "noisy": arena.alloc((B, 4, h, w), f32, "out.noisy"),
+              "noisy_bf16": arena.alloc((B, 4, h, w), torch.bfloat16, "out.noisy_bf16")}
+        head = lib.Program()
+        if zarena.mark() > 0:
+            pz, nz = zarena.region(0, zarena.mark())
+            head.memset(pz, nz, 0, "zero_gn_stats")
+        head.extend(prog)
+        return _Plan(head, io, arena)
+
+    def plan(self, B: int, H: int, W: int) -> _Plan:
+        key = (B, H, W)
+        p = self._plans.get(key)
+        if p is None:
+            if H % 8 or W % 8:
+                raise ValueError("image sides must be multiples of 8 (the reference resizes to 512 / 256 first)")
+            va, vz = Arena(1 << 50, None, "vae-virtual"), Arena(1 << 40, None, "vae-virtual-z")
+            self._build(B, H, W, va, vz)
+            arena = Arena(va.high_water + (1 << 20), self.device, "vae activations")
+            zarena = Arena(vz.high_water + 4096, self.device, "vae GroupNorm statistics")
+            p = self._plans[key] = self._build(B, H, W, arena, zarena)
+            p.zarena = zarena
+        return p
+
+    # ---- the operator ---------------------------------------------------------------------------------------------
+    @staticmethod
+    def preprocess(img) -> torch.Tensor:
+        """VaeImageProcessor.preprocess of one image: PIL / HxWx3 uint8 array / uint8 tensor -> float32 [1][H][W][3] in
+        [-1, 1] (channels last = the pixel-major layout the encoder reads)."""
+        if not torch.is_tensor(img):
+            import numpy as np
+            img = torch.from_numpy(np.asarray(img).copy())
+        if img.ndim == 2:
+            img = img[..., None].expand(-1, -1, 3)
+        return (img[..., :3].to(torch.float32) / 255.0 * 2.0 - 1.0)[None]
+
+    def encode_moments(self, image: torch.Tensor) -> torch.Tensor:
+        """image: [B][H][W][3] float32 in [-1,1] -> moments [B*h*w][8] (mean | logvar), h = H/8."""
+        B, H, W, _ = image.shape
+        p = self.plan(B, H, W)
+        p.io["image"].tensor.copy_(image.reshape(B, H * W, 3))
+        p.prog.run(torch.cuda.current_stream().cuda_stream)
+        return p.io["moments"].tensor
+
+    def get_noisy_image(self, image: torch.Tensor, post_noise: torch.Tensor, noise: torch.Tensor, sqrt_alpha: float,
+                        sqrt_one_minus_alpha: float):
+        """(noisy latents bf16 (B,4,h,w), noisy latents fp32, clean scaled latents fp32).  post_noise / noise: (B,4,h,w)
+        float32: the draw inside latent_dist.sample() and the diffusion noise of scheduler.add_noise."""
+        B, H, W, _ = image.shape
+        p = self.plan(B, H, W)
+        self.encode_moments(image)
+        io = p.io
+        io["post_noise"].tensor.copy_(post_noise.reshape(B, 4, -1))
+        io["noise"].tensor.copy_(noise.reshape(B, 4, -1))
+        d = lib.VaeSampleDesc(moments=io["moments"].ptr, post_noise=io["post_noise"].ptr, noise=io["noise"].ptr,
+                              latent_f32=io["latent"].ptr, noisy_f32=io["noisy"].ptr, noisy_bf16=io["noisy_bf16"].ptr,
+                              batch=B, hw=io["h"] * io["w"], scaling=self.scaling_factor, sqrt_alpha=float(sqrt_alpha),
+                              sqrt_one_minus_alpha=float(sqrt_one_minus_alpha))
+        lib.call(lib.OP_VAE_SAMPLE, d, torch.cuda.current_stream().cuda_stream)
+        return io["noisy_bf16"].tensor, io["noisy"].tensor, io["latent"].tensor

@@ -391,3 +391,25 @@ def test_single_file_checkpoint_is_rejected_before_loading(tmp_path):
     with pytest.raises(NotImplementedError, match="diffusers-format model directory"):
         check_model_files(str(f))
     check_model_files(str(tmp_path))      # a directory passes this gate (the loader then validates its contents)
+
+
+def test_image_slider_cli_keeps_the_reference_flags():
+    """trainscripts/imagesliders/train_lora-scale-xl.py:464-541: --alpha required, folder / scale lists, stylecheck."""
+    from sliders_amd.cli_image import build_parser, parse_folders_scales
+    ps = build_parser()
+    with pytest.raises(SystemExit):
+        ps.parse_args(["--config_file", "c.yaml", "--folder_main", "d/"])            # --alpha is required
+    a = ps.parse_args(["--config_file", "c.yaml", "--alpha", "1", "--folder_main", "datasets/eyesize/", "--name", "eye"])
+    assert (a.folders, a.scales, a.rank, a.stylecheck) == ("verylow, low, high, veryhigh", "-2, -1, 1, 2", 4, None)
+    f, s = parse_folders_scales("bigsize, smallsize", "1, -1")
+    assert f == ["bigsize", "smallsize"] and s == [1, -1]
+    with pytest.raises(Exception):
+        parse_folders_scales("a, b, c", "1, -1")
+    for script in ("train_lora-scale-xl.py", "train_lora-scale.py"):
+        assert os.path.isfile(os.path.join(ROOT, "trainscripts", "imagesliders", script))
+
+
+def test_vae_encoder_refuses_cpu():
+    from sliders_amd.vae import VaeEncoder, random_vae_state_dict
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        VaeEncoder(random_vae_state_dict((128, 128, 128, 128)), "cpu")

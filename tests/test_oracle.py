@@ -163,3 +163,31 @@ def test_lora_init_follows_reference_rng_order():
         ref = m.lora_down.weight.detach().to(torch.bfloat16)
         assert torch.equal(sd[m.lora_name + ".lora_down.weight"], ref), m.lora_name
         assert sd[m.lora_name + ".lora_up.weight"].abs().max() == 0
+
+
+def test_vae_oracle_is_pinned_to_the_published_architecture():
+    """The SD VAE (AutoencoderKL, block_out_channels (128,256,512,512), 2 layers per block, one 512-channel attention head
+    in each mid block) has 83,653,863 parameters - the figure published for sd-vae / the SDXL VAE - and its encoder half
+    uses exactly the diffusers key names sliders_amd.vae.VaeEncoder loads."""
+    from oracle.vae_oracle import build_vae
+    from sliders_amd.vae import random_vae_state_dict
+    vae = build_vae("sdxl", with_decoder=True)
+    assert sum(p.numel() for p in vae.parameters()) == 83_653_863
+    enc_keys = {k for k in vae.state_dict() if k.startswith("encoder.") or k.startswith("quant_conv.")}
+    sd = random_vae_state_dict()
+    assert set(sd) == enc_keys
+    ref = vae.state_dict()
+    assert all(tuple(sd[k].shape) == tuple(ref[k].shape) for k in sd)
+    assert "encoder.mid_block.attentions.0.to_out.0.weight" in sd and "encoder.down_blocks.1.resnets.0.conv_shortcut.weight" in sd
+    # forward shape + the posterior algebra of get_noisy_image
+    import torch
+    from oracle.vae_oracle import AutoencoderKL, get_noisy_image
+    small = AutoencoderKL((32, 32, 64, 64), 0.13025, with_decoder=False).eval()
+    x = torch.rand(1, 3, 32, 32) * 2 - 1
+    dist = small.encode(x).latent_dist
+    assert dist.mean.shape == (1, 4, 4, 4) and float(dist.logvar.max()) <= 20.0
+    ac = torch.linspace(0.9999, 0.01, 1000)
+    n1, n2 = torch.randn(1, 4, 4, 4), torch.randn(1, 4, 4, 4)
+    noisy, _ = get_noisy_image(x, small, ac, 500, n1, n2)
+    lat = 0.13025 * (dist.mean + dist.std * n1)
+    assert torch.allclose(noisy, ac[500].sqrt() * lat + (1 - ac[500]).sqrt() * n2, atol=1e-6)

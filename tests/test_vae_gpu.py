@@ -1,0 +1,202 @@
+"""Image-slider path (trainscripts/imagesliders): the fp32 AutoencoderKL encoder kernels, `get_noisy_image` and one whole
+image-slider iteration of the HIP engine against the CPU oracle (oracle/vae_oracle.py + the reference loop of
+train_lora-scale-xl.py:178-396 written over the oracle UNet).
+
+Tolerances.  The VAE path is fp32 on both sides (the reference keeps the VAE in fp32): relative L2 error < 2e-5 per kernel
+and < 1e-4 for the whole encoder (accumulation order of 30 convolutions; GroupNorm statistics by fp32 atomics).  The
+noisy latents are handed to the UNet in bf16, bit-identical rounding of the fp32 result.  The iteration is compared like
+the text-slider iteration (tests/test_trainer_gpu.py): gradient cosine vs fp32 autograd through the oracle.
+"""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import vae_oracle
+from oracle.ddim_oracle import DDIMScheduler
+from oracle.lora_oracle import LoRANetworkOracle
+from oracle.unet_oracle import build_unet
+from sliders_amd import lib
+from sliders_amd.config import CONFIGS
+from sliders_amd.image_trainer import ImageSliderTrainer
+from sliders_amd.lora_store import LoraStore
+from sliders_amd.trainer import PairEmbeds
+from sliders_amd.unet import UNetEngine
+from sliders_amd.vae import VaeEncoder, random_vae_state_dict
+from tests.util import p, rel_err, report, stream
+
+pytestmark = pytest.mark.gpu
+
+
+def _pix(x):          # NCHW -> [B*H*W][C]
+    B, C, H, W = x.shape
+    return x.permute(0, 2, 3, 1).reshape(B * H * W, C).contiguous()
+
+
+@pytest.mark.parametrize("stride", [1, 2])
+@pytest.mark.parametrize("B,H,W,Ci,Co", [(2, 12, 20, 32, 48), (1, 16, 16, 128, 260), (1, 9, 7, 16, 4)])
+def test_sgemm_conv3x3(dev, stride, B, H, W, Ci, Co):
+    torch.manual_seed(Ci + Co + stride)
+    img = torch.randn(B, Ci, H, W, device=dev)
+    w4 = torch.randn(Co, Ci, 3, 3, device=dev) / math.sqrt(9 * Ci)
+    bias = torch.randn(Co, device=dev)
+    if stride == 1:
+        ref = F.conv2d(img, w4, bias, padding=1)
+    else:                       # Downsample2D(padding=0): zero pad right/bottom, then k3 s2
+        ref = F.conv2d(F.pad(img, (0, 1, 0, 1)), w4, bias, stride=2)
+    Ho, Wo = ref.shape[2:]
+    res = torch.randn(B * Ho * Wo, Co, device=dev)
+    x = _pix(img)
+    wp = w4.permute(0, 2, 3, 1).reshape(Co, -1).contiguous()
+    c = torch.zeros(B * Ho * Wo, Co, device=dev)
+    d = lib.SgemmDesc(x=p(x), w=p(wp), bias=p(bias), residual=p(res), c=p(c), ldx=Ci, ldw=9 * Ci, ldr=Co, ldc=Co,
+                      M=B * Ho * Wo, N=Co, K=9 * Ci, mode=1, cin=Ci, batch=B, hs=H, ws=W, ho=Ho, wo=Wo, stride=stride,
+                      pad=1 if stride == 1 else 0, alpha=1.0)
+    lib.call(lib.OP_SGEMM, d, stream())
+    torch.cuda.synchronize()
+    report(f"sgemm conv s{stride} {B}x{Ci}x{H}x{W}->{Co}", c, _pix(ref) + res, 2e-5)
+
+
+def test_sgemm_dense_alpha_rowbias(dev):
+    torch.manual_seed(3)
+    M, N, K = 300, 132, 64
+    x, w = torch.randn(M, K, device=dev), torch.randn(N, K, device=dev) / 8
+    bn, bm = torch.randn(N, device=dev), torch.randn(M, device=dev)
+    for per_row in (0, 1):
+        c = torch.zeros(M, N, device=dev)
+        d = lib.SgemmDesc(x=p(x), w=p(w), bias=p(bm if per_row else bn), c=p(c), ldx=K, ldw=K, ldc=N, M=M, N=N, K=K, mode=0,
+                          alpha=0.37, bias_per_row=per_row)
+        lib.call(lib.OP_SGEMM, d, stream())
+        torch.cuda.synchronize()
+        ref = 0.37 * (x @ w.t()) + (bm[:, None] if per_row else bn[None, :])
+        report(f"sgemm dense per_row={per_row}", c, ref, 2e-5)
+
+
+def test_gn32_and_softmax32(dev):
+    torch.manual_seed(4)
+    B, HW, C = 2, 300, 128
+    x = torch.randn(B * HW, C, device=dev) * 2 + 0.5
+    gm, bt = torch.randn(C, device=dev), torch.randn(C, device=dev)
+    for act in (0, 1):
+        stats = torch.zeros(B, 32, 2, device=dev)
+        y = torch.zeros_like(x)
+        d = lib.Gn32Desc(x=p(x), gamma=p(gm), beta=p(bt), stats=p(stats), y=p(y), ldx=C, ldy=C, C=C, batch=B, hw=HW, groups=32,
+                         eps=1e-6, act=act)
+        lib.call(lib.OP_GN32_STATS, d, stream())
+        lib.call(lib.OP_GN32_APPLY, d, stream())
+        torch.cuda.synchronize()
+        ref = F.group_norm(x.view(B, HW, C).transpose(1, 2), 32, gm, bt, eps=1e-6)
+        if act:
+            ref = F.silu(ref)
+        report(f"gn32 act={act}", y, ref.transpose(1, 2).reshape(B * HW, C), 2e-5)
+    s = torch.randn(77, 4096, device=dev) * 3
+    ref = torch.softmax(s, -1)
+    lib.call(lib.OP_SOFTMAX32, lib.Softmax32Desc(x=p(s), ld=4096, rows=77, cols=4096), stream())
+    torch.cuda.synchronize()
+    report("softmax32", s, ref, 2e-6)
+
+
+def _oracle_vae(sd, boc, kind="sdxl"):
+    vae = vae_oracle.AutoencoderKL(boc, vae_oracle.VAE_SCALING[kind], with_decoder=False)
+    missing = vae.load_state_dict({k: v.float().cpu() for k, v in sd.items()}, strict=True)
+    return vae.eval()
+
+
+@pytest.mark.parametrize("boc,B,size", [((128, 128, 256, 256), 2, 64), ((128, 256, 512, 512), 1, 256)])
+def test_vae_encoder_and_get_noisy_image(dev, boc, B, size):
+    """sliders_amd.vae.VaeEncoder vs the oracle AutoencoderKL.encode on identical random-init weights, then the whole
+    get_noisy_image (train_util.py:200-235) with the two random draws shared."""
+    sd = random_vae_state_dict(boc, dev, seed=1)
+    enc = VaeEncoder(sd, dev, vae_oracle.VAE_SCALING["sdxl"])
+    vae = _oracle_vae(sd, boc)
+    g = torch.Generator().manual_seed(2)
+    img_u8 = torch.randint(0, 256, (B, size, size, 3), generator=g, dtype=torch.uint8)
+    image = torch.cat([VaeEncoder.preprocess(img_u8[b]) for b in range(B)])            # [B][H][W][3]
+    assert torch.equal(image[0].permute(2, 0, 1), vae_oracle.preprocess_image(img_u8[0].numpy())[0])
+    h = size // 8
+    mom = enc.encode_moments(image.to(dev))
+    torch.cuda.synchronize()
+    with torch.no_grad():
+        ref_m = vae.quant_conv(vae.encoder(image.permute(0, 3, 1, 2)))               # [B][8][h][h]
+    report(f"vae moments boc{boc} {size}px", mom.cpu(), _pix(ref_m), 1e-4)
+    post, noise = torch.randn(B, 4, h, h, generator=g), torch.randn(B, 4, h, h, generator=g)
+    sch = DDIMScheduler()
+    t = 980 - 20 * 7                                                                   # timesteps_50[7]
+    a = sch.alphas_cumprod[t]
+    nb, nf, lat = enc.get_noisy_image(image.to(dev), post.to(dev), noise.to(dev), float(a.sqrt()), float((1 - a).sqrt()))
+    torch.cuda.synchronize()
+    with torch.no_grad():
+        ref_noisy, _ = vae_oracle.get_noisy_image(image.permute(0, 3, 1, 2), vae, sch.alphas_cumprod, t, post, noise)
+    report("get_noisy_image fp32", nf.cpu(), ref_noisy, 1e-4)
+    assert torch.equal(nb.cpu(), nf.cpu().to(torch.bfloat16)), "the bf16 latents must be the rounded fp32 ones"
+
+
+def test_image_slider_iteration_matches_reference_loop_on_oracle(dev):
+    """One iteration of train_lora-scale-xl.py:178-396 (both polarities, gradient accumulation, AdamW) against the same
+    loop over the oracle UNet + oracle VAE in fp32."""
+    name, hw, k, scale = "tiny_sdxl", 16, 5, 2.0
+    cfg = CONFIGS[name]()
+    boc = (128, 128, 128, 128)
+    g = torch.Generator().manual_seed(9)
+    torch.manual_seed(9)
+    store = LoraStore(cfg, rank=4, alpha=1.0, train_method="noxattn", device=dev, kaiming_a=5 ** 0.5)
+    for e in store.entries:
+        store.params[e.up_off:e.up_off + e.up_numel] = (torch.randn(e.up_numel, generator=g) * 0.03).to(dev, torch.bfloat16)
+    sd_lora = store.state_dict()
+    params0 = store.params.clone()
+    emb = {n: torch.randn(1, 77, cfg.cross_attention_dim, generator=g) for n in ("positive", "neutral", "uncond")}
+    pool = {n: torch.randn(1, cfg.pooled_dim, generator=g) for n in emb}
+    size = hw * 8
+    img_low = VaeEncoder.preprocess(torch.randint(0, 256, (size, size, 3), generator=g, dtype=torch.uint8))
+    img_high = VaeEncoder.preprocess(torch.randint(0, 256, (size, size, 3), generator=g, dtype=torch.uint8))
+    post, noise = torch.randn(1, 4, hw, hw, generator=g), torch.randn(1, 4, hw, hw, generator=g)
+    vsd = random_vae_state_dict(boc, dev, seed=3)
+    net = build_unet(name, seed=0)
+    eng = UNetEngine(cfg, net.state_dict(), dev)
+    enc = VaeEncoder(vsd, dev, vae_oracle.VAE_SCALING["sdxl"])
+    tr = ImageSliderTrainer(eng, store, enc, hw, hw, lr=2e-4)
+    cat = lambda n: torch.cat([emb["uncond"], emb[n]]).to(dev, torch.bfloat16).contiguous()
+    pc = lambda n: torch.cat([pool["uncond"], pool[n]]).to(dev, torch.bfloat16).contiguous()
+    pe = PairEmbeds(cat("positive"), cat("positive"), cat("neutral"), cat("uncond"), pc("positive"), pc("positive"),
+                    pc("neutral"), pc("uncond"), guidance_scale=1.0, action="enhance")
+    lh, ll = tr.iteration(pe, k, img_low.to(dev), img_high.to(dev), scale, post.to(dev), noise.to(dev))
+    torch.cuda.synchronize()
+    # ---- the reference loop on the oracle (fp32) ----
+    vae = _oracle_vae(vsd, boc)
+    nw = LoRANetworkOracle(net, rank=4, multiplier=1.0, alpha=1.0, train_method="noxattn")
+    nw.load_state_dict(sd_lora, strict=True)
+    for q in nw.parameters():
+        q.requires_grad_(True)
+    sch = DDIMScheduler()
+    sch.set_timesteps(50)
+    t_add = int(sch.timesteps[k])
+    tid = torch.tensor([[size * 1.0, size * 1.0, 0, 0, size * 1.0, size * 1.0]] * 2)
+    sch.set_timesteps(1000)
+    t_cur = sch.timesteps[int(k * 1000 / 50)]
+    losses = []
+    for sign, img, which in ((1.0, img_high, "positive"), (-1.0, img_low, "neutral")):
+        with torch.no_grad():
+            lat, _ = vae_oracle.get_noisy_image(img.permute(0, 3, 1, 2), vae, sch.alphas_cumprod, t_add, post, noise)
+            lat = lat.to(torch.bfloat16).float()
+        nw.set_lora_slider(sign * scale)
+        with nw:
+            e = net(torch.cat([lat] * 2), t_cur, torch.cat([emb["uncond"], emb[which]]),
+                    {"text_embeds": torch.cat([pool["uncond"], pool[which]]), "time_ids": tid}).sample
+        u, c = e.chunk(2)
+        loss = F.mse_loss(u + 1.0 * (c - u), noise.to(torch.bfloat16).float())
+        loss.backward()
+        losses.append(loss.item())
+    flat = torch.zeros(store.numel)
+    mods = {m.lora_name: m for m in nw.unet_loras}
+    for e_ in store.entries:
+        m = mods[e_.name]
+        flat[e_.down_off:e_.down_off + e_.down_numel] = store._down_to_kernel(e_, m.lora_down.weight.grad)
+        flat[e_.up_off:e_.up_off + e_.up_numel] = m.lora_up.weight.grad.reshape(-1)
+    cos = F.cosine_similarity(store.grads.cpu(), flat, dim=0).item()
+    print(f"[parity] image-slider iteration: loss high {lh.item():.5e} vs {losses[0]:.5e}, low {ll.item():.5e} vs {losses[1]:.5e}, "
+          f"grad cosine {cos:.5f} |g| {store.grads.norm().item():.3e} vs {flat.norm().item():.3e}")
+    assert abs(lh.item() - losses[0]) < 0.02 * losses[0] and abs(ll.item() - losses[1]) < 0.02 * losses[1]
+    assert cos > 0.995
+    delta = (store.params.float() - params0.float()).abs()
+    assert 0 < delta.max().item() < 5e-4
