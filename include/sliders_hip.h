@@ -70,8 +70,9 @@ typedef struct slh_gemm_desc {
     int32_t ld_t, lora_groups; /* N/lora_groups columns share one rank-4 slice of T */
     int32_t ld_res, ldc;
     int32_t geglu;           /* 1: out[:, j] = a_j * gelu(g_j); W rows pre-permuted in 64-row blocks [32 a | 32 g] */
-    int32_t tile;            /* 0 auto; else (WM<<12)|(stages<<8)|(MI<<4)|NI, MI,NI in {1,2}, WM in {0|2, 4}: WM*2 waves per
-                                workgroup, block tile (32*MI*WM) x (64*NI) */
+    int32_t tile;            /* 0 auto; else (S<<16)|(WM<<12)|(stages<<8)|(MI<<4)|NI, MI,NI in {1,2}, WM in {0|2, 4}: WM*2 waves per
+                                workgroup, block tile (32*MI*WM) x (64*NI); stages 0|2: double buffer, 3|4: deep LDS ring;
+                                S: split-K factor (0|1 none), needs splitk_c32 */
     int32_t lora_rank;       /* 0 = 4.  With lora_up_rmajor: total rank 4 | 8 | 12 (T has that many columns) */
     int32_t lora_up_rmajor;  /* 1: lora_up is [rank][N] (= lora_down as stored): backward-data LoRA term */
     int32_t w_layout;        /* 0: w is [N][ldw].  1: frozen weights repacked once at load time into the order the kernel
@@ -80,6 +81,12 @@ typedef struct slh_gemm_desc {
                                 in memory, so every LDS-DMA instruction reads 1 KB of consecutive addresses); ldw unused */
     int32_t reserved_;       /* 0.  Non-zero values are profiling ablations (scripts/probe_gemm.py): 1 skip tile refills,
                                 2 skip MFMA work, 4 skip the epilogue, 8 skip the first fill, 16 return at once */
+    float* splitk_c32;       /* split-K workspace or NULL: [M][N] fp32, ZERO on entry.  With tile bits 16-19 = S > 1 the K
+                                range is cut into S slices, each workgroup adds its partial tile here with fp32 atomics and
+                                a second launch applies the epilogue (bias, rowbias, LoRA, residual) and writes c.  For the
+                                few-row, long-K products (1280-channel 3x3 convolutions at 8x8 / 16x16: 10-40 output tiles on
+                                256 CUs, 29 MB of weights each) this is what fills the chip. */
+    float* splitk_t32;       /* with lora_down: [M][ld_t] fp32, ZERO on entry, receives T (lora_t_out may alias it) */
 } slh_gemm_desc;
 int slh_gemm(const slh_gemm_desc* d, slh_stream_t stream);
 /* (WM<<12)|(MI<<8)|(NI<<4)|mode of the kernel instantiation gemm_kernel<MI,NI,mode,..,WM> slh_gemm would launch for d

@@ -24,7 +24,8 @@ ap.add_argument("--model", default="sdxl")
 ap.add_argument("--hw", type=int, default=128)
 ap.add_argument("--out", default=None)
 ap.add_argument("--reps", type=int, default=2)
-ap.add_argument("--tiles", default="11,12,21,22,4011,4012,4022,322,422,412,421,4412,4322,4411")
+ap.add_argument("--tiles", default="11,12,21,22,4011,4012,4022,322,422,412,421,4412,4322,4411,"
+                "20412,40412,80412,20421,40421,80421,20422,40422,24412,44412,40411,80411,f0412")
 ap.add_argument("--fwd-only", action="store_true")
 args = ap.parse_args()
 
@@ -58,6 +59,9 @@ def launch(op, d):
 
 def valid(d, tile):
     mi, ni, wm = (tile >> 4) & 15, tile & 15, (tile >> 12) & 15
+    if (tile >> 16) & 15:                       # split-K candidates only where the planner provisioned a workspace
+        if not d.splitk_c32 or (d.K // 64) < 4 * ((tile >> 16) & 15):
+            return False
     if d.geglu and ni != 2:
         return False
     if wm == 4 and d.M * d.N < 256 * 128 * 32:

@@ -35,6 +35,8 @@ struct GemmArgs {
     int ld_rowbias, rows_per_sample, ld_t, lora_cols_per_group, ld_res, ldc, geglu;
     int lora_rank, lora_up_rmajor, w_packed;
     int tiles_m, tiles_n, group_m;
+    float* c32; float* t32;   // split-K: fp32 partial sums (zeroed by the caller), see slh_gemm_desc.splitk_c32
+    int splitk;
     int store16;  // c and ldc allow 16-byte row stores
     int probe;   // diagnostics (slh_gemm_desc.reserved_): 1 skip tile refills, 2 skip MFMA work, 4 skip the epilogue,
                  // 8 skip the first tile fill, 16 return at once
@@ -93,6 +95,8 @@ __global__ __launch_bounds__(128 * WM, gemm_waves_per_simd(MI, NI, STAGES, LORA,
         const int xcd = bid & 7, idx = bid >> 3;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
+    int ks_id = 0;                 // split-K: consecutive block ids = the K slices of one tile (same XCD, same L2)
+    if (p.splitk > 1) { ks_id = bid % p.splitk; bid = bid / p.splitk; }
     int tile_m, tile_n;
     {
         const int gsz = p.group_m * p.tiles_n;
@@ -204,7 +208,13 @@ __global__ __launch_bounds__(128 * WM, gemm_waves_per_simd(MI, NI, STAGES, LORA,
 #pragma unroll
             for (int r = 0; r < 16; ++r) accl[i][r] = 0.f;
     }
-    const int nk = p.K / BK;
+    int kt_begin = 0, nk = p.K / BK;
+    if (p.splitk > 1) {
+        const int per = (nk + p.splitk - 1) / p.splitk;
+        kt_begin = ks_id * per;
+        nk = min(nk, kt_begin + per) - kt_begin;
+        if (nk <= 0) return;       // uniform over the workgroup
+    }
     const int lrow = lane & 31, lhi = lane >> 5;
 
     auto compute = [&](int buf) {
@@ -241,10 +251,10 @@ __global__ __launch_bounds__(128 * WM, gemm_waves_per_simd(MI, NI, STAGES, LORA,
     };
 
     if constexpr (STAGES == 2) {
-        if (!(p.probe & 8)) stage(0, 0);
+        if (!(p.probe & 8)) stage(0, kt_begin);
         for (int kt = 0; kt < nk; ++kt) {
             __syncthreads();  // drains this wave's glds (vmcnt(0)) and orders all waves
-            if (kt + 1 < nk && !(p.probe & 1)) stage((kt + 1) & 1, kt + 1);
+            if (kt + 1 < nk && !(p.probe & 1)) stage((kt + 1) & 1, kt_begin + kt + 1);
             if (!(p.probe & 2)) compute(kt & 1);
         }
         if (p.probe & 4) return;
@@ -274,15 +284,18 @@ __global__ __launch_bounds__(128 * WM, gemm_waves_per_simd(MI, NI, STAGES, LORA,
         const char* lsrc = nullptr;
         int ladv = 0;
 #pragma unroll
-        for (int i = 0; i < WI; ++i) wsrc[i] = (const char*)wptr[i];
+        for (int i = 0; i < WI; ++i) wsrc[i] = (const char*)(wptr[i] + (long)kt_begin * wkstep);
         if (LORA) {
             const int row = (wave & 3) * 8 + frow;
             const bool ok = row < p.lora_rank;
-            lsrc = ok ? (const char*)(p.lora_down + (long)row * p.K + ((fslot ^ ((row >> 1) & 7)) << 3))
+            lsrc = ok ? (const char*)(p.lora_down + (long)row * p.K + kt_begin * BK + ((fslot ^ ((row >> 1) & 7)) << 3))
                       : (const char*)slh_zero_page;
             ladv = ok ? 128 : 0;
         }
-        int i_kt = 0, i_c0 = 0, i_tap = 0;             // K tile the next issue belongs to; its channel offset / filter tap
+        // K tile the next issue belongs to (relative to this workgroup's K slice); its channel offset / filter tap
+        int i_kt = 0, i_c0 = kt_begin * BK, i_tap = 0;
+        if (MODE == 1) { i_tap = i_c0 / cin; i_c0 -= i_tap * cin; }
+        bool i_first = true;
         const unsigned lds0 = lds_addr_of(smem);
         const int wkbytes = wkstep * 2;
 
@@ -332,7 +345,10 @@ __global__ __launch_bounds__(128 * WM, gemm_waves_per_simd(MI, NI, STAGES, LORA,
                 lsrc += ladv;
             }
         };
-        auto tile_begin = [&]() { if (i_c0 == 0 || i_c0 == p.ca0) rebase_x(); };
+        auto tile_begin = [&]() {
+            if (i_first || i_c0 == 0 || i_c0 == p.ca0) rebase_x();
+            i_first = false;
+        };
         auto tile_end = [&]() {
             ++i_kt;
             i_c0 += BK;
@@ -451,6 +467,32 @@ __global__ __launch_bounds__(128 * WM, gemm_waves_per_simd(MI, NI, STAGES, LORA,
 
     // ---- epilogue ---------------------------------------------------------------------------------
     // acc[i][j][r] = C[m = m0 + wm*32*MI + i*32 + lrow][n = n0 + wn*32*NI + j*32 + (r&3) + 8*(r>>2) + 4*lhi]
+    if (p.splitk > 1) {
+        // split-K: add this K slice's partial sums to the fp32 workspace; gemm_finalize_kernel applies the epilogue
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            const int m = m0 + wm * (32 * MI) + i * 32 + lrow;
+            if (m >= p.M) continue;
+#pragma unroll
+            for (int j = 0; j < NI; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int n = n0 + wn * (32 * NI) + j * 32 + q * 8 + lhi * 4;
+                    if (n >= p.N) continue;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) unsafeAtomicAdd(p.c32 + (long)m * p.N + n + e, acc[i][j][q * 4 + e]);
+                }
+            if (LORA && tile_n == 0 && wn == 0) {
+                // rank index of accl[i][r]: (r&3) + 8*(r>>2) + 4*lhi  ->  ranks 0-3 / 8-11 in the lhi=0 half, 4-7 in lhi=1
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (4 * lhi + e < p.lora_rank) unsafeAtomicAdd(p.t32 + (long)m * p.ld_t + 4 * lhi + e, accl[i][e]);
+                    if (lhi == 0 && 8 + e < p.lora_rank) unsafeAtomicAdd(p.t32 + (long)m * p.ld_t + 8 + e, accl[i][4 + e]);
+                }
+            }
+        }
+        return;
+    }
     if (p.geglu) {
         // GEGLU: W rows are stored in 64-row blocks [32 value rows | 32 gate rows]; NI is 2 here, so
         // sub-tile j=0 holds the values and j=1 the gates of the same 32 output columns.
@@ -614,9 +656,63 @@ __global__ __launch_bounds__(128 * WM, gemm_waves_per_simd(MI, NI, STAGES, LORA,
     }
 }
 
+// split-K second pass: C = epi(c32) with the epilogue of gemm_kernel (bias, per-sample row bias, LoRA up-projection of
+// the reduced T, residual), one thread per 4 consecutive columns of one row.
+__global__ __launch_bounds__(256) void gemm_finalize_kernel(const GemmArgs p) {
+    const int nq = p.N >> 2;
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long)p.M * nq) return;
+    const int m = (int)(idx / nq);
+    const int n = (int)(idx - (long)m * nq) * 4;
+    const f32x4 c4 = *(const f32x4*)(p.c32 + (long)m * p.N + n);
+    float v[4] = {c4[0], c4[1], c4[2], c4[3]};
+    if (p.bias) {
+        const bf16x4 b4 = *(const bf16x4*)(p.bias + n);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] += (float)b4[e];
+    }
+    if (p.rowbias) {
+        const bf16x4 b4 = *(const bf16x4*)(p.rowbias + (long)(m / p.rows_per_sample) * p.ld_rowbias + n);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] += (float)b4[e];
+    }
+    const float* T = p.lora_down ? p.t32 : p.lora_t;
+    if (T) {
+        const float lscale = *p.lora_scale;
+        if (!p.lora_up_rmajor) {
+            const int g = n / p.lora_cols_per_group;
+            const f32x4 t = *(const f32x4*)(T + (long)m * p.ld_t + g * 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const bf16x4 u = *(const bf16x4*)(p.lora_up + (long)(n + e) * 4);
+                v[e] += lscale * (t[0] * (float)u[0] + t[1] * (float)u[1] + t[2] * (float)u[2] + t[3] * (float)u[3]);
+            }
+        } else {
+            float s4[4] = {0.f, 0.f, 0.f, 0.f};
+            for (int r = 0; r < p.lora_rank; ++r) {
+                const float tr = T[(long)m * p.ld_t + r];
+                const bf16x4 u = *(const bf16x4*)(p.lora_up + (long)r * p.N + n);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) s4[e] += tr * (float)u[e];
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] += lscale * s4[e];
+        }
+    }
+    if (p.residual) {
+        const bf16x4 r4 = *(const bf16x4*)(p.residual + (long)m * p.ld_res + n);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] += (float)r4[e];
+    }
+    bf16x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = (__bf16)v[e];
+    *(bf16x4*)(p.c + (long)m * p.ldc + n) = o;
+}
+
 template <int MI, int NI, int MODE, bool LORA, int WM>
 int launch_gemm3(const GemmArgs& a, int stages, hipStream_t s) {
-    const int grid = a.tiles_m * a.tiles_n;
+    const int grid = a.tiles_m * a.tiles_n * (a.splitk > 1 ? a.splitk : 1);
     constexpr int stage_bytes = (32 * MI * WM + 64 * NI + (LORA ? 32 : 0)) * 128;
     constexpr bool can3 = 3 * stage_bytes <= 160 * 1024;
     constexpr bool can4 = 4 * stage_bytes <= 160 * 1024;
@@ -629,6 +725,11 @@ int launch_gemm3(const GemmArgs& a, int stages, hipStream_t s) {
     else
         hipLaunchKernelGGL((gemm_kernel<MI, NI, MODE, 2, LORA, WM>), dim3(grid), dim3(128 * WM), 0, s, a);
     SLH_LAUNCH_CHECK("slh_gemm");
+    if (a.splitk > 1) {
+        const long nthr = (long)a.M * (a.N >> 2);
+        hipLaunchKernelGGL(gemm_finalize_kernel, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, s, a);
+        SLH_LAUNCH_CHECK("slh_gemm (split-K finalize)");
+    }
     return 0;
 }
 
@@ -759,6 +860,17 @@ extern "C" int slh_gemm(const slh_gemm_desc* d, slh_stream_t stream) {
     a.lora_rank = d->lora_rank > 0 ? d->lora_rank : 4; a.lora_up_rmajor = d->lora_up_rmajor;
     a.w_packed = d->w_layout;
     a.probe = d->reserved_;
+    a.splitk = (d->tile >> 16) & 15;
+    a.c32 = d->splitk_c32;
+    a.t32 = d->splitk_t32 ? d->splitk_t32 : d->lora_t_out;
+    if (a.splitk > 1) {
+        SLH_CHECK(d->splitk_c32, "slh_gemm: split-K needs the zeroed fp32 workspace splitk_c32");
+        SLH_CHECK(!d->geglu, "slh_gemm: split-K excludes the GEGLU epilogue");
+        SLH_CHECK(!d->lora_down || a.t32, "slh_gemm: split-K with a fused adapter needs splitk_t32 (or lora_t_out), zeroed");
+        if (a.splitk > d->K / 64) a.splitk = d->K / 64;
+    } else {
+        a.splitk = 1;
+    }
     a.store16 = (d->ldc % 8 == 0) && (((uintptr_t)d->c & 15) == 0);
     a.tiles_m = (d->M + 32 * MI * WM - 1) / (32 * MI * WM);
     a.tiles_n = (d->N + 64 * NI - 1) / (64 * NI);

@@ -64,6 +64,25 @@ class Act:
 
 Src = Union[Act, Tuple[Act, Act]]
 
+SPLITK_MAX_MN = 1 << 20          # output elements up to which a split-K workspace is provisioned (4 MB fp32)
+SPLITK_MIN_K = 2048
+
+
+def splitk_candidate(d) -> bool:
+    """Few output tiles and a long reduction (the 1280-channel convolutions at 8x8 / 16x16 of SD-1.x and of SDXL at
+    512x512: 10-40 tiles for 256 CUs, 29 MB of weights each): such a product gets a zeroed fp32 workspace so that
+    slh_gemm may cut K into slices (tile bits 16-19, chosen by the tuner or by default_splitk below)."""
+    return d.M * d.N <= SPLITK_MAX_MN and d.K >= SPLITK_MIN_K and not d.geglu and d.N % 4 == 0
+
+
+def default_splitk(d) -> int:
+    """Untuned shape: slices so that tiles x slices is about one workgroup per CU, at least 8 K tiles per slice."""
+    tiles = ((d.M + 127) // 128) * ((d.N + 63) // 64)
+    if tiles >= 128 or d.K < 4096:
+        return 0
+    s = min(8, max(1, 256 // tiles), d.K // 512)
+    return 0 if s < 2 else (s << 16) | 0x412
+
 
 def _src_parts(x: Src):
     if isinstance(x, tuple):
@@ -180,7 +199,9 @@ class UNetPlan:
             R = sum(e.target.rank for e in grp)
             if fused:
                 # lora_down rides inside the GEMM (third operand tile); T is only written out for the backward
-                T = self.f32((M, R), name + ".T") if self.train else None
+                # (zero-initialised when the product may run split-K: the slices then accumulate into it)
+                may_split = M * N <= SPLITK_MAX_MN and K >= SPLITK_MIN_K and not geglu
+                T = self.f32((M, R), name + ".T", zero=may_split) if (self.train or may_split) else None
             else:
                 T = self.skinny(x, self.lora.down_ptr(grp[0]), R, K, conv, M, Ho, Wo, name + ".lora_down")
         d = lib.GemmDesc(a0=x0.ptr, a1=x1.ptr if x1 else 0,
@@ -189,7 +210,8 @@ class UNetPlan:
                          rowbias=rowbias[0] if rowbias else 0,
                          lora_t=T.ptr if (T and not fused) else 0, lora_up=self.lora.up_ptr(grp[0]) if grp else 0,
                          lora_down=self.lora.down_ptr(grp[0]) if fused else 0,
-                         lora_t_out=T.ptr if (T and fused) else 0, lora_rank=(4 * len(grp)) if fused else 0,
+                         lora_t_out=T.ptr if (T and fused and self.train) else 0,
+                         splitk_t32=T.ptr if (T and fused) else 0, lora_rank=(4 * len(grp)) if fused else 0,
                          lora_scale=self.lora_scale_ptr if grp else 0,
                          residual=residual.ptr if residual else 0, c=out.ptr,
                          lda0=x0.ld, lda1=x1.ld if x1 else 0, ca0=x0.C, ca1=x1.C if x1 else 0,
@@ -200,9 +222,13 @@ class UNetPlan:
                          w_layout=1 if (w_ptr is None and self.w.packed) else 0)
         if conv is not None:
             self._conv_fields(d, x0, conv, Ho, Wo)
+        if splitk_candidate(d):
+            d.splitk_c32 = self.f32((M, N), name + ".splitk", zero=True).ptr
         d.tile = tuned_tile(d)
         if not d.tile and M <= 192 and N >= 4096:
             d.tile = 0x12        # few rows, very wide: 64-row tiles waste the least of the short M
+        if not d.tile and d.splitk_c32:
+            d.tile = default_splitk(d)
         self.prog.add(lib.OP_GEMM, d, name)
         if self.train:
             self.tape.append(dict(op="gemm", x=x, out=out, wname=wname, N=N, K=K, conv=conv, grp=grp, T=T,
@@ -633,6 +659,10 @@ class BackwardPlan:
             d.qt, d.dot, d.ldqt, d.dk, d.dv, d.lddk, d.lddv = qt.ptr, dot.ptr, ldqt, gk.ptr, gv.ptr, gk.ld, gv.ld
         self.prog.add(lib.OP_ATTN_BWD, d, "bwd." + rec["name"])
 
+    def _splitk(self, d, name):
+        if splitk_candidate(d):
+            d.splitk_c32 = self.zarena.alloc((d.M, d.N), torch.float32, name + ".splitk").ptr
+
     def _b_gemm(self, rec):
         y = rec["out"]
         if not self.has_grad(y):
@@ -714,7 +744,8 @@ class BackwardPlan:
             if grp is not None:
                 d.lora_t, d.ld_t, d.lora_up, d.lora_scale = U.ptr, 4 * len(grp), self.lora.down_ptr(grp[0]), self.scale_ptr
                 d.lora_groups, d.lora_rank, d.lora_up_rmajor = 1, 4 * len(grp), 1
-            d.tile = tuned_tile(d)
+            self._splitk(d, name)
+            d.tile = tuned_tile(d) or (default_splitk(d) if d.splitk_c32 else 0)
             self.prog.add(lib.OP_GEMM, d, name + ".dgrad")
             if x1 is not None:
                 if need0:
@@ -735,7 +766,8 @@ class BackwardPlan:
                              batch=self.nb, hs=Ho, ws=Wo, src_xform=2 if stride == 2 else 0, stride=1, ho=HL, wo=WL,
                              ldw=9 * N, M=self.nb * HL * WL, N=cin, K=9 * N, ld_res=tgt.ld, ldc=tgt.ld,
                              rows_per_sample=HL * WL, w_layout=1 if self.w.packed else 0)
-            d.tile = tuned_tile(d)
+            self._splitk(d, name)
+            d.tile = tuned_tile(d) or (default_splitk(d) if d.splitk_c32 else 0)
             self.prog.add(lib.OP_GEMM, d, name + ".dgrad")
             if grp is not None:
                 d2 = lib.LoraCdgradDesc(u=U.ptr, a_down=self.lora.down_ptr(grp[0]), scale=self.scale_ptr, gx=tgt.ptr,

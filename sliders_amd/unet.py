@@ -54,7 +54,7 @@ class UNetEngine:
         self._plans: Dict[Tuple, UNetPlan] = {}
         self._arena_bytes = arena_bytes
         self.arena: Optional[Arena] = None
-        self.zarena = Arena(64 << 20, self.device, "zero-init accumulators")
+        self.zarena = Arena(2048 << 20, self.device, "zero-init accumulators")   # GroupNorm statistics, loss, split-K partial sums
         self.train_plan: Optional[UNetPlan] = None
         self.one = torch.ones(1, dtype=torch.float32, device=self.device)
         self.grad_all_samples = False

@@ -524,3 +524,54 @@ def test_gemm_fused_lora_down(dev, tile):
     torch.cuda.synchronize()
     report(f"conv_fused_lora tile{tile:x}", c, ref, TOL)
     report(f"conv_fused_lora T tile{tile:x}", Tout, _to_pix(t_img), 1e-5)
+
+
+@pytest.mark.parametrize("tile", [0x20412, 0x40421, 0x80422, 0x44412, 0x30011, 0x20022, 0xf0412])
+def test_gemm_splitk(dev, tile):
+    """Split-K (slh_gemm_desc.tile bits 16-19): K slices accumulate into the zeroed fp32 workspace, the second launch
+    applies the epilogue.  Dense + bias + residual, 3x3 convolution, fused LoRA down/up (T reduced too), two-source K."""
+    torch.manual_seed(tile & 0xff)
+    M, N, K = 300, 320, 1280
+    x = bf(torch.randn(M, K, device=dev))
+    w = bf(torch.randn(N, K, device=dev) / math.sqrt(K))
+    bias = bf(torch.randn(N, device=dev))
+    res = bf(torch.randn(M, N, device=dev))
+    c = torch.zeros(M, N, device=dev, dtype=torch.bfloat16)
+    ws = torch.zeros(M, N, device=dev)
+    d = lib.GemmDesc(a0=p(x), w=p(w), bias=p(bias), residual=p(res), c=p(c), lda0=K, ca0=K, mode=0, stride=1, ldw=K,
+                     M=M, N=N, K=K, ld_res=N, ldc=N, rows_per_sample=M, tile=tile, splitk_c32=p(ws))
+    lib.call(lib.OP_GEMM, d, stream())
+    torch.cuda.synchronize()
+    report(f"splitk dense tile{tile:x}", c, x.float() @ w.float().t() + bias.float() + res.float(), TOL)
+    # fused adapter: T is reduced across the slices as well
+    A = bf(torch.randn(8, K, device=dev) / math.sqrt(K))
+    up = bf(torch.randn(N, 4, device=dev))
+    scale = torch.tensor([0.25], device=dev)
+    ws.zero_()
+    T32 = torch.zeros(M, 8, device=dev)
+    d = lib.GemmDesc(a0=p(x), w=p(w), bias=p(bias), c=p(c), lora_down=p(A), lora_up=p(up), lora_scale=p(scale), lda0=K, ca0=K,
+                     mode=0, stride=1, ldw=K, M=M, N=N, K=K, ldc=N, rows_per_sample=M, ld_t=8, lora_groups=2, lora_rank=8,
+                     tile=tile, splitk_c32=p(ws), splitk_t32=p(T32))
+    lib.call(lib.OP_GEMM, d, stream())
+    torch.cuda.synchronize()
+    T = x.float() @ A.float().t()
+    ref = x.float() @ w.float().t() + bias.float()
+    for g in range(2):
+        ref[:, g * 160:(g + 1) * 160] += 0.25 * T[:, 4 * g:4 * g + 4] @ up.float()[g * 160:(g + 1) * 160].t()
+    report(f"splitk fused lora tile{tile:x}", c, ref, TOL)
+    report(f"splitk fused lora T tile{tile:x}", T32, T, 1e-5)
+    # 3x3 convolution, two sources, stride 1
+    B, H, W, C0, C1, Co = 2, 8, 8, 128, 64, 128
+    i0, i1 = bf(torch.randn(B, C0, H, W, device=dev)), bf(torch.randn(B, C1, H, W, device=dev))
+    w4 = bf(torch.randn(Co, C0 + C1, 3, 3, device=dev) / math.sqrt(9 * (C0 + C1)))
+    ref = _to_pix(_conv_ref(torch.cat([i0, i1], 1).float(), w4.float()))
+    x0, x1 = bf(_to_pix(i0.float())), bf(_to_pix(i1.float()))
+    Mc = B * H * W
+    cc = torch.zeros(Mc, Co, device=dev, dtype=torch.bfloat16)
+    wsc = torch.zeros(Mc, Co, device=dev)
+    d = lib.GemmDesc(a0=p(x0), a1=p(x1), w=p(_pack_conv(w4)), c=p(cc), lda0=C0, lda1=C1, ca0=C0, ca1=C1, mode=1, batch=B, hs=H,
+                     ws=W, stride=1, ho=H, wo=W, ldw=9 * (C0 + C1), M=Mc, N=Co, K=9 * (C0 + C1), ldc=Co, rows_per_sample=H * W,
+                     tile=tile, splitk_c32=p(wsc))
+    lib.call(lib.OP_GEMM, d, stream())
+    torch.cuda.synchronize()
+    report(f"splitk conv 2src tile{tile:x}", cc, ref, TOL)
