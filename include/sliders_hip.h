@@ -362,6 +362,8 @@ typedef struct slh_sgemm_desc {
     int32_t cin, batch, hs, ws, ho, wo, stride, pad;   /* pad 1: symmetric; pad 0 with stride 2: zero pad right/bottom (Downsample2D(padding=0)) */
     int32_t bias_per_row;
     float alpha;            /* C = alpha * (X W^T) + bias + residual */
+    int32_t upsample;       /* conv: 1 = the source is read through a nearest-2x upsample (Upsample2D), ho = 2*hs */
+    int32_t pad2_;
 } slh_sgemm_desc;
 int slh_sgemm(const slh_sgemm_desc* d, slh_stream_t stream);
 
@@ -384,10 +386,14 @@ typedef struct slh_vae_conv_desc {
     const void* w; const void* bias;      /* conv_in: [cout][3][3][3]; moments: conv_out [8][3][3][cin], [8] */
     const void* qw; const void* qb;       /* moments only: quant_conv [8][8], [8] */
     void* y;                /* conv_in: [batch*h*wd][cout]; moments: [batch*h*wd][8] = mean | logvar */
-    int32_t batch, h, wd, cin, cout, pad_;
+    int32_t batch, h, wd, cin, cout;
+    float inv_scaling;      /* post_quant only: 1 / vae.config.scaling_factor */
 } slh_vae_conv_desc;
-int slh_vae_conv_in(const slh_vae_conv_desc* d, slh_stream_t stream);
+int slh_vae_conv_in(const slh_vae_conv_desc* d, slh_stream_t stream);    /* cin 3 (encoder) or 4 (decoder conv_in) */
 int slh_vae_moments(const slh_vae_conv_desc* d, slh_stream_t stream);
+/* decoder input: x = latents NCHW [batch][4][h*wd] (fp32, or bf16 if cin == 1) -> * inv_scaling -> post_quant_conv (qw [4][4],
+ * qb [4]) -> y pixel-major [batch*h*wd][4] fp32.  eval-scripts/generate_images_sd1.py:166-168. */
+int slh_vae_post_quant(const slh_vae_conv_desc* d, slh_stream_t stream);
 
 typedef struct slh_vae_sample_desc {
     const float* moments;       /* [batch*hw][8] */
@@ -414,7 +420,7 @@ enum {
     SLH_OP_WGRAD = 14, SLH_OP_ADAMW = 15, SLH_OP_GN_BWD_STATS = 16, SLH_OP_GN_BWD_APPLY = 17,
     SLH_OP_LAYERNORM_BWD = 18, SLH_OP_ATTN_BWD = 19, SLH_OP_MEMSET = 20, SLH_OP_LORA_CONV_DGRAD = 21,
     SLH_OP_TEMB_LORA_BWD = 22, SLH_OP_SGEMM = 23, SLH_OP_GN32_STATS = 24, SLH_OP_GN32_APPLY = 25, SLH_OP_SOFTMAX32 = 26,
-    SLH_OP_VAE_CONV_IN = 27, SLH_OP_VAE_MOMENTS = 28, SLH_OP_VAE_SAMPLE = 29
+    SLH_OP_VAE_CONV_IN = 27, SLH_OP_VAE_MOMENTS = 28, SLH_OP_VAE_SAMPLE = 29, SLH_OP_VAE_POST_QUANT = 30
 };
 typedef struct slh_memset_desc { void* ptr; int64_t nbytes; int32_t value; int32_t pad; } slh_memset_desc;
 int slh_run_program(const void* program, int64_t nbytes, slh_stream_t stream);

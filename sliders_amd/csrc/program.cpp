@@ -70,6 +70,7 @@ extern "C" int slh_run_program(const void* program, int64_t nbytes, slh_stream_t
             case SLH_OP_SOFTMAX32: rc = run_desc<slh_softmax32_desc>(p, sz, slh_softmax32, stream, "softmax32"); break;
             case SLH_OP_VAE_CONV_IN: rc = run_desc<slh_vae_conv_desc>(p, sz, slh_vae_conv_in, stream, "vae_conv_in"); break;
             case SLH_OP_VAE_MOMENTS: rc = run_desc<slh_vae_conv_desc>(p, sz, slh_vae_moments, stream, "vae_moments"); break;
+            case SLH_OP_VAE_POST_QUANT: rc = run_desc<slh_vae_conv_desc>(p, sz, slh_vae_post_quant, stream, "vae_post_quant"); break;
             case SLH_OP_VAE_SAMPLE: rc = run_desc<slh_vae_sample_desc>(p, sz, slh_vae_sample, stream, "vae_sample"); break;
             case SLH_OP_MEMSET: {
                 if (sz != (int32_t)sizeof(slh_memset_desc)) { slh_set_error("slh_run_program: memset desc size"); return -3; }

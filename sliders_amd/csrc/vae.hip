@@ -70,8 +70,9 @@ __global__ __launch_bounds__(256) void sgemm_kernel(const slh_sgemm_desc d) {
             const int tap = k0 / cin, c0 = k0 - tap * cin;
             const int ky = tap / 3, kx = tap - ky * 3;
             const int iy = xoy * d.stride + ky - d.pad, ix = xox * d.stride + kx - d.pad;
-            ok = ok && iy >= 0 && iy < d.hs && ix >= 0 && ix < d.ws;
-            src = X + (((long)xb * d.hs + iy) * d.ws + ix) * d.ldx + c0;
+            const int sh = d.upsample ? 1 : 0;         // nearest-2x upsampled source (Upsample2D): read pixel (iy>>1, ix>>1)
+            ok = ok && iy >= 0 && iy < (d.hs << sh) && ix >= 0 && ix < (d.ws << sh);
+            src = X + (((long)xb * d.hs + (iy >> sh)) * d.ws + (ix >> sh)) * d.ldx + c0;
         }
         a = ok ? *(const f4*)(src + 4 * kq) : z;
         b = ok ? *(const f4*)(src + 4 * (kq + 2)) : z;
@@ -235,10 +236,10 @@ __global__ __launch_bounds__(256) void softmax32_kernel(float* x, int rows, int 
     }
 }
 
-// conv_in: image [B][H*W][3] fp32 (pixel-major, values in [-1,1]) -> [B*H*W][cout] fp32, 3x3 pad 1.
-// w: [cout][3(ky)][3(kx)][3(c)] fp32.  One thread = one pixel x 4 output channels.
+// conv_in: image [B][H*W][cin] fp32 (pixel-major; cin = 3: encoder input in [-1,1], cin = 4: decoder latents)
+// -> [B*H*W][cout] fp32, 3x3 pad 1.  w: [cout][3(ky)][3(kx)][cin] fp32.  One thread = one pixel x 4 output channels.
 __global__ __launch_bounds__(256) void vae_conv_in_kernel(const float* img, const float* w, const float* bias, float* y,
-                                                          int B, int H, int Wd, int cout) {
+                                                          int B, int H, int Wd, int cout, int cin) {
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const int nq = cout / 4;
     const long total = (long)B * H * Wd * nq;
@@ -255,12 +256,12 @@ __global__ __launch_bounds__(256) void vae_conv_in_kernel(const float* img, cons
         for (int kx = 0; kx < 3; ++kx) {
             const int ix = ox + kx - 1;
             if (ix < 0 || ix >= Wd) continue;
-            const float* p = img + (((long)b * H + iy) * Wd + ix) * 3;
-            const float x0 = p[0], x1 = p[1], x2 = p[2];
+            const float* p = img + (((long)b * H + iy) * Wd + ix) * cin;
+            const float x0 = p[0], x1 = p[1], x2 = p[2], x3 = cin > 3 ? p[3] : 0.f;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const float* wp = w + ((long)(co + e) * 9 + ky * 3 + kx) * 3;
-                acc[e] += x0 * wp[0] + x1 * wp[1] + x2 * wp[2];
+                const float* wp = w + ((long)(co + e) * 9 + ky * 3 + kx) * cin;
+                acc[e] += x0 * wp[0] + x1 * wp[1] + x2 * wp[2] + (cin > 3 ? x3 * wp[3] : 0.f);
             }
         }
     }
@@ -319,7 +320,35 @@ __global__ __launch_bounds__(256) void vae_sample_kernel(const slh_vae_sample_de
     if (d.noisy_bf16) ((__bf16*)d.noisy_bf16)[idx] = (__bf16)noisy;
 }
 
+// decoder input: z NCHW [B][4][hw] (fp32 or bf16) -> (z * inv_scaling) -> post_quant_conv 1x1 (4 -> 4) -> pixel-major [B*hw][4]
+__global__ __launch_bounds__(256) void vae_post_quant_kernel(const void* z, int z_bf16, const float* qw, const float* qb, float* y,
+                                                             int B, int hw, float inv_scaling) {
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long)B * hw) return;
+    const int b = (int)(idx / hw), pix = (int)(idx - (long)b * hw);
+    float v[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const long o = ((long)b * 4 + c) * hw + pix;
+        v[c] = (z_bf16 ? (float)((const __bf16*)z)[o] : ((const float*)z)[o]) * inv_scaling;
+    }
+    f4 out;
+#pragma unroll
+    for (int o = 0; o < 4; ++o) out[o] = qb[o] + qw[o * 4] * v[0] + qw[o * 4 + 1] * v[1] + qw[o * 4 + 2] * v[2] + qw[o * 4 + 3] * v[3];
+    *(f4*)(y + idx * 4) = out;
+}
+
 }  // namespace
+
+extern "C" int slh_vae_post_quant(const slh_vae_conv_desc* d, slh_stream_t stream) {
+    SLH_CHECK(d && d->x && d->qw && d->qb && d->y, "slh_vae_post_quant: bad descriptor");
+    const long n = (long)d->batch * d->h * d->wd;
+    hipLaunchKernelGGL(vae_post_quant_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, d->x,
+                       d->cin /* 1: z is bf16 */, (const float*)d->qw, (const float*)d->qb, (float*)d->y, d->batch, d->h * d->wd,
+                       d->inv_scaling);
+    SLH_LAUNCH_CHECK("slh_vae_post_quant");
+    return 0;
+}
 
 extern "C" int slh_sgemm(const slh_sgemm_desc* d, slh_stream_t stream) {
     SLH_CHECK(d && d->x && d->w && d->c, "slh_sgemm: null pointer");
@@ -373,10 +402,11 @@ extern "C" int slh_softmax32(const slh_softmax32_desc* d, slh_stream_t stream) {
 }
 
 extern "C" int slh_vae_conv_in(const slh_vae_conv_desc* d, slh_stream_t stream) {
-    SLH_CHECK(d && d->x && d->w && d->bias && d->y && d->cout % 4 == 0, "slh_vae_conv_in: bad descriptor");
+    SLH_CHECK(d && d->x && d->w && d->bias && d->y && d->cout % 4 == 0 && (d->cin == 3 || d->cin == 4), "slh_vae_conv_in: bad descriptor");
     const long total = (long)d->batch * d->h * d->wd * (d->cout / 4);
     hipLaunchKernelGGL(vae_conv_in_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                       (const float*)d->x, (const float*)d->w, (const float*)d->bias, (float*)d->y, d->batch, d->h, d->wd, d->cout);
+                       (const float*)d->x, (const float*)d->w, (const float*)d->bias, (float*)d->y, d->batch, d->h, d->wd, d->cout,
+                       d->cin);
     SLH_LAUNCH_CHECK("slh_vae_conv_in");
     return 0;
 }

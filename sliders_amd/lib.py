@@ -79,11 +79,12 @@ TembLoraBwdDesc = _struct("TembLoraBwdDesc", _ptrs("g", "t", "up", "emb", "d_up"
 # image sliders: fp32 AutoencoderKL encoder (csrc/vae.hip)
 SgemmDesc = _struct("SgemmDesc", _ptrs("x", "w", "bias", "residual", "c")
                     + _ints("ldx", "ldw", "ldr", "ldc", "M", "N", "K", "mode", "cin", "batch", "hs", "ws", "ho", "wo", "stride",
-                            "pad", "bias_per_row") + [("alpha", c_f32)])
+                            "pad", "bias_per_row") + [("alpha", c_f32)] + _ints("upsample", "pad2_"))
 Gn32Desc = _struct("Gn32Desc", _ptrs("x", "gamma", "beta", "stats", "y") + _ints("ldx", "ldy", "C", "batch", "hw", "groups")
                    + [("eps", c_f32)] + _ints("act"))
 Softmax32Desc = _struct("Softmax32Desc", _ptrs("x") + [("ld", c_i64)] + _ints("rows", "cols"))
-VaeConvDesc = _struct("VaeConvDesc", _ptrs("x", "w", "bias", "qw", "qb", "y") + _ints("batch", "h", "wd", "cin", "cout", "pad_"))
+VaeConvDesc = _struct("VaeConvDesc", _ptrs("x", "w", "bias", "qw", "qb", "y") + _ints("batch", "h", "wd", "cin", "cout")
+                      + [("inv_scaling", c_f32)])
 VaeSampleDesc = _struct("VaeSampleDesc", _ptrs("moments", "post_noise", "noise", "latent_f32", "noisy_f32", "noisy_bf16")
                         + _ints("batch", "hw") + [("scaling", c_f32), ("sqrt_alpha", c_f32), ("sqrt_one_minus_alpha", c_f32)]
                         + _ints("pad_"))
@@ -98,7 +99,7 @@ OP_GEMM, OP_SKINNY, OP_GEMV, OP_GN_STATS, OP_GN_APPLY, OP_LAYERNORM, OP_ATTN_FWD
 OP_TEMBED, OP_CONV_IN, OP_ELEMENTWISE, OP_CFG_DDIM, OP_LOSS, OP_WGRAD, OP_ADAMW = range(9, 16)
 OP_GN_BWD_STATS, OP_GN_BWD_APPLY, OP_LAYERNORM_BWD, OP_ATTN_BWD, OP_MEMSET = range(16, 21)
 OP_LORA_CONV_DGRAD, OP_TEMB_LORA_BWD = 21, 22
-OP_SGEMM, OP_GN32_STATS, OP_GN32_APPLY, OP_SOFTMAX32, OP_VAE_CONV_IN, OP_VAE_MOMENTS, OP_VAE_SAMPLE = range(23, 30)
+OP_SGEMM, OP_GN32_STATS, OP_GN32_APPLY, OP_SOFTMAX32, OP_VAE_CONV_IN, OP_VAE_MOMENTS, OP_VAE_SAMPLE, OP_VAE_POST_QUANT = range(23, 31)
 
 EW_COPY, EW_ADD, EW_GEGLU_FWD, EW_GEGLU_BWD, EW_UPSAMPLE_BWD, EW_COLSUM = range(6)
 
@@ -117,6 +118,7 @@ _ENTRY = {
     OP_SGEMM: ("slh_sgemm", SgemmDesc), OP_GN32_STATS: ("slh_gn32_stats", Gn32Desc), OP_GN32_APPLY: ("slh_gn32_apply", Gn32Desc),
     OP_SOFTMAX32: ("slh_softmax32", Softmax32Desc), OP_VAE_CONV_IN: ("slh_vae_conv_in", VaeConvDesc),
     OP_VAE_MOMENTS: ("slh_vae_moments", VaeConvDesc), OP_VAE_SAMPLE: ("slh_vae_sample", VaeSampleDesc),
+    OP_VAE_POST_QUANT: ("slh_vae_post_quant", VaeConvDesc),
 }
 
 EXPORTS = ["slh_version", "slh_last_error", "slh_run_program", "slh_desc_sizes"] + [v[0] for v in _ENTRY.values()]

@@ -1,0 +1,82 @@
+"""Slider inference on the MI355X engine: the sampling loop the reference's consumers run over a trained slider
+(eval-scripts/generate_images_sd1.py:136-171, trainscripts/textsliders/generate_images_xl.py:39-394, the inference
+notebooks):
+
+    latents = randn(seed) * init_noise_sigma
+    for t in scheduler.timesteps (DDIM, `ddim_steps`):
+        network.set_lora_slider(scale = 0 if t > start_noise else scale)
+        with network: eps = unet(cat([latents] * 2), t, cat([uncond, text]) [, added_cond_kwargs])
+        eps = eps_uncond + guidance_scale * (eps_text - eps_uncond)
+        latents = scheduler.step(eps, t, latents).prev_sample
+    image = vae.decode(latents / scaling_factor); image = (image / 2 + 0.5).clamp(0, 1)
+
+Every UNet evaluation is one replay of the engine's LoRA-on command buffer (the adapter scale is a device scalar, so
+gating it per step costs nothing); CFG combine + DDIM step is the fused slh_cfg_ddim kernel; the VAE decoder is the fp32
+command buffer of sliders_amd/vae.py.  This is what lets a slider trained here be evaluated here (CLIP-score direction,
+eval-scripts/clip_score.py) without the diffusers pipelines.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from . import lib
+from .ddim import DDIMSchedule
+from .lora_store import LoraStore
+from .unet import UNetEngine
+from .vae import VaeDecoder
+
+
+class SliderSampler:
+    def __init__(self, engine: UNetEngine, store: Optional[LoraStore] = None, decoder: Optional[VaeDecoder] = None):
+        self.eng, self.store, self.decoder = engine, store, decoder
+        if store is not None and engine.lora is not store:
+            engine.attach_lora(store)
+        self.sched = DDIMSchedule()
+
+    @torch.no_grad()
+    def sample_latents(self, ctx: torch.Tensor, noise: torch.Tensor, scale: float = 0.0, start_noise: int = 750,
+                       ddim_steps: int = 50, guidance_scale: float = 7.5, pooled: Optional[torch.Tensor] = None,
+                       time_ids: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """ctx: (2*bs, 77, D) = cat([unconditional, text]); noise: (bs, 4, h, w) (already * init_noise_sigma = 1);
+        returns the final latents (bs, 4, h, w) bf16.  LoRA multiplier per step: 0 while t > start_noise, `scale` after."""
+        eng = self.eng
+        bs, _, h, w = noise.shape
+        mode = "on" if self.store is not None else "off"
+        p = eng.plan(2 * bs, h, w, mode)
+        io = p.io
+        io["ctx"].tensor.copy_(ctx.to(torch.bfloat16))
+        if eng.cfg.is_xl:
+            if time_ids is None:
+                time_ids = torch.tensor([[h * 8.0, w * 8.0, 0.0, 0.0, h * 8.0, w * 8.0]] * (2 * bs))
+            io["time_ids"].tensor.copy_(time_ids.to(device=eng.device, dtype=torch.float32).reshape(2 * bs, 6))
+            io["add_in"].tensor[:, : eng.cfg.pooled_dim].copy_(pooled.to(torch.bfloat16))
+        smp = io["sample"]
+        lat = noise.to(eng.device, torch.bfloat16)
+        smp.tensor[:bs].copy_(lat)
+        smp.tensor[bs:].copy_(lat)
+        s = torch.cuda.current_stream().cuda_stream
+        chw = eng.cfg.out_channels * h * w
+        half = bs * chw * 2
+        for t in self.sched.make_timesteps(ddim_steps):
+            if self.store is not None:
+                eng.set_lora(True, 0.0 if t > start_noise else float(scale))
+            io["t"].tensor.fill_(float(t))
+            p.prog.run(s)
+            cb, cia, cp, cd = self.sched.step_coefficients(t, ddim_steps)
+            d = lib.CfgDdimDesc(eps=io["eps"].ptr, x=smp.ptr, out=smp.ptr, out2=smp.ptr + half, nb=bs, chw=chw,
+                                guidance=float(guidance_scale), c_sqrt_beta_t=cb, c_inv_sqrt_alpha_t=cia,
+                                c_sqrt_alpha_prev=cp, c_dir=cd, do_step=1)
+            lib.call(lib.OP_CFG_DDIM, d, s)
+        if self.store is not None:
+            eng.set_lora(False)
+        return smp.tensor[:bs].clone()
+
+    @torch.no_grad()
+    def generate(self, ctx, noise, **kw) -> torch.Tensor:
+        """-> uint8 images [bs][H][W][3] (needs a VaeDecoder)."""
+        if self.decoder is None:
+            raise RuntimeError("SliderSampler.generate needs a VaeDecoder")
+        lat = self.sample_latents(ctx, noise, **kw)
+        return VaeDecoder.to_uint8(self.decoder.decode(lat))

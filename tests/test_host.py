@@ -413,3 +413,14 @@ def test_vae_encoder_refuses_cpu():
     from sliders_amd.vae import VaeEncoder, random_vae_state_dict
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         VaeEncoder(random_vae_state_dict((128, 128, 128, 128)), "cpu")
+
+
+def test_generate_parses_the_slider_file_name_like_the_notebooks():
+    """XL-sliders-inference.ipynb cell 6: rank / alpha / train_method come from substrings of the checkpoint path."""
+    from sliders_amd.generate import build_parser, parse_slider_name
+    assert parse_slider_name("models/age_alpha1.0_rank4_noxattn/age_alpha1.0_rank4_noxattn_last.pt") == (4, 1.0, "noxattn")
+    assert parse_slider_name("eyesize_alpha2_rank8_full_500steps.pt") == (8, 2.0, "full")
+    assert parse_slider_name("x_alpha1.0_rank4_xattn-strict_last.pt")[2] == "xattn-strict"
+    assert parse_slider_name("unnamed.pt") == (4, 1.0, "noxattn")
+    a = build_parser().parse_args(["--scales=-2,0,2", "--start_noise", "800", "--synthetic"])
+    assert a.start_noise == 800 and a.ddim_steps == 50 and a.guidance_scale == 7.5

@@ -200,3 +200,70 @@ def test_image_slider_iteration_matches_reference_loop_on_oracle(dev):
     assert cos > 0.995
     delta = (store.params.float() - params0.float()).abs()
     assert 0 < delta.max().item() < 5e-4
+
+
+@pytest.mark.parametrize("boc,B,h", [((128, 128, 256, 256), 2, 8), ((128, 256, 512, 512), 1, 16)])
+def test_vae_decoder(dev, boc, B, h):
+    """sliders_amd.vae.VaeDecoder vs the oracle: vae.decode(latents / scaling_factor) (generate_images_sd1.py:166-168)."""
+    from sliders_amd.vae import VaeDecoder
+    sd = random_vae_state_dict(boc, dev, seed=4, decoder=True)
+    dec = VaeDecoder(sd, dev, vae_oracle.VAE_SCALING["sd1"])
+    vae = vae_oracle.AutoencoderKL(boc, vae_oracle.VAE_SCALING["sd1"], with_decoder=True).eval()
+    vae.load_state_dict({k: v.float().cpu() for k, v in sd.items()}, strict=True)
+    g = torch.Generator().manual_seed(6)
+    lat = torch.randn(B, 4, h, h, generator=g)
+    for dt in (torch.float32, torch.bfloat16):
+        z = lat.to(dt)
+        img = dec.decode(z.to(dev))
+        torch.cuda.synchronize()
+        with torch.no_grad():
+            ref = vae.decode(z.float() * (1.0 / vae_oracle.VAE_SCALING["sd1"]))           # [B][3][8h][8h]
+        report(f"vae decode boc{boc} {dt}", img.cpu(), ref.permute(0, 2, 3, 1), 1e-4)
+        u8 = VaeDecoder.to_uint8(img).cpu()
+        ref8 = ((ref.permute(0, 2, 3, 1) / 2 + 0.5).clamp(0, 1) * 255).round().to(torch.uint8)
+        assert (u8.int() - ref8.int()).abs().max() <= 1
+
+
+@pytest.mark.parametrize("name", ["tiny_sdxl", "tiny_sd1"])
+def test_slider_sampler_matches_reference_loop_on_oracle(dev, name):
+    """The inference loop of eval-scripts/generate_images_sd1.py:160-164 / generate_images_xl.py (start_noise gating of the
+    slider scale, CFG 7.5, DDIM) against the same loop over the oracle UNet + oracle LoRA in fp32."""
+    from sliders_amd.sampler import SliderSampler
+    cfg = CONFIGS[name]()
+    hw, steps, start_noise, scale, gs = 16, 6, 600, 2.0, 7.5
+    g = torch.Generator().manual_seed(12)
+    torch.manual_seed(12)
+    store = LoraStore(cfg, rank=4, alpha=1.0, train_method="noxattn", device=dev)
+    for e in store.entries:
+        store.params[e.up_off:e.up_off + e.up_numel] = (torch.randn(e.up_numel, generator=g) * 0.03).to(dev, torch.bfloat16)
+    sd_lora = store.state_dict()
+    unc, txt = torch.randn(1, 77, cfg.cross_attention_dim, generator=g), torch.randn(1, 77, cfg.cross_attention_dim, generator=g)
+    pool = torch.randn(2, cfg.pooled_dim, generator=g) if cfg.is_xl else None
+    noise = torch.randn(1, 4, hw, hw, generator=g)
+    net = build_unet(name, seed=0)
+    eng = UNetEngine(cfg, net.state_dict(), dev)
+    ctx = torch.cat([unc, txt])
+    got = SliderSampler(eng, store).sample_latents(ctx.to(dev), noise.to(dev), scale=scale, start_noise=start_noise,
+                                                   ddim_steps=steps, guidance_scale=gs,
+                                                   pooled=pool.to(dev) if pool is not None else None)
+    torch.cuda.synchronize()
+    nw = LoRANetworkOracle(net, rank=4, multiplier=1.0, alpha=1.0, train_method="noxattn")
+    nw.load_state_dict(sd_lora, strict=True)
+    sch = DDIMScheduler()
+    sch.set_timesteps(steps)
+    size = hw * 8.0
+    kw = {"text_embeds": pool, "time_ids": torch.tensor([[size, size, 0, 0, size, size]] * 2)} if cfg.is_xl else None
+    x = noise.clone()
+    used = []
+    with torch.no_grad():
+        for t in sch.timesteps:
+            nw.set_lora_slider(0 if t > start_noise else scale)
+            used.append(float(nw.lora_scale))
+            with nw:
+                e = net(torch.cat([x] * 2), t, ctx, kw).sample
+            u, c = e.chunk(2)
+            x = sch.step(u + gs * (c - u), t, x).prev_sample
+    assert 0.0 in used and scale in used, "the test must exercise both sides of start_noise"
+    r = rel_err(got.float().cpu(), x)
+    print(f"[parity] sampler {name}: final latents rel_l2 {r:.3e} after {steps} steps (scales used {used})")
+    assert r < 2.5e-2
