@@ -24,7 +24,7 @@ _LEAVES = ["Linear", "Conv2d", "LoRACompatibleLinear", "LoRACompatibleConv"]
 
 
 class LoRAModuleOracle(nn.Module):
-    def __init__(self, lora_name: str, org: nn.Module, multiplier: float, rank: int, alpha: float):
+    def __init__(self, lora_name: str, org: nn.Module, multiplier: float, rank: int, alpha: float, apply: bool = True):
         super().__init__()
         self.lora_name = lora_name
         cls = org.__class__.__name__
@@ -43,8 +43,9 @@ class LoRAModuleOracle(nn.Module):
         nn.init.kaiming_uniform_(self.lora_down.weight, a=1)
         nn.init.zeros_(self.lora_up.weight)
         self.multiplier = multiplier
-        self._org_forward = org.forward
-        org.forward = self.forward
+        if apply:              # LoRAModule.apply_to (lora.py:103-106); duplicate visits are built but never applied
+            self._org_forward = org.forward
+            org.forward = self.forward
 
     def forward(self, x):
         return self._org_forward(x) + self.lora_up(self.lora_down(x)) * self.multiplier * self.scale
@@ -86,16 +87,14 @@ class LoRANetworkOracle(nn.Module):
                         "mid_block" not in name or ".1" not in name or "conv2" not in child_name):
                     continue
                 lora_name = ("lora_unet." + name + "." + child_name).replace(".", "_")
+                # the reference constructs the LoRAModule (RNG draws) BEFORE the duplicate-name check (lora.py:206-216)
+                m = LoRAModuleOracle(lora_name, child, multiplier, rank, alpha, apply=lora_name not in seen)
                 if lora_name in seen:
                     continue
                 seen.add(lora_name)
-                self.unet_loras.append((lora_name, child))
-        mods = []
-        for lora_name, child in self.unet_loras:
-            m = LoRAModuleOracle(lora_name, child, multiplier, rank, alpha)
-            self.add_module(lora_name, m)
-            mods.append(m)
-        self.unet_loras = mods
+                self.unet_loras.append(m)
+        for m in self.unet_loras:
+            self.add_module(m.lora_name, m)
 
     def set_lora_slider(self, scale):
         self.lora_scale = scale

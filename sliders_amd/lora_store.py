@@ -27,7 +27,7 @@ import torch
 import torch.nn as nn
 
 from .config import UNetConfig
-from .modules import LoraTarget, lora_targets
+from .modules import LoraTarget, lora_targets, lora_visits
 
 
 @dataclass
@@ -62,6 +62,7 @@ class LoraStore:
         self.rank = rank
         self.alpha = rank if alpha is None or alpha == 0 else alpha
         self.train_method = train_method
+        self.network_type = network_type
         self.device = device
         targets = lora_targets(cfg, train_method, rank, network_type)
         for t in targets:
@@ -172,12 +173,13 @@ class LoraStore:
         return (t.out_dim, t.rank) if t.kind == "linear" else (t.out_dim, t.rank, 1, 1)
 
     def init_reference(self, kaiming_a: float = 1.0):
-        """Same RNG draws, in the same order, as LoRAModule.__init__ (lora.py:68-97) so that
-        torch.manual_seed(s) gives the reference's initial adapter weights: the nn.Linear / nn.Conv2d
-        constructors draw their default init first, then kaiming_uniform_(down, a=1) and zeros_(up)."""
+        """Same RNG draws, in the same order, as the reference's network construction so that torch.manual_seed(s) gives
+        the reference's initial adapter weights: LoRAModule.__init__ (lora.py:68-97) lets the nn.Linear / nn.Conv2d
+        constructors draw their default init first, then kaiming_uniform_(down, a) and zeros_(up) - and create_modules
+        (lora.py:206-216) does so for the duplicate visits of the conv leaves as well, before dropping them by name.
+        Pinned by tests/golden/lora_init.json, produced by the reference's own LoRANetwork."""
         host = torch.zeros(self.numel, dtype=torch.float32)
-        for e in self.entries:
-            t = e.target
+        for t, dup in lora_visits(self.cfg, self.train_method, self.rank, self.network_type):
             if t.kind == "linear":
                 down = nn.Linear(t.in_dim, t.rank, bias=False)
                 up = nn.Linear(t.rank, t.out_dim, bias=False)
@@ -187,6 +189,9 @@ class LoraStore:
                 up = nn.Conv2d(t.rank, t.out_dim, (1, 1), (1, 1), bias=False)
             nn.init.kaiming_uniform_(down.weight, a=kaiming_a)
             nn.init.zeros_(up.weight)
+            if dup:
+                continue                       # constructed (RNG advanced) and discarded, like the reference
+            e = self.by_name[t.lora_name]
             host[e.down_off:e.down_off + e.down_numel] = self._down_to_kernel(e, down.weight.detach())
         self.params.copy_(host.to(torch.bfloat16))
 

@@ -218,6 +218,14 @@ class LoraTarget:
 
 def lora_targets(cfg: UNetConfig, train_method: str, rank: int = 4, network_type: str = "c3lier") -> List[LoraTarget]:
     """network_type 'c3lier' adds the conv classes (train_lora.py:44-46 mutates the shared list)."""
+    return [t for t, dup in lora_visits(cfg, train_method, rank, network_type) if not dup]
+
+
+def lora_visits(cfg: UNetConfig, train_method: str, rank: int = 4, network_type: str = "c3lier"):
+    """Every (target, is_duplicate) the reference's create_modules CONSTRUCTS, in its order (lora.py:164-218): with the
+    conv classes enabled, DownBlock2D / UpBlock2D are targets too, so every leaf under them is reached a second time
+    through its ResnetBlock2D / Downsample2D / Upsample2D parent; the reference builds a LoRAModule for that second
+    visit (drawing the RNG) and only then drops it by name.  Duplicates matter for seed parity of the initial weights."""
     if train_method not in TRAINING_METHODS:
         raise NotImplementedError(f"train_method: {train_method} is not implemented.")
     targets_cls = list(UNET_TARGET_REPLACE_MODULE_TRANSFORMER)
@@ -251,14 +259,13 @@ def lora_targets(cfg: UNetConfig, train_method: str, rank: int = 4, network_type
                 if "mid_block" not in name or ".1" not in name or "conv2" not in child_name:
                     continue
             lora_name = (LORA_PREFIX_UNET + "." + name + "." + child_name).replace(".", "_")
-            if lora_name in names:
-                continue
+            dup = lora_name in names
             names.add(lora_name)
             if child.kernel == 0:
                 kind, r = "linear", rank
             else:
                 kind = "conv3" if child.kernel == 3 else "conv1"
                 r = min(rank, child.in_dim, child.out_dim)   # lora.py:78
-            out.append(LoraTarget(lora_name, name + "." + child_name, kind, child.in_dim, child.out_dim,
-                                  child.stride, r))
+            out.append((LoraTarget(lora_name, name + "." + child_name, kind, child.in_dim, child.out_dim,
+                                   child.stride, r), dup))
     return out

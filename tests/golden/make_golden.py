@@ -12,6 +12,9 @@ the GPU box, so these fixtures are how the oracle and the HIP path are pinned to
                         steps, guidance 3), all fp32                                        <- lora.py:108-112,
                                                                                               train_util.py:145-294
   loss.pt               PromptEmbedsPair.loss (erase / enhance) on seeded bf16 tensors       <- prompt_util.py:108-148
+  lora_init.json        the reference's LoRANetwork built under torch.manual_seed(1234) over the tiny UNets: per module
+                        [sum, first, last] of the bf16 lora_down weights (pins the RNG draw ORDER, duplicates of the
+                        conv leaves included)                                               <- lora.py:68-97, 206-216
   schema.json           the reference's pydantic parse of tests/golden/{config,prompts}_sample.yaml
                                                                                            <- config_util.py, prompt_util.py
 Run:  python tests/golden/make_golden.py      (needs /root/reference; not run on the GPU box)
@@ -158,3 +161,25 @@ if __name__ == "__main__":
     tiny_forward()
     loss()
     schema()
+
+
+def lora_init():
+    """Seeded initial adapter weights of the reference's own network (RNG order incl. the duplicate conv visits)."""
+    out = {}
+    for name in ("tiny_sdxl", "tiny_sd1"):
+        for method in ("noxattn", "full"):
+            c3lier()
+            net = build_unet(name, seed=0)
+            torch.manual_seed(1234)
+            nw = quiet(reflora.LoRANetwork, net, rank=4, multiplier=1.0, alpha=1.0, train_method=method)
+            ent = {}
+            for m in nw.unet_loras:
+                w = m.lora_down.weight.detach().to(torch.bfloat16).float()
+                ent[m.lora_name] = [float(w.sum()), float(w.flatten()[0]), float(w.flatten()[-1])]
+            out[f"{name}/{method}"] = ent
+    with open(os.path.join(HERE, "lora_init.json"), "w") as f:
+        json.dump(out, f, indent=0, sort_keys=True)
+
+
+if __name__ == "__main__":
+    lora_init()

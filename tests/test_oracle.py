@@ -46,7 +46,7 @@ def test_lora_census_and_checkpoint_layout_match_reference(name):
     """Key order, names and shapes of LoRANetwork.state_dict() (lora.py:231-248) - what the reference's
     inference notebooks strict-load."""
     gold = json.load(open(os.path.join(G, "lora_census.json")))
-    for method in ("noxattn", "full", "xattn", "selfattn", "innoxattn", "noxattn-hspace", "noxattn-hspace-last"):
+    for method in ("noxattn", "full", "xattn", "xattn-strict", "selfattn", "innoxattn", "noxattn-hspace", "noxattn-hspace-last"):
         ent = gold[f"{name}/{method}"]
         tg = lora_targets(CONFIGS[name](), method)
         assert len(tg) == ent["modules"]
@@ -149,18 +149,25 @@ def test_ddim_closed_form_and_tables():
     assert DDIMSchedule().make_timesteps(50) == sch.timesteps.tolist()
 
 
-def test_lora_init_follows_reference_rng_order():
-    """LoraStore.init_reference draws the RNG exactly like LoRAModule.__init__ (lora.py:68-97): same seed ->
-    same kaiming_uniform(a=1) down weights as the oracle network built module by module."""
-    cfg = CONFIGS["tiny_sdxl"]()
+@pytest.mark.parametrize("name,method", [("tiny_sdxl", "noxattn"), ("tiny_sdxl", "full"), ("tiny_sd1", "noxattn"), ("tiny_sd1", "full")])
+def test_lora_init_follows_reference_rng_order(name, method):
+    """torch.manual_seed(s) gives the REFERENCE's initial adapter weights: LoraStore.init_reference and the oracle network
+    both draw the RNG like lora.py:68-97 / 206-216 (default init of down and up, then kaiming_uniform(a=1); the duplicate
+    visits of the conv leaves under DownBlock2D / UpBlock2D are constructed and discarded).  Golden: the reference's own
+    LoRANetwork (tests/golden/make_golden.py::lora_init)."""
+    gold = json.load(open(os.path.join(G, "lora_init.json")))[f"{name}/{method}"]
+    cfg = CONFIGS[name]()
     torch.manual_seed(1234)
-    s = LoraStore(cfg, train_method="noxattn")
-    net = build_unet("tiny_sdxl", seed=0)
-    torch.manual_seed(1234)
-    nw = LoRANetworkOracle(net, rank=4, multiplier=1.0, alpha=1.0, train_method="noxattn")
+    s = LoraStore(cfg, train_method=method)
     sd = s.state_dict()
+    net = build_unet(name, seed=0)
+    torch.manual_seed(1234)
+    nw = LoRANetworkOracle(net, rank=4, multiplier=1.0, alpha=1.0, train_method=method)
+    assert [m.lora_name for m in nw.unet_loras] == list(gold.keys()) or set(m.lora_name for m in nw.unet_loras) == set(gold)
     for m in nw.unet_loras:
         ref = m.lora_down.weight.detach().to(torch.bfloat16)
+        g = gold[m.lora_name]
+        assert [float(ref.float().sum()), float(ref.float().flatten()[0]), float(ref.float().flatten()[-1])] == g, m.lora_name
         assert torch.equal(sd[m.lora_name + ".lora_down.weight"], ref), m.lora_name
         assert sd[m.lora_name + ".lora_up.weight"].abs().max() == 0
 
