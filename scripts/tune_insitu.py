@@ -9,7 +9,8 @@ import sys
 from collections import defaultdict
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-os.environ["SLIDERS_NO_TUNING"] = "1"          # plans are built with the library heuristic; tiles are set here
+if "--incremental" not in sys.argv:
+    os.environ["SLIDERS_NO_TUNING"] = "1"      # plans are built with the library heuristic; tiles are set here
 import torch
 
 from sliders_amd import lib
@@ -27,6 +28,8 @@ ap.add_argument("--reps", type=int, default=2)
 ap.add_argument("--tiles", default="11,12,21,22,4011,4012,4022,322,422,412,421,4412,4322,4411,"
                 "20412,40412,80412,20421,40421,80421,20422,40422,24412,44412,40411,80411,f0412")
 ap.add_argument("--fwd-only", action="store_true")
+ap.add_argument("--incremental", action="store_true",
+                help="baseline = the committed table; a candidate replaces an entry only when it is > 2 %% faster")
 args = ap.parse_args()
 
 dev = torch.device("cuda:0")
@@ -128,7 +131,19 @@ for pname, prog in programs:
     print(f"== {pname}: {len(gemms)} GEMM launches, {len(counts)} shapes")
     for key, tt in sorted(times.items(), key=lambda kv: -kv[1][-1]):
         cand = {t: v for t, v in tt.items() if t != -1}
+        if not cand:
+            continue
         bt = min(cand, key=cand.get)
+        if args.incremental:
+            tot_h += tt[-1]
+            if cand[bt] < 0.98 * tt[-1]:
+                best_table[key] = bt
+                tot_b += cand[bt]
+            else:
+                tot_b += tt[-1]
+            line = "  ".join(f"{t:x}:{v / counts[key]:.1f}" for t, v in sorted(cand.items(), key=lambda kv: kv[1])[:5])
+            print(f"  {key:48s} x{counts[key]:4d}  table {tt[-1] / counts[key]:7.1f}us | {line}")
+            continue
         tot_h += tt[-1]
         tot_b += cand[bt]
         best_table[key] = bt if key not in best_table else best_table[key]
@@ -140,6 +155,13 @@ for pname, prog in programs:
 out = args.out or os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "sliders_amd", "tuning",
                                f"gfx950_{args.model}_{hw}_insitu.json")
 os.makedirs(os.path.dirname(out), exist_ok=True)
+if args.incremental:
+    src = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "sliders_amd", "tuning",
+                       f"gfx950_{args.model}_{hw}_insitu.json")
+    merged = json.load(open(src))
+    merged.update(best_table)
+    print(f"incremental: {len(best_table)} entries replaced")
+    best_table = merged
 with open(out, "w") as f:
     json.dump(best_table, f, indent=0, sort_keys=True)
 print("wrote", out)

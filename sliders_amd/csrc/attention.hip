@@ -210,7 +210,7 @@ __global__ __launch_bounds__(256) void transpose_heads_kernel(const slh_transpos
 template <int DT>
 int launch_fwd(const slh_attn_desc* d, hipStream_t s) {
     const long blocks4 = (long)((d->Tq + 127) / 128) * d->H * d->B;
-    if (blocks4 >= 512)
+    if (blocks4 >= 256)
         hipLaunchKernelGGL((attn_fwd_kernel<4, DT>), dim3((d->Tq + 127) / 128, d->H, d->B), dim3(256), 0, s, *d);
     else
         hipLaunchKernelGGL((attn_fwd_kernel<2, DT>), dim3((d->Tq + 63) / 64, d->H, d->B), dim3(128), 0, s, *d);
