@@ -87,6 +87,13 @@ typedef struct slh_gemm_desc {
                                 few-row, long-K products (1280-channel 3x3 convolutions at 8x8 / 16x16: 10-40 output tiles on
                                 256 CUs, 29 MB of weights each) this is what fills the chip. */
     float* splitk_t32;       /* with lora_down: [M][ld_t] fp32, ZERO on entry, receives T (lora_t_out may alias it) */
+    void* vt_out;            /* optional: the columns >= vt_col0 of the result (the V third of a fused q|k|v projection,
+                                diffusers Attention.to_v) are written HEAD-TRANSPOSED for slh_attn_fwd instead of into c:
+                                vt_out[((b*vt_heads + h)*Dp + d)*vt_ld + t] = C[b*vt_tokens + t][vt_col0 + h*vt_D + d],
+                                Dp = 64*ceil(vt_D/64) - exactly what slh_transpose_heads would produce from c, without
+                                the extra launch and the round trip of V through HBM.  Needs vt_D % 64 == 0 (no padded
+                                rows), vt_col0 % 128 == 0, vt_tokens % 8 == 0, M % 8 == 0; not with geglu / split-K */
+    int32_t vt_col0, vt_D, vt_heads, vt_tokens, vt_ld, vt_pad_;
 } slh_gemm_desc;
 int slh_gemm(const slh_gemm_desc* d, slh_stream_t stream);
 /* (WM<<12)|(MI<<8)|(NI<<4)|mode of the kernel instantiation gemm_kernel<MI,NI,mode,..,WM> slh_gemm would launch for d
@@ -424,6 +431,14 @@ enum {
 };
 typedef struct slh_memset_desc { void* ptr; int64_t nbytes; int32_t value; int32_t pad; } slh_memset_desc;
 int slh_run_program(const void* program, int64_t nbytes, slh_stream_t stream);
+/* hipGraph replay of a command buffer: capture records the launches slh_run_program would issue (on a private stream;
+ * nothing executes), launch re-submits them as one graph.  The buffer must be static between replays (descriptors are baked
+ * into the kernel arguments); everything the reference's loop changes per step (latents, timestep, adapter scale and
+ * weights - train_util.py:220-260) is read through device pointers and may change freely.  Replaces the ~1.2k Python
+ * op dispatches of one diffusers UNet forward with one submission. */
+int slh_graph_capture(const void* program, int64_t nbytes, void** out_graph);
+int slh_graph_launch(void* graph, slh_stream_t stream);
+int slh_graph_destroy(void* graph);
 /* sizeof() of every descriptor, in declaration order above, for binding self-checks */
 int slh_desc_sizes(int32_t* out, int32_t cap);
 

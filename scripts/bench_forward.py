@@ -20,6 +20,7 @@ ap.add_argument("--batch", type=int, default=2)
 ap.add_argument("--iters", type=int, default=10)
 ap.add_argument("--lora", action="store_true")
 ap.add_argument("--warm", type=int, default=3)
+ap.add_argument("--no-graph", action="store_true", help="plain launches instead of the hipGraph replay")
 args = ap.parse_args()
 
 dev = torch.device("cuda:0")
@@ -49,11 +50,11 @@ print("eps rms", out.float().pow(2).mean().sqrt().item(), "finite", bool(torch.i
 p = eng.plan(B, hw, hw, mode)
 s = torch.cuda.current_stream().cuda_stream
 for _ in range(args.warm):
-    p.prog.run(s)
+    p.prog.run(s, graph=not args.no_graph)
 torch.cuda.synchronize()
 t0 = time.time()
 for _ in range(args.iters):
-    p.prog.run(s)
+    p.prog.run(s, graph=not args.no_graph)
 torch.cuda.synchronize()
 dt = (time.time() - t0) / args.iters
 print(f"{args.model} hw={hw} B={B} mode={mode}: {dt * 1e3:.2f} ms / UNet forward ({p.prog.n_ops} launches)", flush=True)

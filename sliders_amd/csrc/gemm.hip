@@ -37,6 +37,7 @@ struct GemmArgs {
     int tiles_m, tiles_n, group_m;
     float* c32; float* t32;   // split-K: fp32 partial sums (zeroed by the caller), see slh_gemm_desc.splitk_c32
     int splitk;
+    __bf16* vt; int vt_col0, vt_D, vt_heads, vt_tokens, vt_ld;   // head-transposed store of the V columns (slh_gemm_desc.vt_out)
     int store16;  // c and ldc allow 16-byte row stores
     int probe;   // diagnostics (slh_gemm_desc.reserved_): 1 skip tile refills, 2 skip MFMA work, 4 skip the epilogue,
                  // 8 skip the first tile fill, 16 return at once
@@ -539,6 +540,8 @@ __global__ __launch_bounds__(128 * WM, gemm_waves_per_simd(MI, NI, STAGES, LORA,
     const bool have_t = LORA || p.lora_t != nullptr;
     const float lscale = have_t ? *p.lora_scale : 0.f;
     const int ncol0 = n0 + wn * (32 * NI);
+    // wave-uniform: this wave's columns belong to the V block that slh_attn_fwd wants head-transposed
+    const bool to_vt = p.vt != nullptr && ncol0 >= p.vt_col0;
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
         const int mbase = m0 + wm * (32 * MI) + i * 32;
@@ -624,6 +627,14 @@ __global__ __launch_bounds__(128 * WM, gemm_waves_per_simd(MI, NI, STAGES, LORA,
                 bf16x4 o;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) o[e] = (__bf16)v[e];
+                if (to_vt) {
+                    // transposed patch sT[n_local][m_local] (32*NI rows of 32 bf16): column n of the tile becomes a
+                    // 64-byte run along m
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        *(__bf16*)(sE + ((j * 32 + q * 8 + lhi * 4 + e) * 32 + lrow) * 2) = o[e];
+                    continue;
+                }
                 // logical 16-byte slot j*4+q, 8-byte half lhi of row lrow; slot ^ row and half ^ row-bit keep both
                 // the 8-byte writes and the 16-byte row reads off each other's banks
                 const int slot = (j * 4 + q) ^ (lrow & (S - 1));
@@ -631,6 +642,24 @@ __global__ __launch_bounds__(128 * WM, gemm_waves_per_simd(MI, NI, STAGES, LORA,
             }
         }
         __builtin_amdgcn_wave_barrier();       // same-wave LDS ops retire in order; only the compiler must not reorder
+        if (to_vt) {
+            const int Dp = (p.vt_D + 63) & ~63;
+#pragma unroll
+            for (int it = 0; it < 2 * NI; ++it) {
+                const int idx = it * 64 + lane;
+                const int nl = idx >> 2, seg = idx & 3;
+                const bf16x8 t8 = *(const bf16x8*)(sE + nl * 64 + seg * 16);
+                const int m2 = mbase + seg * 8, n2 = ncol0 + nl;
+                if (m2 < p.M && n2 < p.N) {
+                    const int nv = n2 - p.vt_col0;
+                    const int hh = nv / p.vt_D, dd = nv - hh * p.vt_D;
+                    const int bb = m2 / p.vt_tokens, tt = m2 - bb * p.vt_tokens;
+                    *(bf16x8*)(p.vt + (((long)bb * p.vt_heads + hh) * Dp + dd) * p.vt_ld + tt) = t8;
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            continue;
+        }
 #pragma unroll
         for (int it = 0; it < S / 2; ++it) {
             const int idx = it * 64 + lane;
@@ -859,6 +888,14 @@ extern "C" int slh_gemm(const slh_gemm_desc* d, slh_stream_t stream) {
     a.ld_res = d->ld_res; a.ldc = d->ldc; a.geglu = d->geglu;
     a.lora_rank = d->lora_rank > 0 ? d->lora_rank : 4; a.lora_up_rmajor = d->lora_up_rmajor;
     a.w_packed = d->w_layout;
+    a.vt = (__bf16*)d->vt_out; a.vt_col0 = d->vt_col0; a.vt_D = d->vt_D; a.vt_heads = d->vt_heads;
+    a.vt_tokens = d->vt_tokens; a.vt_ld = d->vt_ld;
+    if (d->vt_out) {
+        SLH_CHECK(d->vt_D > 0 && d->vt_D % 64 == 0 && d->vt_col0 % 128 == 0 && d->vt_col0 < d->N && d->vt_heads > 0 &&
+                      (d->N - d->vt_col0) == d->vt_heads * d->vt_D && d->vt_tokens % 8 == 0 && d->M % d->vt_tokens == 0 &&
+                      d->vt_ld % 8 == 0 && d->vt_ld >= d->vt_tokens && !d->geglu && ((uintptr_t)d->vt_out & 15) == 0,
+                  "slh_gemm: vt_out constraints");
+    }
     a.probe = d->reserved_;
     a.splitk = (d->tile >> 16) & 15;
     a.c32 = d->splitk_c32;
@@ -866,6 +903,7 @@ extern "C" int slh_gemm(const slh_gemm_desc* d, slh_stream_t stream) {
     if (a.splitk > 1) {
         SLH_CHECK(d->splitk_c32, "slh_gemm: split-K needs the zeroed fp32 workspace splitk_c32");
         SLH_CHECK(!d->geglu, "slh_gemm: split-K excludes the GEGLU epilogue");
+        SLH_CHECK(!d->vt_out, "slh_gemm: split-K excludes the head-transposed V store");
         SLH_CHECK(!d->lora_down || a.t32, "slh_gemm: split-K with a fused adapter needs splitk_t32 (or lora_t_out), zeroed");
         if (a.splitk > d->K / 64) a.splitk = d->K / 64;
     } else {

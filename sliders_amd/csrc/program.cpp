@@ -91,6 +91,64 @@ extern "C" int slh_run_program(const void* program, int64_t nbytes, slh_stream_t
     return 0;
 }
 
+// ---- hipGraph replay ------------------------------------------------------------------------------------------------
+// A finalized command buffer is static (descriptors are passed to the kernels by value, everything that changes between
+// replays - latents, timestep, adapter scale, adapter weights - lives behind device pointers), so the ~1000 launches of
+// a UNet pass can be recorded once and re-submitted as one graph: no per-launch API call, argument marshalling or
+// descriptor validation on the host, and the command processor sees the whole chain up front.
+struct slh_graph_ {
+    hipGraph_t graph;
+    hipGraphExec_t exec;
+};
+
+extern "C" int slh_graph_capture(const void* program, int64_t nbytes, void** out) {
+    if (!out) { slh_set_error("slh_graph_capture: null out"); return -3; }
+    *out = nullptr;
+    // recorded on a private stream (the caller's may be the legacy default stream, which cannot capture); the graph
+    // itself is not tied to a stream
+    hipStream_t s = nullptr;
+    hipError_t e = hipStreamCreateWithFlags(&s, hipStreamNonBlocking);
+    if (e != hipSuccess) { slh_set_error("slh_graph_capture: stream create: %s", hipGetErrorString(e)); return -2; }
+    e = hipStreamBeginCapture(s, hipStreamCaptureModeRelaxed);
+    if (e != hipSuccess) {
+        (void)hipStreamDestroy(s);
+        slh_set_error("slh_graph_capture: begin capture: %s", hipGetErrorString(e));
+        return -2;
+    }
+    const int rc = slh_run_program(program, nbytes, (slh_stream_t)s);
+    hipGraph_t g = nullptr;
+    e = hipStreamEndCapture(s, &g);
+    (void)hipStreamDestroy(s);
+    if (rc != 0) { if (g) (void)hipGraphDestroy(g); return rc; }
+    if (e != hipSuccess || !g) { slh_set_error("slh_graph_capture: end capture: %s", hipGetErrorString(e)); return -2; }
+    hipGraphExec_t x = nullptr;
+    e = hipGraphInstantiate(&x, g, nullptr, nullptr, 0);
+    if (e != hipSuccess) {
+        (void)hipGraphDestroy(g);
+        slh_set_error("slh_graph_capture: instantiate: %s", hipGetErrorString(e));
+        return -2;
+    }
+    slh_graph_* h = new slh_graph_{g, x};
+    *out = h;
+    return 0;
+}
+
+extern "C" int slh_graph_launch(void* graph, slh_stream_t stream) {
+    if (!graph) { slh_set_error("slh_graph_launch: null graph"); return -3; }
+    hipError_t e = hipGraphLaunch(((slh_graph_*)graph)->exec, (hipStream_t)stream);
+    if (e != hipSuccess) { slh_set_error("slh_graph_launch: %s", hipGetErrorString(e)); return -2; }
+    return 0;
+}
+
+extern "C" int slh_graph_destroy(void* graph) {
+    if (!graph) return 0;
+    slh_graph_* h = (slh_graph_*)graph;
+    (void)hipGraphExecDestroy(h->exec);
+    (void)hipGraphDestroy(h->graph);
+    delete h;
+    return 0;
+}
+
 extern "C" int slh_desc_sizes(int32_t* out, int32_t cap) {
     const int32_t sizes[] = {
         (int32_t)sizeof(slh_gemm_desc),     (int32_t)sizeof(slh_skinny_desc),   (int32_t)sizeof(slh_gemv_desc),

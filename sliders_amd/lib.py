@@ -33,7 +33,8 @@ GemmDesc = _struct("GemmDesc", _ptrs("a0", "a1", "w", "bias", "rowbias", "lora_t
                    + _ints("lda0", "lda1", "ca0", "ca1", "mode", "batch", "hs", "ws", "src_xform", "stride",
                            "ho", "wo", "ldw", "M", "N", "K", "ld_rowbias", "rows_per_sample", "ld_t",
                            "lora_groups", "ld_res", "ldc", "geglu", "tile", "lora_rank", "lora_up_rmajor", "w_layout",
-                           "reserved_") + _ptrs("splitk_c32", "splitk_t32"))
+                           "reserved_") + _ptrs("splitk_c32", "splitk_t32", "vt_out")
+                   + _ints("vt_col0", "vt_D", "vt_heads", "vt_tokens", "vt_ld", "vt_pad_"))
 SkinnyDesc = _struct("SkinnyDesc", _ptrs("a0", "a1", "w", "bias", "out")
                      + _ints("lda0", "lda1", "ca0", "ca1", "mode", "batch", "hs", "ws", "src_xform", "stride",
                              "ho", "wo", "M", "R", "K", "ldo", "out_kind", "w_kmajor"))
@@ -121,7 +122,8 @@ _ENTRY = {
     OP_VAE_POST_QUANT: ("slh_vae_post_quant", VaeConvDesc),
 }
 
-EXPORTS = ["slh_version", "slh_last_error", "slh_run_program", "slh_desc_sizes"] + [v[0] for v in _ENTRY.values()]
+EXPORTS = ["slh_version", "slh_last_error", "slh_run_program", "slh_desc_sizes", "slh_graph_capture", "slh_graph_launch",
+           "slh_graph_destroy"] + [v[0] for v in _ENTRY.values()]
 
 
 class SlidersHipError(RuntimeError):
@@ -149,6 +151,12 @@ def load() -> C.CDLL:
     lib.slh_run_program.argtypes = [c_vp, c_i64, c_vp]
     lib.slh_run_program.restype = c_i32
     lib.slh_desc_sizes.argtypes = [C.POINTER(c_i32), c_i32]
+    lib.slh_graph_capture.argtypes = [c_vp, c_i64, C.POINTER(c_vp)]
+    lib.slh_graph_capture.restype = c_i32
+    lib.slh_graph_launch.argtypes = [c_vp, c_vp]
+    lib.slh_graph_launch.restype = c_i32
+    lib.slh_graph_destroy.argtypes = [c_vp]
+    lib.slh_graph_destroy.restype = c_i32
     for name, desc in _ENTRY.values():
         fn = getattr(lib, name)
         fn.argtypes = [C.POINTER(desc), c_vp]
@@ -188,8 +196,16 @@ def call(opcode: int, desc, stream: int):
     check(getattr(lib, name)(C.byref(desc), c_vp(stream)), name)
 
 
+_GRAPHS_ON = os.environ.get("SLIDERS_HIPGRAPH", "1") != "0"
+
+
 class Program:
-    """Flat command buffer replayed by slh_run_program with one C call."""
+    """Flat command buffer replayed by slh_run_program with one C call - or, once it has been replayed GRAPH_AFTER times
+    unchanged and is long enough to matter, as one hipGraph submission (slh_graph_capture / slh_graph_launch).
+    SLIDERS_HIPGRAPH=0 keeps plain launches."""
+
+    GRAPH_AFTER = 2          # eager replays before capture (first runs also load the code objects)
+    GRAPH_MIN_OPS = 64
 
     def __init__(self):
         self._chunks = []
@@ -197,6 +213,21 @@ class Program:
         self._buf = None
         self.op_names = []
         self.ops = []          # (opcode, descriptor) kept for per-op timing / tuning tools
+        self._graphs = None    # captured graph handle
+        self._runs = 0
+
+    def _drop_graphs(self):
+        if self._graphs is not None:
+            load().slh_graph_destroy(self._graphs)
+        self._graphs = None
+        self._runs = 0
+
+    def __del__(self):
+        try:
+            if self._graphs and _lib is not None:
+                self._drop_graphs()
+        except Exception:
+            pass
 
     def add(self, opcode: int, desc, name: str = ""):
         raw = bytes(desc)
@@ -207,6 +238,8 @@ class Program:
         self.op_names.append(name)
         self.ops.append((opcode, desc))
         self._buf = None
+        if self._graphs:
+            self._drop_graphs()
 
     def memset(self, ptr: int, nbytes: int, value: int = 0, name: str = "memset"):
         self.add(OP_MEMSET, MemsetDesc(ptr=ptr, nbytes=nbytes, value=value, pad=0), name)
@@ -217,6 +250,8 @@ class Program:
         self.n_ops += other.n_ops
         self.op_names.extend(other.op_names)
         self._buf = None
+        if self._graphs:
+            self._drop_graphs()
 
     def finalize(self):
         if self._buf is None:
@@ -224,6 +259,17 @@ class Program:
             self._buf = C.create_string_buffer(data, len(data))
         return self._buf
 
-    def run(self, stream: int):
+    def run(self, stream: int, graph: bool = True):
         buf = self.finalize()
-        check(load().slh_run_program(C.cast(buf, c_vp), len(buf), c_vp(stream)), "slh_run_program")
+        lib = load()
+        if graph and self.n_ops >= self.GRAPH_MIN_OPS and _GRAPHS_ON:
+            g = self._graphs
+            if g is None and self._runs >= self.GRAPH_AFTER:
+                h = c_vp()
+                check(lib.slh_graph_capture(C.cast(buf, c_vp), len(buf), C.byref(h)), "slh_graph_capture")
+                g = self._graphs = h
+            if g is not None:
+                check(lib.slh_graph_launch(g, c_vp(stream)), "slh_graph_launch")
+                return
+        self._runs += 1
+        check(lib.slh_run_program(C.cast(buf, c_vp), len(buf), c_vp(stream)), "slh_run_program")

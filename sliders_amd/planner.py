@@ -175,8 +175,11 @@ class UNetPlan:
     def gemm(self, x: Src, wname: str, N: int, name: str, bias: bool = True, conv: Optional[dict] = None,
              rowbias: Optional[Tuple[int, int]] = None, residual: Optional[Act] = None,
              lora_paths: Optional[List[str]] = None, geglu: bool = False, out: Optional[Act] = None,
-             w_ptr: Optional[int] = None, bias_ptr: Optional[int] = None) -> Act:
-        """y = x . W^T (+bias)(+rowbias per sample)(+LoRA)(+residual).  conv: {'stride','xform'} for 3x3."""
+             w_ptr: Optional[int] = None, bias_ptr: Optional[int] = None, vt_heads: Optional[int] = None) -> Act:
+        """y = x . W^T (+bias)(+rowbias per sample)(+LoRA)(+residual).  conv: {'stride','xform'} for 3x3.
+        vt_heads: the product is a fused q|k|v projection of that many heads; where the kernel supports it (no-grad
+        passes, head_dim % 64 == 0) its V third is written head-transposed for slh_attn_fwd straight from the epilogue
+        and self.last_vt = (pointer, 0) names it - one launch and one HBM round trip of V less per self-attention."""
         x0, x1 = _src_parts(x)
         cin = x0.C + (x1.C if x1 else 0)
         B = x0.B
@@ -229,6 +232,14 @@ class UNetPlan:
             d.tile = 0x12        # few rows, very wide: 64-row tiles waste the least of the short M
         if not d.tile and d.splitk_c32:
             d.tile = default_splitk(d)
+        self.last_vt = None
+        if vt_heads and not self.train and not geglu and conv is None and os.environ.get("SLIDERS_NO_FUSED_VT") is None:
+            Cq = N // 3
+            Dh, Tk = Cq // vt_heads, Ho * Wo
+            if Dh % 64 == 0 and (2 * Cq) % 128 == 0 and Tk % 64 == 0 and not (d.tile >> 16) & 15:
+                vt = self.arena.alloc((B, vt_heads, Dh, Tk), torch.bfloat16, name + ".vt")
+                d.vt_out, d.vt_col0, d.vt_D, d.vt_heads, d.vt_tokens, d.vt_ld = vt.ptr, 2 * Cq, Dh, vt_heads, Tk, Tk
+                self.last_vt = (vt.ptr, 0)
         self.prog.add(lib.OP_GEMM, d, name)
         if self.train:
             self.tape.append(dict(op="gemm", x=x, out=out, wname=wname, N=N, K=K, conv=conv, grp=grp, T=T,
@@ -374,9 +385,9 @@ class UNetPlan:
         a1, a2 = path + ".attn1", path + ".attn2"
         n1 = self.layernorm(h, path + ".norm1", path + ".norm1")
         qkv = self.gemm(n1, a1 + ".qkv", 3 * C, a1 + ".qkv", bias=False,
-                        lora_paths=[a1 + ".to_q", a1 + ".to_k", a1 + ".to_v"])
+                        lora_paths=[a1 + ".to_q", a1 + ".to_k", a1 + ".to_v"], vt_heads=heads)
         T = h.HW
-        o1 = self.attention(qkv.cols(0, C), qkv.cols(C, C), qkv.cols(2 * C, C), T, heads, a1 + ".sdpa")
+        o1 = self.attention(qkv.cols(0, C), qkv.cols(C, C), qkv.cols(2 * C, C), T, heads, a1 + ".sdpa", vt_pre=self.last_vt)
         h1 = self.gemm(o1, a1 + ".out", C, a1 + ".out", residual=h, lora_paths=[a1 + ".to_out.0"])
         n2 = self.layernorm(h1, path + ".norm2", path + ".norm2")
         q2 = self.gemm(n2, a2 + ".q", C, a2 + ".q", bias=False, lora_paths=[a2 + ".to_q"])

@@ -121,6 +121,35 @@ def test_gemm_two_source_rowbias_lora(dev, tile):
         report(f"gemm_2src_rowbias_lora g{groups}", c, ref, TOL)
 
 
+@pytest.mark.parametrize("tile", [0, 0x22, 0x12, 0x21, 0x11, 0x4012, 0x4011, 0x4022, 0x422, 0x4412, 0x4322, 0x312])
+def test_gemm_head_transposed_v_store(dev, tile):
+    """vt_out: the V third of a fused q|k|v projection leaves the epilogue in slh_attn_fwd's [B][H][D][T] layout
+    (what slh_transpose_heads would make of c[:, 2C:]); q and k still land in c.  With the LoRA term of to_q/k/v."""
+    torch.manual_seed(11)
+    B, T, heads, D, K = 2, 192, 2, 64, 192
+    C = heads * D
+    M, N = B * T, 3 * C
+    x = bf(torch.randn(M, K, device=dev))
+    w = bf(torch.randn(N, K, device=dev) / math.sqrt(K))
+    Tl = torch.randn(M, 12, device=dev)
+    up = bf(torch.randn(N, 4, device=dev))
+    scale = torch.tensor([0.5], device=dev)
+    c = torch.full((M, N), 7.0, device=dev, dtype=torch.bfloat16)
+    vt = torch.full((B, heads, D, T), 7.0, device=dev, dtype=torch.bfloat16)
+    d = lib.GemmDesc(a0=p(x), w=p(w), lora_t=p(Tl), lora_up=p(up), lora_scale=p(scale), c=p(c), lda0=K, ca0=K, mode=0,
+                     stride=1, ldw=K, M=M, N=N, K=K, ld_t=12, lora_groups=3, ldc=N, rows_per_sample=T, tile=tile,
+                     vt_out=p(vt), vt_col0=2 * C, vt_D=D, vt_heads=heads, vt_tokens=T, vt_ld=T)
+    lib.call(lib.OP_GEMM, d, stream())
+    torch.cuda.synchronize()
+    ref = x.float() @ w.float().t()
+    for g in range(3):
+        ref[:, g * C:(g + 1) * C] += 0.5 * Tl[:, 4 * g:4 * g + 4] @ up.float()[g * C:(g + 1) * C].t()
+    report(f"gemm_vt tile{tile:x} q|k", c[:, :2 * C], ref[:, :2 * C], TOL)
+    assert (c[:, 2 * C:].float() == 7.0).all(), "the V columns must not be written to c"
+    vref = ref[:, 2 * C:].reshape(B, T, heads, D).permute(0, 2, 3, 1)
+    report(f"gemm_vt tile{tile:x} v^T", vt, vref, TOL)
+
+
 def test_gemm_geglu(dev):
     torch.manual_seed(2)
     M, d_, K = 512, 128, 256      # proj: K -> 8*d_/... here N = 2*n_out
