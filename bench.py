@@ -393,13 +393,14 @@ def main():
         value_no_dedup = round(us2 / (time.time() - t1), 3)
         tr.dedup_frozen = True
 
+    label = {"sdxl": "SDXL", "sd1": "SD-1.x", "sd2": "SD-2.x"}.get(a.model, a.model)
     res = {
-        "metric": "UNet denoise steps/sec (SDXL rank-4 text slider)" if a.workload == "text" else
-                  "UNet denoise steps/sec (SDXL rank-4 image slider, VAE encode on GPU)",
+        "metric": f"UNet denoise steps/sec ({label} rank-4 text slider)" if a.workload == "text" else
+                  f"UNet denoise steps/sec ({label} rank-4 image slider, VAE encode on GPU)",
         "value": round(unet_steps * world / dt, 3), "unit": "steps/s", "n_gpus": world, "steps": a.steps,
         "warmup": a.warmup, "ms_per_step": round(1e3 * dt / a.steps, 2), "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
-        "data": "synthetic (seeded random-init weights with the real SDXL shapes, randn text embeddings)",
+        "data": f"synthetic (seeded random-init weights with the real {label} shapes, randn text embeddings)",
         "config": {"workload": (f"{a.model} text slider rank=4 alpha=1 noxattn+c3lier, {a.res}x{a.res}, batch 1 "
                                 f"(CFG pair), DDIM-50 partial denoise k~U{{1..49}} + 4 predictions + backward + AdamW")
                                if a.workload == "text" else

@@ -292,6 +292,11 @@ typedef struct slh_cfg_ddim_desc {
     float guidance;
     float c_sqrt_beta_t, c_inv_sqrt_alpha_t, c_sqrt_alpha_prev, c_dir;
     int32_t do_step;
+    int32_t v_prediction;    /* 1: the network predicts v (SD-2.x 768-v; model_util.py:126 prediction_type="v_prediction"):
+                                x0 = sqrt(a_t) x - sqrt(1-a_t) v, eps = sqrt(a_t) v + sqrt(1-a_t) x, same rounding points
+                                as the DDIMScheduler.step tensor ops */
+    float c_sqrt_alpha_t;    /* v_prediction only: alpha_prod_t ** 0.5 (fp32) */
+    int32_t pad_;
 } slh_cfg_ddim_desc;
 int slh_cfg_ddim(const slh_cfg_ddim_desc* d, slh_stream_t stream);
 

@@ -28,7 +28,9 @@ class _StepOutput:
 
 class DDIMScheduler:
     def __init__(self, num_train_timesteps: int = 1000, beta_start: float = 0.00085,
-                 beta_end: float = 0.012):
+                 beta_end: float = 0.012, prediction_type: str = "epsilon"):
+        assert prediction_type in ("epsilon", "v_prediction")   # model_util.py:126
+        self.prediction_type = prediction_type
         self.num_train_timesteps = num_train_timesteps
         # "scaled_linear": linspace in sqrt space, fp32
         self.betas = torch.linspace(beta_start ** 0.5, beta_end ** 0.5, num_train_timesteps,
@@ -76,6 +78,14 @@ class DDIMScheduler:
         c_inv_sqrt_alpha = torch.tensor(1.0) / (alpha_prod_t ** 0.5)
         c_dir = (1 - alpha_prod_t_prev - std_dev_t ** 2) ** 0.5
         c_sqrt_alpha_prev = alpha_prod_t_prev ** 0.5
+        if self.prediction_type == "v_prediction":
+            # diffusers:  pred_original_sample = (alpha_prod_t**0.5) * sample - (beta_prod_t**0.5) * model_output
+            #             pred_epsilon = (alpha_prod_t**0.5) * model_output + (beta_prod_t**0.5) * sample
+            c_sqrt_alpha = alpha_prod_t ** 0.5
+            pred_original_sample = _smul(c_sqrt_alpha, sample) - _smul(c_sqrt_beta, model_output)
+            pred_epsilon = _smul(c_sqrt_alpha, model_output) + _smul(c_sqrt_beta, sample)
+            prev_sample = _smul(c_sqrt_alpha_prev, pred_original_sample) + _smul(c_dir, pred_epsilon)
+            return _StepOutput(prev_sample, pred_original_sample)
         pred_original_sample = _smul(c_inv_sqrt_alpha, sample - _smul(c_sqrt_beta, model_output))
         pred_sample_direction = _smul(c_dir, model_output)
         prev_sample = _smul(c_sqrt_alpha_prev, pred_original_sample) + pred_sample_direction

@@ -94,6 +94,18 @@ def sdxl_config() -> UNetConfig:
     )
 
 
+def sd2_config() -> UNetConfig:
+    """stabilityai/stable-diffusion-2-1(-base) (the reference's pretrained_model.v2, model_util.py:31-50): 5/10/20/20 heads
+    of width 64, Linear proj_in/proj_out, 1024-d context.  Published size: 865,910,724 parameters."""
+    return UNetConfig(attention_head_dim=(5, 10, 20, 20), cross_attention_dim=1024, use_linear_projection=True)
+
+
+def tiny_sd2_config() -> UNetConfig:
+    """Same topology as SD-2.x, narrow."""
+    return UNetConfig(sample_size=16, block_out_channels=(64, 128, 256, 256), attention_head_dim=(1, 2, 4, 4),
+                      cross_attention_dim=128, use_linear_projection=True)
+
+
 def tiny_sd1_config() -> UNetConfig:
     """Same topology as SD-1.x, 1/5 width (channels stay multiples of 64) - for fast tests."""
     return UNetConfig(
@@ -123,6 +135,8 @@ def tiny_sdxl_config() -> UNetConfig:
 
 CONFIGS = {
     "sd1": sd1_config,
+    "sd2": sd2_config,
+    "tiny_sd2": tiny_sd2_config,
     "sdxl": sdxl_config,
     "tiny_sd1": tiny_sd1_config,
     "tiny_sdxl": tiny_sdxl_config,

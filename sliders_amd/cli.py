@@ -71,14 +71,14 @@ def _synthetic_pairs(cfg, prompts, dev, seed):
     return build_pairs(cfg, prompts, encode, dev)
 
 
-def _encoded_pairs(cfg, prompts, name_or_path, dev, dtype):
+def _encoded_pairs(cfg, prompts, name_or_path, dev, dtype, v2: bool = False):
     """Real checkpoints: CLIP text encoder(s) through `transformers`, run once before the loop (not on the hot path)."""
     from . import model_util
     if cfg.is_xl:
         toks, encs = model_util.load_text_encoders_xl(name_or_path, dev, dtype)
         encode = lambda text: model_util.encode_prompts_xl(toks, encs, [text])
     else:
-        tok, enc = model_util.load_text_encoder(name_or_path, dev, dtype)
+        tok, enc = model_util.load_text_encoder(name_or_path, dev, dtype, v2=v2)
         encode = lambda text: (model_util.encode_prompts(tok, enc, [text]), None)
     pairs = build_pairs(cfg, prompts, encode, dev)
     torch.cuda.empty_cache()                    # the encoders are dropped here, as the reference does (train_lora_xl.py:153-156)
@@ -138,8 +138,6 @@ def check_supported(config: config_util.RootConfig):
         raise NotImplementedError(f"train.precision '{t.precision}': the MI355X hot path computes in bf16 (the reference's default)")
     if t.noise_scheduler != "ddim":
         raise NotImplementedError(f"train.noise_scheduler '{t.noise_scheduler}': only DDIM (model_util.py:237-246) is implemented")
-    if config.pretrained_model.v2 or config.pretrained_model.v_pred:
-        raise NotImplementedError("pretrained_model.v2 / v_pred (SD-2.x, v-prediction) are outside the implemented configs")
     optimizer_options(t)
     LrSchedule(t.lr_scheduler, t.lr, t.iterations)
 
@@ -165,12 +163,15 @@ def train(config: config_util.RootConfig, prompts, device: int, xl: bool, synthe
     if config.network.type != "c3lier":
         print("note: network.type lierla -> attention-only targets")
     if synthetic:
-        eng = synthetic_engine("sdxl" if xl else "sd1", dev, seed)
+        eng = synthetic_engine("sdxl" if xl else ("sd2" if config.pretrained_model.v2 else "sd1"), dev, seed)
     else:
         eng = load_unet_engine(config.pretrained_model.name_or_path, dev)
         if eng.cfg.is_xl != xl:
-            raise ValueError(f"{config.pretrained_model.name_or_path} is {'an SDXL' if eng.cfg.is_xl else 'an SD-1.x'} "
-                             f"UNet but the {'XL' if xl else 'SD-1.x'} entry point was used")
+            raise ValueError(f"{config.pretrained_model.name_or_path} is {'an SDXL' if eng.cfg.is_xl else 'an SD-1.x / 2.x'} "
+                             f"UNet but the {'XL' if xl else 'SD-1.x / 2.x'} entry point was used")
+        if not xl and (eng.cfg.cross_attention_dim == 1024) != bool(config.pretrained_model.v2):
+            raise ValueError(f"pretrained_model.v2 = {config.pretrained_model.v2} but the UNet's context width is "
+                             f"{eng.cfg.cross_attention_dim} (SD-2.x: 1024, SD-1.x: 768)")
     torch.manual_seed(seed)
     store = LoraStore(eng.cfg, rank=config.network.rank, alpha=config.network.alpha,
                       train_method=config.network.training_method, network_type=config.network.type, device=dev)
@@ -179,12 +180,13 @@ def train(config: config_util.RootConfig, prompts, device: int, xl: bool, synthe
     tr = SliderTrainer(eng, store, hw0, hw0, batch_size=prompts[0].batch_size, lr=config.train.lr, betas=opt["betas"],
                        eps=opt["eps"], weight_decay=opt["weight_decay"],
                        max_denoising_steps=config.train.max_denoising_steps,
-                       process_group=torch.distributed.group.WORLD if world > 1 else None)
+                       process_group=torch.distributed.group.WORLD if world > 1 else None,
+                       prediction_type="v_prediction" if config.pretrained_model.v_pred else "epsilon")
     if synthetic:
         pairs = _synthetic_pairs(eng.cfg, prompts, dev, seed)
     else:
         pairs = _encoded_pairs(eng.cfg, prompts, config.pretrained_model.name_or_path, dev,
-                               config_util.parse_precision(config.train.precision))
+                               config_util.parse_precision(config.train.precision), v2=config.pretrained_model.v2)
     samp = StepSampler(seed, rank, world, len(pairs), config.train.max_denoising_steps)
     sched = LrSchedule(config.train.lr_scheduler, config.train.lr, config.train.iterations)
     wandb = None

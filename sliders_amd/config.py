@@ -71,6 +71,17 @@ def sdxl_config() -> UNetConfig:
         addition_time_embed_dim=256, projection_class_embeddings_input_dim=2816)
 
 
+def sd2_config() -> UNetConfig:
+    """stabilityai/stable-diffusion-2-1(-base): pretrained_model.v2 (model_util.py:31-50, 85) - 64-wide heads (5/10/20/20 of
+    them), Linear proj_in / proj_out, 1024-d OpenCLIP context; 865,910,724 parameters."""
+    return UNetConfig(attention_head_dim=(5, 10, 20, 20), cross_attention_dim=1024, use_linear_projection=True)
+
+
+def tiny_sd2_config() -> UNetConfig:
+    return UNetConfig(sample_size=16, block_out_channels=(64, 128, 256, 256), attention_head_dim=(1, 2, 4, 4),
+                      cross_attention_dim=128, use_linear_projection=True)
+
+
 def tiny_sd1_config() -> UNetConfig:
     return UNetConfig(sample_size=16, block_out_channels=(64, 128, 320, 320),
                       attention_head_dim=(8, 8, 8, 8), cross_attention_dim=128)   # head dims 8 / 16 / 40 / 40
@@ -86,7 +97,8 @@ def tiny_sdxl_config() -> UNetConfig:
         addition_time_embed_dim=32, projection_class_embeddings_input_dim=64 + 6 * 32)
 
 
-CONFIGS = {"sd1": sd1_config, "sdxl": sdxl_config, "tiny_sd1": tiny_sd1_config, "tiny_sdxl": tiny_sdxl_config}
+CONFIGS = {"sd1": sd1_config, "sd2": sd2_config, "sdxl": sdxl_config, "tiny_sd1": tiny_sd1_config,
+           "tiny_sd2": tiny_sd2_config, "tiny_sdxl": tiny_sdxl_config}
 
 
 def config_from_json(path: str) -> UNetConfig:

@@ -186,6 +186,16 @@ __global__ __launch_bounds__(256) void cfg_ddim_kernel(const slh_cfg_ddim_desc d
     const float e = round_bf16(u + scaled);
     if (!d.do_step) { ((__bf16*)d.out)[i] = (__bf16)e; return; }
     const float x = (float)((const __bf16*)d.x)[i];
+    if (d.v_prediction) {
+        // DDIMScheduler.step, eta = 0, v prediction: every scalar*tensor and tensor+-tensor rounds to bf16
+        const float x0 = round_bf16(round_bf16(d.c_sqrt_alpha_t * x) - round_bf16(d.c_sqrt_beta_t * e));
+        const float pe = round_bf16(round_bf16(d.c_sqrt_alpha_t * e) + round_bf16(d.c_sqrt_beta_t * x));
+        const float dirv = round_bf16(d.c_dir * pe);
+        const __bf16 resv = (__bf16)(round_bf16(d.c_sqrt_alpha_prev * x0) + dirv);
+        ((__bf16*)d.out)[i] = resv;
+        if (d.out2) ((__bf16*)d.out2)[i] = resv;
+        return;
+    }
     // DDIMScheduler.step, eta = 0, epsilon prediction, fp32 0-dim scalars times bf16 tensors
     const float r1 = round_bf16(d.c_sqrt_beta_t * e);
     const float r2 = round_bf16(x - r1);

@@ -1,8 +1,8 @@
 """Host-side DDIM scheduler state for the hot path (timestep tables and per-step fp32 coefficients).
 
 Mirrors the scheduler the reference builds at trainscripts/textsliders/model_util.py:237-246
-(diffusers DDIMScheduler: scaled_linear betas 0.00085..0.012, 1000 train steps, clip_sample False, epsilon
-prediction, eta 0, set_alpha_to_one, leading spacing).  Only scalars live here; the tensor update
+(diffusers DDIMScheduler: scaled_linear betas 0.00085..0.012, 1000 train steps, clip_sample False, epsilon or
+v prediction (model_util.py:126), eta 0, set_alpha_to_one, leading spacing).  Only scalars live here; the tensor update
 x_t -> x_{t-1} is the fused slh_cfg_ddim kernel.
 """
 from __future__ import annotations
@@ -13,7 +13,11 @@ import torch
 
 
 class DDIMSchedule:
-    def __init__(self, num_train_timesteps: int = 1000, beta_start: float = 0.00085, beta_end: float = 0.012):
+    def __init__(self, num_train_timesteps: int = 1000, beta_start: float = 0.00085, beta_end: float = 0.012,
+                 prediction_type: str = "epsilon"):
+        if prediction_type not in ("epsilon", "v_prediction"):
+            raise ValueError(f"prediction_type {prediction_type!r}: the fused step implements epsilon and v_prediction")
+        self.prediction_type = prediction_type
         self.num_train_timesteps = num_train_timesteps
         betas = torch.linspace(beta_start ** 0.5, beta_end ** 0.5, num_train_timesteps, dtype=torch.float32) ** 2
         self.alphas_cumprod = torch.cumprod(1.0 - betas, dim=0)
@@ -38,6 +42,14 @@ class DDIMSchedule:
         a_p = self.alphas_cumprod[prev_t] if prev_t >= 0 else self.final_alpha_cumprod
         return (float((1 - a_t) ** 0.5), float(torch.tensor(1.0) / (a_t ** 0.5)), float(a_p ** 0.5),
                 float((1 - a_p) ** 0.5))
+
+    def step_fields(self, t: int, n_steps: int) -> dict:
+        """The scheduler fields of slh_cfg_ddim_desc for timestep t (do_step = 1)."""
+        cb, cia, cp, cd = self.step_coefficients(t, n_steps)
+        f = dict(c_sqrt_beta_t=cb, c_inv_sqrt_alpha_t=cia, c_sqrt_alpha_prev=cp, c_dir=cd, do_step=1, v_prediction=0)
+        if self.prediction_type == "v_prediction":
+            f.update(v_prediction=1, c_sqrt_alpha_t=float(self.alphas_cumprod[t] ** 0.5))
+        return f
 
     def add_noise_coefficients(self, t: int) -> Tuple[float, float]:
         a = self.alphas_cumprod[t]

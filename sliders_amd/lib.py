@@ -64,7 +64,8 @@ EwDesc = _struct("EwDesc", _ptrs("a", "b", "out") + _ints("M", "C", "lda", "ldb"
                  + [("alpha", c_f32)] + _ints("pad_"))
 CfgDdimDesc = _struct("CfgDdimDesc", _ptrs("eps", "x", "out", "out2", "eps_text") + _ints("nb", "chw")
                       + [("guidance", c_f32), ("c_sqrt_beta_t", c_f32), ("c_inv_sqrt_alpha_t", c_f32),
-                         ("c_sqrt_alpha_prev", c_f32), ("c_dir", c_f32)] + _ints("do_step"))
+                         ("c_sqrt_alpha_prev", c_f32), ("c_dir", c_f32)] + _ints("do_step", "v_prediction")
+                      + [("c_sqrt_alpha_t", c_f32)] + _ints("pad_"))
 LossDesc = _struct("LossDesc", _ptrs("target", "positive", "neutral", "uncond", "loss", "dtarget", "dtarget_pix")
                    + _ints("n") + [("guidance", c_f32)] + _ints("erase", "hw", "nch"))
 WgradDesc = _struct("WgradDesc", _ptrs("z0", "z1", "v", "out", "scale")

@@ -24,9 +24,11 @@ from .unet import UNetEngine
 
 
 def create_noise_scheduler(scheduler_name: str = "ddim", prediction_type: str = "epsilon"):
-    if scheduler_name.lower().replace(" ", "_") != "ddim" or prediction_type != "epsilon":
-        raise ValueError("only the DDIM / epsilon scheduler of the reference's default configs is implemented")
-    return DDIMScheduler()
+    """model_util.py:230-277.  DDIM with epsilon or v prediction; the reference's other choices (ddpm, lms, euler_a) draw
+    device-side noise per step / work in sigma space and are not implemented by the fused step."""
+    if scheduler_name.lower().replace(" ", "_") != "ddim":
+        raise ValueError(f"noise scheduler '{scheduler_name}': only ddim is implemented")
+    return DDIMScheduler(prediction_type=prediction_type)
 
 
 def load_unet_state(name_or_path: str):
@@ -71,11 +73,13 @@ def synthetic_engine(model: str = "sdxl", device="cuda:0", seed: int = 0) -> UNe
     return UNetEngine(cfg, random_state_dict(cfg, device, seed), device)
 
 
-def load_text_encoder(name_or_path: str, device, dtype=torch.bfloat16):
-    """SD-1.x: one CLIP tokenizer + text encoder (model_util.py:48-66)."""
+def load_text_encoder(name_or_path: str, device, dtype=torch.bfloat16, v2: bool = False):
+    """SD-1.x / SD-2.x: one CLIP tokenizer + text encoder (model_util.py:29-71).  v2: the OpenCLIP-H encoder is cut after
+    its 23rd layer (penultimate-layer embeddings, the reference's "default is clip skip 2")."""
     from transformers import CLIPTextModel, CLIPTokenizer
     tok = CLIPTokenizer.from_pretrained(name_or_path, subfolder="tokenizer")
-    enc = CLIPTextModel.from_pretrained(name_or_path, subfolder="text_encoder").to(device, dtype).eval()
+    kw = {"num_hidden_layers": 23} if v2 else {}
+    enc = CLIPTextModel.from_pretrained(name_or_path, subfolder="text_encoder", **kw).to(device, dtype).eval()
     return tok, enc
 
 

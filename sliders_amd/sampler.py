@@ -29,11 +29,12 @@ from .vae import VaeDecoder
 
 
 class SliderSampler:
-    def __init__(self, engine: UNetEngine, store: Optional[LoraStore] = None, decoder: Optional[VaeDecoder] = None):
+    def __init__(self, engine: UNetEngine, store: Optional[LoraStore] = None, decoder: Optional[VaeDecoder] = None,
+                 prediction_type: str = "epsilon"):
         self.eng, self.store, self.decoder = engine, store, decoder
         if store is not None and engine.lora is not store:
             engine.attach_lora(store)
-        self.sched = DDIMSchedule()
+        self.sched = DDIMSchedule(prediction_type=prediction_type)
 
     @torch.no_grad()
     def sample_latents(self, ctx: torch.Tensor, noise: torch.Tensor, scale: float = 0.0, start_noise: int = 750,
@@ -64,10 +65,8 @@ class SliderSampler:
                 eng.set_lora(True, 0.0 if t > start_noise else float(scale))
             io["t"].tensor.fill_(float(t))
             p.prog.run(s)
-            cb, cia, cp, cd = self.sched.step_coefficients(t, ddim_steps)
             d = lib.CfgDdimDesc(eps=io["eps"].ptr, x=smp.ptr, out=smp.ptr, out2=smp.ptr + half, nb=bs, chw=chw,
-                                guidance=float(guidance_scale), c_sqrt_beta_t=cb, c_inv_sqrt_alpha_t=cia,
-                                c_sqrt_alpha_prev=cp, c_dir=cd, do_step=1)
+                                guidance=float(guidance_scale), **self.sched.step_fields(t, ddim_steps))
             lib.call(lib.OP_CFG_DDIM, d, s)
         if self.store is not None:
             eng.set_lora(False)

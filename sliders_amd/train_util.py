@@ -63,11 +63,9 @@ class DDIMScheduler(DDIMSchedule):
         eps = torch.cat([model_output, model_output]).to(torch.bfloat16).contiguous()   # guidance 1: u + 1*(t-u) = t
         x = sample.to(torch.bfloat16).contiguous()
         out = torch.empty_like(x)
-        cb, cia, cp, cd = self.step_coefficients(int(timestep), self.num_inference_steps)
         nb = x.shape[0]
         d = lib.CfgDdimDesc(eps=eps.data_ptr(), x=x.data_ptr(), out=out.data_ptr(), nb=nb, chw=x[0].numel(),
-                            guidance=1.0, c_sqrt_beta_t=cb, c_inv_sqrt_alpha_t=cia, c_sqrt_alpha_prev=cp, c_dir=cd,
-                            do_step=1)
+                            guidance=1.0, **self.step_fields(int(timestep), self.num_inference_steps))
         lib.call(lib.OP_CFG_DDIM, d, torch.cuda.current_stream().cuda_stream)
         return DDIMScheduler._Out(out)
 

@@ -70,12 +70,12 @@ class SliderTrainer:
     def __init__(self, engine: UNetEngine, store: LoraStore, H: int, W: int, batch_size: int = 1,
                  lr: float = 2e-4, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.01,
                  max_denoising_steps: int = 50, denoise_guidance: float = 3.0, process_group=None,
-                 dedup_frozen: bool = True):
+                 dedup_frozen: bool = True, prediction_type: str = "epsilon"):
         self.eng, self.store = engine, store
         self.lr, self.betas, self.eps, self.wd = lr, betas, eps, weight_decay
         self.nsteps = max_denoising_steps
         self.denoise_guidance = denoise_guidance
-        self.sched = DDIMSchedule()
+        self.sched = DDIMSchedule(prediction_type=prediction_type)   # v_prediction: pretrained_model.v_pred (model_util.py:126)
         self.pg = process_group
         self.rank, self.world = world_info(process_group)
         self.grad_scale = 1.0
@@ -114,8 +114,8 @@ class SliderTrainer:
         d = lib.CfgDdimDesc(eps=p.io["eps"].ptr, x=x or 0, out=out, out2=out2 or 0, eps_text=eps_text or 0,
                             nb=self.bs, chw=self.chw, guidance=guidance, do_step=0)
         if coeff is not None:
-            d.c_sqrt_beta_t, d.c_inv_sqrt_alpha_t, d.c_sqrt_alpha_prev, d.c_dir = coeff
-            d.do_step = 1
+            for kf, vf in coeff.items():
+                setattr(d, kf, vf)
         lib.call(lib.OP_CFG_DDIM, d, _stream())
 
     def _predict(self, p, lat, ctx, pooled, t, out):
@@ -181,7 +181,7 @@ class SliderTrainer:
             p_on.io["t"].tensor.fill_(float(t))
             p_on.prog.run(s)
             self.unet_passes += 1
-            self._cfg(p_on, smp.ptr, self.denoise_guidance, self.sched.step_coefficients(t, self.nsteps),
+            self._cfg(p_on, smp.ptr, self.denoise_guidance, self.sched.step_fields(t, self.nsteps),
                       out2=smp.ptr + half, x=smp.ptr)
         self.denoised.copy_(smp.tensor[:bs])
         t_cur = self.t1000[int(k * 1000 / self.nsteps)]

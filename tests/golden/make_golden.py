@@ -5,7 +5,7 @@ container, over the oracle UNet (class names / module paths of diffusers) with a
 The reference repo has no tests or golden vectors of its own, and it cannot travel to
 the GPU box, so these fixtures are how the oracle and the HIP path are pinned to the reference's code:
 
-  lora_census.json      LoRANetwork(...).state_dict() key order + shapes for SD-1.x / SDXL and every
+  lora_census.json      LoRANetwork(...).state_dict() key order + shapes for SD-1.x / SD-2.x / SDXL and every
                         train_method (full lists for noxattn, sha256 for the rest)         <- lora.py:164-248
   tiny_forward.pt       tiny SDXL-/SD1-topology UNets with the reference LoRANetwork attached (non-zero up
                         weights): unet(...) under `with network`, predict_noise[_xl], diffusion[_xl] (3 DDIM
@@ -17,7 +17,8 @@ the GPU box, so these fixtures are how the oracle and the HIP path are pinned to
                         conv leaves included)                                               <- lora.py:68-97, 206-216
   schema.json           the reference's pydantic parse of tests/golden/{config,prompts}_sample.yaml
                                                                                            <- config_util.py, prompt_util.py
-Run:  python tests/golden/make_golden.py      (needs /root/reference; not run on the GPU box)
+Run:  python tests/golden/make_golden.py [census|tiny_forward|loss|schema|lora_init ...]   (needs /root/reference; not run
+      on the GPU box)
 """
 import contextlib
 import hashlib
@@ -57,7 +58,7 @@ def quiet(fn, *a, **k):
 
 def census():
     out = {}
-    for name in ("sd1", "sdxl"):
+    for name in ("sd1", "sd2", "sdxl"):
         for method in METHODS:
             c3lier()
             net = build_unet(name, device="meta")
@@ -182,4 +183,6 @@ def lora_init():
 
 
 if __name__ == "__main__":
-    lora_init()
+    which = sys.argv[1:] or ["census", "tiny_forward", "loss", "schema", "lora_init"]
+    for w in which:
+        {"census": census, "tiny_forward": tiny_forward, "loss": loss, "schema": schema, "lora_init": lora_init}[w]()

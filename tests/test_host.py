@@ -341,9 +341,8 @@ def test_optimizer_options_and_rejections():
     with pytest.raises(ValueError):
         check_supported(_cfg(lr_scheduler="nope"))
     c = _cfg()
-    c.pretrained_model.v_pred = True
-    with pytest.raises(NotImplementedError):
-        check_supported(c)
+    c.pretrained_model.v2 = c.pretrained_model.v_pred = True      # SD-2.x 768-v: implemented (sd2 config + v-prediction DDIM)
+    check_supported(c)
     check_supported(_cfg(lr_scheduler="cosine", optimizer="adam"))
 
 

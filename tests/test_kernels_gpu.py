@@ -432,6 +432,30 @@ def test_cfg_ddim_bit_exact(dev):
     print("[parity] cfg_ddim: bit-exact at t=980,500,0")
 
 
+def test_cfg_ddim_v_prediction_bit_exact(dev):
+    """SD-2.x 768-v (pretrained_model.v_pred): the fused CFG + DDIM step with v-prediction against the oracle scheduler's
+    restatement of the diffusers tensor ops (bf16 tensors x fp32 0-dim scalars), bit for bit."""
+    torch.manual_seed(12)
+    from oracle.ddim_oracle import DDIMScheduler
+    from sliders_amd.ddim import DDIMSchedule
+    sch = DDIMScheduler(prediction_type="v_prediction")
+    sch.set_timesteps(50)
+    prod = DDIMSchedule(prediction_type="v_prediction")
+    nb, chw = 2, 4 * 32 * 32
+    eps = bf(torch.randn(2 * nb, chw, device=dev))
+    x = bf(torch.randn(nb, chw, device=dev))
+    for t in (980, 500, 0):
+        out = torch.zeros(nb, chw, device=dev, dtype=torch.bfloat16)
+        d = lib.CfgDdimDesc(eps=p(eps), x=p(x), out=p(out), nb=nb, chw=chw, guidance=3.0, **prod.step_fields(t, 50))
+        lib.call(lib.OP_CFG_DDIM, d, stream())
+        torch.cuda.synchronize()
+        u, tt = eps.cpu().chunk(2)
+        ref = sch.step(u + 3 * (tt - u), t, x.cpu()).prev_sample
+        assert ref.dtype == torch.bfloat16
+        assert torch.equal(out.cpu(), ref), f"v-prediction cfg+ddim not bit-exact at t={t}"
+    print("[parity] cfg_ddim v_prediction: bit-exact at t=980,500,0")
+
+
 def test_loss_and_grad(dev):
     torch.manual_seed(12)
     n = 4 * 64 * 64

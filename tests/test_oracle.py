@@ -23,14 +23,14 @@ G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
 def test_param_counts_match_published_architectures():
-    """859,520,964 (SD-1.x) and 2,567,463,684 (SDXL-base) UNet parameters."""
-    for name, n in (("sd1", 859_520_964), ("sdxl", 2_567_463_684)):
+    """859,520,964 (SD-1.x), 865,910,724 (SD-2.x) and 2,567,463,684 (SDXL-base) UNet parameters."""
+    for name, n in (("sd1", 859_520_964), ("sd2", 865_910_724), ("sdxl", 2_567_463_684)):
         net = build_unet(name, device="meta")
         assert sum(p.numel() for p in net.parameters()) == n
 
 
 def test_module_tree_matches_oracle():
-    for name in ("sd1", "sdxl", "tiny_sd1", "tiny_sdxl"):
+    for name in ("sd1", "sd2", "sdxl", "tiny_sd1", "tiny_sd2", "tiny_sdxl"):
         net = build_unet(name, device="meta")
         a = [(n, m.__class__.__name__) for n, m in net.named_modules()]
         b = [(n, m.cls) for n, m in build_tree(CONFIGS[name]()).named_modules()]
@@ -41,7 +41,7 @@ def _key_shapes(store):
     return [[k, list(v.shape)] for k, v in store.state_dict().items()]
 
 
-@pytest.mark.parametrize("name", ["sd1", "sdxl"])
+@pytest.mark.parametrize("name", ["sd1", "sd2", "sdxl"])
 def test_lora_census_and_checkpoint_layout_match_reference(name):
     """Key order, names and shapes of LoRANetwork.state_dict() (lora.py:231-248) - what the reference's
     inference notebooks strict-load."""
@@ -147,6 +147,31 @@ def test_ddim_closed_form_and_tables():
         p = DDIMSchedule()
         assert p.step_coefficients(t, 50) == sch.step_coefficients(t)
     assert DDIMSchedule().make_timesteps(50) == sch.timesteps.tolist()
+
+
+def test_ddim_v_prediction_closed_form():
+    """pretrained_model.v_pred (model_util.py:126): x0 = sqrt(a) x - sqrt(1-a) v, eps = sqrt(a) v + sqrt(1-a) x, then the same
+    eta = 0 update; oracle and product-side coefficient tables agree."""
+    sch = DDIMScheduler(prediction_type="v_prediction")
+    sch.set_timesteps(50)
+    a = torch.cumprod(1 - torch.linspace(0.00085 ** 0.5, 0.012 ** 0.5, 1000, dtype=torch.float64) ** 2, 0)
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(1, 4, 8, 8, dtype=torch.float64, generator=g)
+    v = torch.randn(1, 4, 8, 8, dtype=torch.float64, generator=g)
+    p = DDIMSchedule(prediction_type="v_prediction")
+    for t in (980, 500, 20, 0):
+        at, ap = a[t], (a[t - 20] if t >= 20 else torch.tensor(1.0, dtype=torch.float64))
+        x0 = at.sqrt() * x - (1 - at).sqrt() * v
+        e = at.sqrt() * v + (1 - at).sqrt() * x
+        ref = ap.sqrt() * x0 + (1 - ap).sqrt() * e
+        got = sch.step(v.float(), t, x.float()).prev_sample
+        assert (got.double() - ref).abs().max() < 5e-5 * max(1.0, ref.abs().max().item())
+        f = p.step_fields(t, 50)
+        assert f["v_prediction"] == 1 and f["c_sqrt_alpha_t"] == float(sch.alphas_cumprod[t] ** 0.5)
+        assert (f["c_sqrt_beta_t"], f["c_inv_sqrt_alpha_t"], f["c_sqrt_alpha_prev"], f["c_dir"]) == sch.step_coefficients(t)
+    assert DDIMSchedule().step_fields(500, 50)["v_prediction"] == 0
+    with pytest.raises(ValueError):
+        DDIMSchedule(prediction_type="sample")
 
 
 @pytest.mark.parametrize("name,method", [("tiny_sdxl", "noxattn"), ("tiny_sdxl", "full"), ("tiny_sd1", "noxattn"), ("tiny_sd1", "full")])

@@ -39,15 +39,17 @@ def _pair(emb, pool, dev, action="enhance"):
                       guidance_scale=4.0, action=action)
 
 
-@pytest.mark.parametrize("name,action", [("tiny_sdxl", "enhance"), ("tiny_sd1", "erase")])
-def test_iteration_matches_reference_loop_on_oracle(dev, name, action):
-    """SDXL loop (train_lora_xl.py) with an `enhance` pair and SD-1.x loop (train_lora.py) with an `erase` pair."""
+@pytest.mark.parametrize("name,action,pred", [("tiny_sdxl", "enhance", "epsilon"), ("tiny_sd1", "erase", "epsilon"),
+                                              ("tiny_sd2", "enhance", "v_prediction")])
+def test_iteration_matches_reference_loop_on_oracle(dev, name, action, pred):
+    """SDXL loop (train_lora_xl.py) with an `enhance` pair, SD-1.x loop (train_lora.py) with an `erase` pair, and the
+    SD-2.x 768-v setting (pretrained_model.v2 + v_pred: model_util.py:107-128) with the v-prediction DDIM step."""
     k, hw = 3, 16
     cfg, store, emb, pool, noise = _setup(dev, name)
     sd = store.state_dict()
     params0 = store.params.clone()
     eng = UNetEngine(cfg, build_unet(name, seed=0).state_dict(), dev)
-    tr = SliderTrainer(eng, store, hw, hw, lr=2e-4)
+    tr = SliderTrainer(eng, store, hw, hw, lr=2e-4, prediction_type=pred)
     loss = tr.iteration(_pair(emb, pool, dev, action), k, noise.to(dev))
     torch.cuda.synchronize()
     assert tr.unet_passes == k + 4
@@ -57,7 +59,7 @@ def test_iteration_matches_reference_loop_on_oracle(dev, name, action):
     nw.load_state_dict(sd, strict=True)
     for p_ in nw.parameters():
         p_.requires_grad_(True)
-    sch = DDIMScheduler()
+    sch = DDIMScheduler(prediction_type=pred)
     tid = torch.tensor([[128.0, 128.0, 0, 0, 128.0, 128.0]] * 2)
 
     def predict(x, which, t, g):
@@ -95,7 +97,9 @@ def test_iteration_matches_reference_loop_on_oracle(dev, name, action):
     # 1.3 x the worst values measured on MI355X over both cases and several runs (denoised 6.5e-3, target 1.31e-2,
     # loss within 3.3 %, gradient cosine 0.9857-0.9959; the run-to-run floor of the engine itself is cosine 0.993)
     assert r_den < 8.5e-3 and r_tgt < 1.7e-2
-    assert abs(loss.item() - ref_loss.item()) < 0.045 * ref_loss.item()
+    # (the SD-2.x-like net measured 6.2 %: its predictions sit at rel-L2 1.2-1.5e-2 like its torch-bf16 arm, and the loss is a
+    # difference of four of them)
+    assert abs(loss.item() - ref_loss.item()) < (0.08 if name == "tiny_sd2" else 0.045) * ref_loss.item()
     assert cos > 0.98
     # AdamW moved every trainable parameter by about lr (first step: |update| ~ lr)
     delta = (store.params.float() - params0.float()).abs()

@@ -58,7 +58,7 @@ def check(name, got, e32, ebf):
     assert (got - e32).abs().max().item() <= 2.8e-2, f"{name}: max abs error {(got - e32).abs().max().item():.3e}"
 
 
-@pytest.mark.parametrize("name,hw", [("tiny_sdxl", 16), ("tiny_sd1", 16), ("tiny_sdxl", 24)])
+@pytest.mark.parametrize("name,hw", [("tiny_sdxl", 16), ("tiny_sd1", 16), ("tiny_sdxl", 24), ("tiny_sd2", 16)])
 def test_unet_forward_parity_no_lora(dev, name, hw):
     cfg = CONFIGS[name]()
     net = build_unet(name, seed=0)
@@ -92,7 +92,7 @@ def test_unet_forward_rectangular_and_odd_batches(dev, name, B, h, w):
 
 
 @pytest.mark.parametrize("name,method", [("tiny_sdxl", "noxattn"), ("tiny_sdxl", "full"), ("tiny_sd1", "noxattn"),
-                                         ("tiny_sdxl", "xattn")])
+                                         ("tiny_sdxl", "xattn"), ("tiny_sd2", "full")])
 def test_unet_forward_parity_with_lora(dev, name, method):
     cfg = CONFIGS[name]()
     hw = 16
@@ -140,9 +140,9 @@ def test_unet_forward_parity_with_lora(dev, name, method):
     assert rel_err(e_on, e_plain) > 1e-3, "test is vacuous: adapters have no visible effect"
 
 
-@pytest.mark.parametrize("name", ["sd1", "sdxl"])
+@pytest.mark.parametrize("name", ["sd1", "sd2", "sdxl"])
 def test_full_size_forward_parity(dev, name):
-    """The real SD-1.x / SDXL architectures (859.5 M / 2567 M parameters, seeded random init) at 256x256:
+    """The real SD-1.x / SD-2.x / SDXL architectures (859.5 M / 865.9 M / 2567 M parameters, seeded random init) at 256x256:
     HIP engine vs the fp32 CPU oracle on identical bf16-rounded weights."""
     import os
     import time
