@@ -356,6 +356,18 @@ typedef struct slh_adamw_desc {
 } slh_adamw_desc;
 int slh_adamw(const slh_adamw_desc* d, slh_stream_t stream);
 
+/* flat Lion over the packed LoRA parameter buffer (train.optimizer "lion": train_util.py:365-368 -> lion_pytorch==0.1.2,
+ * requirements.txt:5).  One bf16 moment; op order and bf16 rounding points of that package's update_fn:
+ *   p.mul_(1 - lr*wd); update = sign(exp_avg*b1 + (1-b1)*g); p.add_(update, alpha=-lr); exp_avg = exp_avg*b2 + (1-b2)*g */
+typedef struct slh_lion_desc {
+    void* param; void* exp_avg; const float* grad;
+    int64_t n;
+    double lr, beta1, beta2, weight_decay;
+    float grad_scale;        /* multiply grads first (1/world_size after all-reduce) */
+    int32_t pad_;
+} slh_lion_desc;
+int slh_lion(const slh_lion_desc* d, slh_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Image sliders: AutoencoderKL encoder + posterior sample + add_noise in fp32 on the GPU.
  * Replaces trainscripts/imagesliders/train_util.py:200-235 `get_noisy_image` (vae.encode(...).latent_dist.sample()
@@ -432,7 +444,7 @@ enum {
     SLH_OP_WGRAD = 14, SLH_OP_ADAMW = 15, SLH_OP_GN_BWD_STATS = 16, SLH_OP_GN_BWD_APPLY = 17,
     SLH_OP_LAYERNORM_BWD = 18, SLH_OP_ATTN_BWD = 19, SLH_OP_MEMSET = 20, SLH_OP_LORA_CONV_DGRAD = 21,
     SLH_OP_TEMB_LORA_BWD = 22, SLH_OP_SGEMM = 23, SLH_OP_GN32_STATS = 24, SLH_OP_GN32_APPLY = 25, SLH_OP_SOFTMAX32 = 26,
-    SLH_OP_VAE_CONV_IN = 27, SLH_OP_VAE_MOMENTS = 28, SLH_OP_VAE_SAMPLE = 29, SLH_OP_VAE_POST_QUANT = 30
+    SLH_OP_VAE_CONV_IN = 27, SLH_OP_VAE_MOMENTS = 28, SLH_OP_VAE_SAMPLE = 29, SLH_OP_VAE_POST_QUANT = 30, SLH_OP_LION = 31
 };
 typedef struct slh_memset_desc { void* ptr; int64_t nbytes; int32_t value; int32_t pad; } slh_memset_desc;
 int slh_run_program(const void* program, int64_t nbytes, slh_stream_t stream);

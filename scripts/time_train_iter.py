@@ -52,3 +52,34 @@ p_tr = eng.plan(2, hw, hw, "train")
 print(f"train forward (B=2, tape kept):  {timeit(lambda: p_tr.prog.run(s)):.2f} ms")
 eng.run_backward(d_eps=torch.randn(1, 4, hw, hw, device=dev) * 1e-3)
 print(f"backward (1 sample):             {timeit(lambda: p_tr.backward.prog.run(s)):.2f} ms  ({p_tr.backward.prog.n_ops} launches)")
+
+
+def breakdown(prog, title):
+    """Per entry-point totals of one replay, HIP events around every op (adds ~1 us per op)."""
+    from collections import defaultdict
+    from sliders_amd import lib
+    stream = torch.cuda.current_stream()
+    recs = []
+    for op, d in prog.ops:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(stream)
+        if op in lib._ENTRY:
+            lib.call(op, d, s)
+        else:
+            one = lib.Program(); one.add(op, d); one.run(s)
+        e1.record(stream)
+        recs.append((op, e0, e1))
+    torch.cuda.synchronize()
+    agg = defaultdict(lambda: [0, 0.0])
+    for op, e0, e1 in recs:
+        k = lib._ENTRY[op][0] if op in lib._ENTRY else "memset"
+        agg[k][0] += 1
+        agg[k][1] += e0.elapsed_time(e1)
+    print(f"-- {title}: {sum(v[1] for v in agg.values()):.2f} ms summed over {len(recs)} ops")
+    for k, (n, ms) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+        print(f"   {k:24s} x{n:5d} {ms:8.3f} ms  ({ms / n * 1e3:7.1f} us each)")
+
+
+if "--breakdown" in sys.argv:
+    breakdown(p_tr.backward.prog, "backward")
+    breakdown(p_on.prog, "denoise pass")

@@ -107,12 +107,14 @@ class LrSchedule:
 
 
 def optimizer_options(train_cfg) -> dict:
-    """`train.optimizer` + `train.optimizer_args` ("k=v k=v", train_lora_xl.py:92-101) -> arguments of the fused flat AdamW
-    (slh_adamw).  Anything that kernel does not implement is an error, never silently ignored."""
+    """`train.optimizer` + `train.optimizer_args` ("k=v k=v", train_lora_xl.py:92-101) -> arguments of the fused flat
+    optimizer kernels (slh_adamw for adam / adamw, slh_lion for lion).  Anything those kernels do not implement is an error,
+    never silently ignored."""
     name = (train_cfg.optimizer or "adamw").lower()
-    if name not in ("adamw", "adam"):
-        raise NotImplementedError(f"train.optimizer '{train_cfg.optimizer}': the fused MI355X path implements adam / adamw "
-                                  f"(lion, prodigy, dadapt*, *8bit need packages that are not in this image)")
+    if name not in ("adamw", "adam", "lion"):
+        raise NotImplementedError(f"train.optimizer '{train_cfg.optimizer}': the fused MI355X path implements adam / adamw / lion "
+                                  f"(prodigy, dadapt*, *8bit are adaptive-step / quantised-state methods of packages that are "
+                                  f"not in this image)")
     kw = {}
     if train_cfg.optimizer_args:
         for arg in train_cfg.optimizer_args.split(" "):
@@ -120,11 +122,16 @@ def optimizer_options(train_cfg) -> dict:
                 continue
             key, value = arg.split("=")
             kw[key] = ast.literal_eval(value)
-    out = {"betas": (0.9, 0.999), "eps": 1e-8, "weight_decay": 0.01 if name == "adamw" else 0.0}
+    if name == "lion":      # lion_pytorch.Lion defaults (requirements.txt:5)
+        out = {"betas": (0.9, 0.99), "weight_decay": 0.0}
+    else:
+        out = {"betas": (0.9, 0.999), "eps": 1e-8, "weight_decay": 0.01 if name == "adamw" else 0.0}
     for key, value in kw.items():
         if key not in out:
-            raise NotImplementedError(f"train.optimizer_args '{key}' is not implemented by the fused AdamW")
+            raise NotImplementedError(f"train.optimizer_args '{key}' is not implemented by the fused {name} kernel")
         out[key] = value
+    out.setdefault("eps", 0.0)
+    out["name"] = name
     if name == "adam" and out["weight_decay"] != 0:
         raise NotImplementedError("adam with weight_decay != 0 is L2-coupled decay; only decoupled (adamw) decay is implemented")
     out["betas"] = (float(out["betas"][0]), float(out["betas"][1]))
@@ -181,7 +188,8 @@ def train(config: config_util.RootConfig, prompts, device: int, xl: bool, synthe
                        eps=opt["eps"], weight_decay=opt["weight_decay"],
                        max_denoising_steps=config.train.max_denoising_steps,
                        process_group=torch.distributed.group.WORLD if world > 1 else None,
-                       prediction_type="v_prediction" if config.pretrained_model.v_pred else "epsilon")
+                       prediction_type="v_prediction" if config.pretrained_model.v_pred else "epsilon",
+                       optimizer=opt["name"])
     if synthetic:
         pairs = _synthetic_pairs(eng.cfg, prompts, dev, seed)
     else:

@@ -103,7 +103,7 @@ def train(config, prompts, device: int, xl: bool, folder_main: str, folders, sca
     hw = size // 8
     tr = ImageSliderTrainer(eng, store, vae, hw, hw, batch_size=1, lr=config.train.lr, betas=opt["betas"], eps=opt["eps"],
                             weight_decay=opt["weight_decay"], max_denoising_steps=config.train.max_denoising_steps,
-                            process_group=torch.distributed.group.WORLD if world > 1 else None)
+                            process_group=torch.distributed.group.WORLD if world > 1 else None, optimizer=opt["name"])
     pairs = (_synthetic_pairs(eng.cfg, prompts, dev, seed) if synthetic else
              _encoded_pairs(eng.cfg, prompts, config.pretrained_model.name_or_path, dev,
                             config_util.parse_precision(config.train.precision)))

@@ -256,6 +256,24 @@ __global__ __launch_bounds__(256) void adamw_kernel(const slh_adamw_desc d, floa
     P[i] = (__bf16)p; M1[i] = (__bf16)m; M2[i] = (__bf16)v;
 }
 
+// ---- Lion over the flat LoRA buffer: lion_pytorch 0.1.2 update_fn op order, bf16 state -------------------
+__global__ __launch_bounds__(256) void lion_kernel(const slh_lion_desc d, float decay, float b1, float w1, float b2,
+                                                   float w2, float neg_lr) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= d.n) return;
+    __bf16* P = (__bf16*)d.param; __bf16* M = (__bf16*)d.exp_avg;
+    const float g = round_bf16(d.grad[i] * d.grad_scale);     // param.grad is bf16 in the reference
+    float p = round_bf16((float)P[i] * decay);                  // p.data.mul_(1 - lr * wd)
+    const float m0 = (float)M[i];
+    float u = round_bf16(m0 * b1);                              // exp_avg.clone().mul_(beta1)
+    u = round_bf16(u + w1 * g);                                 //   .add(grad, alpha = 1 - beta1)
+    const float sg = u > 0.f ? 1.f : (u < 0.f ? -1.f : 0.f);    //   .sign_()
+    p = round_bf16(p + neg_lr * sg);                            // p.add_(update, alpha = -lr)
+    float m = round_bf16(m0 * b2);                              // exp_avg.mul_(beta2)
+    m = round_bf16(m + w2 * g);                                 //   .add_(grad, alpha = 1 - beta2)
+    P[i] = (__bf16)p; M[i] = (__bf16)m;
+}
+
 }  // namespace
 
 extern "C" int slh_timestep_embed(const slh_tembed_desc* d, slh_stream_t stream) {
@@ -326,5 +344,15 @@ extern "C" int slh_adamw(const slh_adamw_desc* d, slh_stream_t stream) {
                        decay, bc2_sqrt, step_size, (float)(1.0 - d->beta1), (float)d->beta2, (float)(1.0 - d->beta2),
                        (float)d->eps);
     SLH_LAUNCH_CHECK("slh_adamw");
+    return 0;
+}
+
+extern "C" int slh_lion(const slh_lion_desc* d, slh_stream_t stream) {
+    SLH_CHECK(d && d->param && d->exp_avg && d->grad && d->n > 0, "slh_lion: bad desc");
+    // scalars are python floats in the package: computed in double, then cast to the fp32 opmath type
+    hipLaunchKernelGGL(lion_kernel, dim3((unsigned)((d->n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, *d,
+                       (float)(1.0 - d->lr * d->weight_decay), (float)d->beta1, (float)(1.0 - d->beta1), (float)d->beta2,
+                       (float)(1.0 - d->beta2), (float)(-d->lr));
+    SLH_LAUNCH_CHECK("slh_lion");
     return 0;
 }

@@ -53,6 +53,7 @@ extern "C" int slh_run_program(const void* program, int64_t nbytes, slh_stream_t
             case SLH_OP_LOSS: rc = run_desc<slh_loss_desc>(p, sz, slh_guidance_loss, stream, "loss"); break;
             case SLH_OP_WGRAD: rc = run_desc<slh_wgrad_desc>(p, sz, slh_lora_wgrad, stream, "wgrad"); break;
             case SLH_OP_ADAMW: rc = run_desc<slh_adamw_desc>(p, sz, slh_adamw, stream, "adamw"); break;
+            case SLH_OP_LION: rc = run_desc<slh_lion_desc>(p, sz, slh_lion, stream, "lion"); break;
             case SLH_OP_GN_BWD_STATS:
                 rc = run_desc<slh_gn_bwd_desc>(p, sz, slh_gn_bwd_stats, stream, "gn_bwd_stats"); break;
             case SLH_OP_GN_BWD_APPLY:
@@ -159,7 +160,7 @@ extern "C" int slh_desc_sizes(int32_t* out, int32_t cap) {
         (int32_t)sizeof(slh_wgrad_desc),    (int32_t)sizeof(slh_adamw_desc),    (int32_t)sizeof(slh_memset_desc),
         (int32_t)sizeof(slh_lora_cdgrad_desc), (int32_t)sizeof(slh_temb_lora_bwd_desc),
         (int32_t)sizeof(slh_sgemm_desc),    (int32_t)sizeof(slh_gn32_desc),     (int32_t)sizeof(slh_softmax32_desc),
-        (int32_t)sizeof(slh_vae_conv_desc), (int32_t)sizeof(slh_vae_sample_desc)};
+        (int32_t)sizeof(slh_vae_conv_desc), (int32_t)sizeof(slh_vae_sample_desc), (int32_t)sizeof(slh_lion_desc)};
     const int n = (int)(sizeof(sizes) / sizeof(sizes[0]));
     for (int i = 0; i < n && i < cap; ++i) out[i] = sizes[i];
     return n;

@@ -74,6 +74,8 @@ WgradDesc = _struct("WgradDesc", _ptrs("z0", "z1", "v", "out", "scale")
 AdamwDesc = _struct("AdamwDesc", _ptrs("param", "exp_avg", "exp_avg_sq", "grad") + [("n", c_i64)]
                     + [(n, c_f64) for n in ("lr", "beta1", "beta2", "eps", "weight_decay")]
                     + _ints("step") + [("grad_scale", c_f32)])
+LionDesc = _struct("LionDesc", _ptrs("param", "exp_avg", "grad") + [("n", c_i64)]
+                   + [(n, c_f64) for n in ("lr", "beta1", "beta2", "weight_decay")] + [("grad_scale", c_f32)] + _ints("pad_"))
 MemsetDesc = _struct("MemsetDesc", _ptrs("ptr") + [("nbytes", c_i64)] + _ints("value", "pad"))
 LoraCdgradDesc = _struct("LoraCdgradDesc", _ptrs("u", "a_down", "scale", "gx")
                          + _ints("batch", "hl", "wl", "ho", "wo", "stride", "cin", "ldu", "ldgx", "accumulate"))
@@ -94,7 +96,7 @@ VaeSampleDesc = _struct("VaeSampleDesc", _ptrs("moments", "post_noise", "noise",
 # order of slh_desc_sizes()
 _SIZE_ORDER = [GemmDesc, SkinnyDesc, GemvDesc, GnDesc, GnBwdDesc, LnDesc, LnBwdDesc, AttnDesc, TransposeDesc,
                AttnBwdDesc, TembedDesc, ConvInDesc, EwDesc, CfgDdimDesc, LossDesc, WgradDesc, AdamwDesc, MemsetDesc,
-               LoraCdgradDesc, TembLoraBwdDesc, SgemmDesc, Gn32Desc, Softmax32Desc, VaeConvDesc, VaeSampleDesc]
+               LoraCdgradDesc, TembLoraBwdDesc, SgemmDesc, Gn32Desc, Softmax32Desc, VaeConvDesc, VaeSampleDesc, LionDesc]
 
 # opcodes (enum in sliders_hip.h)
 OP_GEMM, OP_SKINNY, OP_GEMV, OP_GN_STATS, OP_GN_APPLY, OP_LAYERNORM, OP_ATTN_FWD, OP_TRANSPOSE_HEADS = range(1, 9)
@@ -102,6 +104,7 @@ OP_TEMBED, OP_CONV_IN, OP_ELEMENTWISE, OP_CFG_DDIM, OP_LOSS, OP_WGRAD, OP_ADAMW 
 OP_GN_BWD_STATS, OP_GN_BWD_APPLY, OP_LAYERNORM_BWD, OP_ATTN_BWD, OP_MEMSET = range(16, 21)
 OP_LORA_CONV_DGRAD, OP_TEMB_LORA_BWD = 21, 22
 OP_SGEMM, OP_GN32_STATS, OP_GN32_APPLY, OP_SOFTMAX32, OP_VAE_CONV_IN, OP_VAE_MOMENTS, OP_VAE_SAMPLE, OP_VAE_POST_QUANT = range(23, 31)
+OP_LION = 31
 
 EW_COPY, EW_ADD, EW_GEGLU_FWD, EW_GEGLU_BWD, EW_UPSAMPLE_BWD, EW_COLSUM = range(6)
 
@@ -120,7 +123,7 @@ _ENTRY = {
     OP_SGEMM: ("slh_sgemm", SgemmDesc), OP_GN32_STATS: ("slh_gn32_stats", Gn32Desc), OP_GN32_APPLY: ("slh_gn32_apply", Gn32Desc),
     OP_SOFTMAX32: ("slh_softmax32", Softmax32Desc), OP_VAE_CONV_IN: ("slh_vae_conv_in", VaeConvDesc),
     OP_VAE_MOMENTS: ("slh_vae_moments", VaeConvDesc), OP_VAE_SAMPLE: ("slh_vae_sample", VaeSampleDesc),
-    OP_VAE_POST_QUANT: ("slh_vae_post_quant", VaeConvDesc),
+    OP_VAE_POST_QUANT: ("slh_vae_post_quant", VaeConvDesc), OP_LION: ("slh_lion", LionDesc),
 }
 
 EXPORTS = ["slh_version", "slh_last_error", "slh_run_program", "slh_desc_sizes", "slh_graph_capture", "slh_graph_launch",

@@ -44,10 +44,9 @@ def load_unet_state(name_or_path: str):
             raw = raw.get("state_dict", raw)
         is_xl = any(k.startswith(LDM_PREFIX + "label_emb.") for k in raw)
         probe = raw.get(LDM_PREFIX + "input_blocks.1.1.proj_in.weight")
-        if not is_xl and probe is not None and probe.ndim == 2:
-            raise NotImplementedError("Stable Diffusion 2.x single-file checkpoints (linear projections, 1024-d "
-                                      "context, v-prediction) are outside the implemented configs")
-        cfg = CONFIGS["sdxl" if is_xl else "sd1"]()
+        # SD-2.x single files: Linear proj_in (2-D weight) without SDXL's label_emb MLP; same key renaming
+        is_v2 = not is_xl and probe is not None and probe.ndim == 2
+        cfg = CONFIGS["sdxl" if is_xl else ("sd2" if is_v2 else "sd1")]()
         return cfg, convert_ldm_unet_state_dict(raw, cfg)
     unet_dir = os.path.join(name_or_path, "unet")
     cfg_path = os.path.join(unet_dir, "config.json")

@@ -70,9 +70,12 @@ class SliderTrainer:
     def __init__(self, engine: UNetEngine, store: LoraStore, H: int, W: int, batch_size: int = 1,
                  lr: float = 2e-4, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.01,
                  max_denoising_steps: int = 50, denoise_guidance: float = 3.0, process_group=None,
-                 dedup_frozen: bool = True, prediction_type: str = "epsilon"):
+                 dedup_frozen: bool = True, prediction_type: str = "epsilon", optimizer: str = "adamw"):
         self.eng, self.store = engine, store
         self.lr, self.betas, self.eps, self.wd = lr, betas, eps, weight_decay
+        if optimizer not in ("adamw", "adam", "lion"):
+            raise NotImplementedError(f"optimizer '{optimizer}': fused flat kernels exist for adam / adamw (slh_adamw) and lion (slh_lion)")
+        self.optimizer = optimizer
         self.nsteps = max_denoising_steps
         self.denoise_guidance = denoise_guidance
         self.sched = DDIMSchedule(prediction_type=prediction_type)   # v_prediction: pretrained_model.v_pred (model_util.py:126)
@@ -217,6 +220,12 @@ class SliderTrainer:
     def optimizer_step(self):
         st = self.store
         st.opt_step += 1
+        if self.optimizer == "lion":        # one moment (store.exp_avg); lion_pytorch 0.1.2 op order
+            d = lib.LionDesc(param=st.params.data_ptr(), exp_avg=st.exp_avg.data_ptr(), grad=st.grads.data_ptr(), n=st.numel,
+                             lr=self.lr, beta1=self.betas[0], beta2=self.betas[1], weight_decay=self.wd,
+                             grad_scale=self.grad_scale)
+            lib.call(lib.OP_LION, d, _stream())
+            return
         d = lib.AdamwDesc(param=st.params.data_ptr(), exp_avg=st.exp_avg.data_ptr(), exp_avg_sq=st.exp_avg_sq.data_ptr(),
                           grad=st.grads.data_ptr(), n=st.numel, lr=self.lr, beta1=self.betas[0], beta2=self.betas[1],
                           eps=self.eps, weight_decay=self.wd, step=st.opt_step, grad_scale=self.grad_scale)

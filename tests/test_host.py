@@ -328,11 +328,15 @@ def test_cli_rank_and_alpha_override_only_when_given():
 
 def test_optimizer_options_and_rejections():
     from sliders_amd.cli import check_supported, optimizer_options
-    assert optimizer_options(_cfg().train) == {"betas": (0.9, 0.999), "eps": 1e-8, "weight_decay": 0.01}
+    assert optimizer_options(_cfg().train) == {"betas": (0.9, 0.999), "eps": 1e-8, "weight_decay": 0.01, "name": "adamw"}
     o = optimizer_options(_cfg(optimizer="adamw", optimizer_args="weight_decay=0.1 betas=(0.8,0.99) eps=1e-6").train)
-    assert o == {"betas": (0.8, 0.99), "eps": 1e-6, "weight_decay": 0.1}
+    assert o == {"betas": (0.8, 0.99), "eps": 1e-6, "weight_decay": 0.1, "name": "adamw"}
     assert optimizer_options(_cfg(optimizer="adam").train)["weight_decay"] == 0.0
-    for bad in (dict(optimizer="lion"), dict(optimizer="prodigy"), dict(optimizer="adam8bit"),
+    # lion_pytorch.Lion defaults (requirements.txt:5) and its own argument names only
+    assert optimizer_options(_cfg(optimizer="Lion").train) == {"betas": (0.9, 0.99), "weight_decay": 0.0, "eps": 0.0, "name": "lion"}
+    assert optimizer_options(_cfg(optimizer="lion", optimizer_args="weight_decay=0.02 betas=(0.95,0.98)").train)["betas"] == (0.95, 0.98)
+    for bad in (dict(optimizer="lion", optimizer_args="eps=1e-6"), dict(optimizer="lion", optimizer_args="use_triton=True"),
+                dict(optimizer="prodigy"), dict(optimizer="adam8bit"), dict(optimizer="dadaptlion"),
                 dict(optimizer="adam", optimizer_args="weight_decay=0.01"), dict(optimizer_args="amsgrad=True"),
                 dict(precision="float32"), dict(precision="fp16"), dict(noise_scheduler="euler_a"),
                 dict(lr_scheduler="linear")):

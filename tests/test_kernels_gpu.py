@@ -499,6 +499,35 @@ def test_adamw_bit_exact(dev):
     assert mism == 0, "AdamW not bit-exact"
 
 
+def test_lion_bit_exact(dev):
+    """slh_lion against the oracle's restatement of lion_pytorch 0.1.2, five steps with weight decay, including exact-zero
+    updates (sign(0) = 0).  The oracle's tensor ops run ON THE GPU here: the reference trains on cuda, where
+    `add(t, alpha=a)` keeps `a` in fp32 opmath; torch's CPU kernel rounds `a` to the tensor dtype (bf16) first, which
+    moves ~18 % of the moments by one ulp - the kernel restates the device semantics."""
+    from oracle.optim_oracle import Lion
+    torch.manual_seed(15)
+    n = 10007
+    p0 = bf(torch.randn(n) * 0.05)
+    param = torch.nn.Parameter(p0.clone().to(dev))
+    opt = Lion([param], lr=1e-4, betas=(0.9, 0.99), weight_decay=0.05)
+    dp = p0.clone().to(dev)
+    m = torch.zeros(n, device=dev, dtype=torch.bfloat16)
+    for step in range(1, 6):
+        g = torch.randn(n) * 1e-3
+        g[:17] = 0.0
+        param.grad = bf(g).to(dev)
+        opt.step()
+        gd = bf(g).float().to(dev)
+        d = lib.LionDesc(param=p(dp), exp_avg=p(m), grad=p(gd), n=n, lr=1e-4, beta1=0.9, beta2=0.99, weight_decay=0.05,
+                         grad_scale=1.0)
+        lib.call(lib.OP_LION, d, stream())
+        torch.cuda.synchronize()
+        mism = (dp.view(torch.int16) != param.data.view(torch.int16)).sum().item()
+        mm = (m.view(torch.int16) != opt.state[id(param)]["exp_avg"].view(torch.int16)).sum().item()
+        print(f"[parity] lion step {step}: {mism}/{n} params, {mm}/{n} moments differ from the oracle (bf16 torch ops on the GPU)")
+        assert mism == 0 and mm == 0, "Lion not bit-exact"
+
+
 def test_lora_wgrad(dev):
     torch.manual_seed(14)
     M, C, R = 1500, 320, 4

@@ -79,7 +79,7 @@ def test_single_file_checkpoint_to_engine_state_dict(tmp_path):
 
 
 def test_model_util_detects_single_file_layout(tmp_path, monkeypatch):
-    """load_unet_state on a file path: SDXL is recognised by its label_emb MLP, SD-2.x style files are refused."""
+    """load_unet_state on a file path: SDXL is recognised by its label_emb MLP, SD-2.x by its 2-D proj_in weight."""
     from safetensors.torch import save_file
     from sliders_amd import model_util
     cfg = CONFIGS["tiny_sdxl"]()
@@ -89,7 +89,10 @@ def test_model_util_detects_single_file_layout(tmp_path, monkeypatch):
     save_file({LDM_PREFIX + diffusers_to_ldm_key(k, cfg): v for k, v in sd.items()}, str(path))
     got_cfg, got = model_util.load_unet_state(str(path))
     assert got_cfg == cfg and got.keys() == sd.keys()
+    cfg2 = CONFIGS["tiny_sd2"]()
+    monkeypatch.setitem(model_util.CONFIGS, "sd2", CONFIGS["tiny_sd2"])
+    sd2 = {k: v.contiguous() for k, v in build_unet("tiny_sd2", seed=3).state_dict().items()}
     v2 = tmp_path / "v2.safetensors"
-    save_file({LDM_PREFIX + "input_blocks.1.1.proj_in.weight": torch.zeros(8, 8)}, str(v2))
-    with pytest.raises(NotImplementedError):
-        model_util.load_unet_state(str(v2))
+    save_file({LDM_PREFIX + diffusers_to_ldm_key(k, cfg2): v for k, v in sd2.items()}, str(v2))
+    got_cfg, got = model_util.load_unet_state(str(v2))
+    assert got_cfg == cfg2 and got.keys() == sd2.keys() and all(torch.equal(got[k], sd2[k]) for k in sd2)

@@ -197,6 +197,24 @@ def test_lora_init_follows_reference_rng_order(name, method):
         assert sd[m.lora_name + ".lora_up.weight"].abs().max() == 0
 
 
+def test_lion_oracle_follows_the_published_algorithm():
+    """oracle/optim_oracle.Lion (restating lion_pytorch 0.1.2, requirements.txt:5) against a float64 evaluation of Alg. 1 of
+    the Lion paper: c = b1 m + (1-b1) g; theta <- theta (1 - lr wd) - lr sign(c); m <- b2 m + (1-b2) g."""
+    from oracle.optim_oracle import Lion
+    g_ = torch.Generator().manual_seed(21)
+    p = torch.nn.Parameter(torch.randn(4096, generator=g_, dtype=torch.float64))
+    opt = Lion([p], lr=1e-3, betas=(0.9, 0.99), weight_decay=0.1)
+    th, m = p.detach().clone(), torch.zeros(4096, dtype=torch.float64)
+    for _ in range(5):
+        g = torch.randn(4096, generator=g_, dtype=torch.float64)
+        p.grad = g.clone()
+        opt.step()
+        th = th * (1 - 1e-3 * 0.1) - 1e-3 * torch.sign(0.9 * m + 0.1 * g)
+        m = 0.99 * m + 0.01 * g
+        assert torch.allclose(p.detach(), th, rtol=0, atol=1e-12)
+    assert torch.allclose(opt.state[id(p)]["exp_avg"], m, rtol=0, atol=1e-12)
+
+
 def test_vae_oracle_is_pinned_to_the_published_architecture():
     """The SD VAE (AutoencoderKL, block_out_channels (128,256,512,512), 2 layers per block, one 512-channel attention head
     in each mid block) has 83,653,863 parameters - the figure published for sd-vae / the SDXL VAE - and its encoder half
