@@ -1,0 +1,34 @@
+"""profiles/rNN_pmc_traffic.json from the two PMC summaries of scripts/measure_round2.sh (scripts/pmc_summary.py CSVs):
+per kernel, fabric-side bytes per launch.  FETCH_SIZE is doubled (gfx950 tallies 128-B read requests at 64 B,
+MI355X_MICROARCH.md section HBM), WRITE_SIZE is taken as reported (uncalibrated); both counters are in KB.
+usage: make_pmc_traffic.py fetch_summary.csv write_summary.csv out.json"""
+import csv
+import json
+import sys
+
+
+def rows(path):
+    with open(path) as f:
+        lines = [l for l in f if "," in l]
+    return list(csv.DictReader(lines))
+
+
+fetch, write, out = sys.argv[1:4]
+kern = {}
+for r in rows(fetch):
+    n = max(int(r["dispatches"]), 1)
+    kern[r["kernel"]] = {"launches": n, "fetch_bytes_per_launch": int(2 * 1024 * float(r["FETCH_SIZE"]) / n)}
+for r in rows(write):
+    n = max(int(r["dispatches"]), 1)
+    k = kern.setdefault(r["kernel"], {"launches": n})
+    k["write_bytes_per_launch"] = int(1024 * float(r["WRITE_SIZE"]) / n)
+    hit, miss = float(r["TCC_HIT_sum"]), float(r["TCC_MISS_sum"])
+    k["l2_hit_rate"] = round(hit / (hit + miss), 3) if hit + miss > 0 else None
+res = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum (separate passes, --kernel-trace only) over "
+                 "LoRA-on SDXL 1024x1024 B=2 UNet passes (scripts/bench_forward.py --lora --warm 0 --iters 1: the first call "
+                 "plus one replay); FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports 64 B per 128-B request); "
+                 "WRITE_SIZE uncalibrated; KB -> bytes",
+       "kernels": {k: v for k, v in kern.items() if "fetch_bytes_per_launch" in v and "write_bytes_per_launch" in v}}
+with open(out, "w") as f:
+    json.dump(res, f, indent=1)
+print(f"{len(res['kernels'])} kernels -> {out}")

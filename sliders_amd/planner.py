@@ -115,6 +115,18 @@ class UNetPlan:
             head.memset(p, n, 0, "zero_stats")
         head.extend(self.prog)
         self.prog = head
+        # The text K/V of every cross-attention block depend only on the prompt embeddings (and frozen weights): inside a
+        # denoise loop (train_util.py:263-294: same embeddings for every timestep) steps 2.. replay the pass without
+        # the batched K/V projection and its head transpose.  Valid only while no other plan ran in between (plans
+        # share the arena) and io["ctx"] is unchanged - the caller's responsibility (trainer / sampler loops).
+        self.prog_text_cached = None
+        if self.kv_all is not None:
+            skip = {"attn2_kv_all", "attn2_vt_all"}
+            pc = lib.Program()
+            for (op, d), nm in zip(self.prog.ops, self.prog.op_names):
+                if nm not in skip:
+                    pc.add(op, d, nm)
+            self.prog_text_cached = pc
 
     # ------------------------------------------------------------------------------------------------
     # buffers

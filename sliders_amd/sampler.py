@@ -60,11 +60,11 @@ class SliderSampler:
         s = torch.cuda.current_stream().cuda_stream
         chw = eng.cfg.out_channels * h * w
         half = bs * chw * 2
-        for t in self.sched.make_timesteps(ddim_steps):
+        for i, t in enumerate(self.sched.make_timesteps(ddim_steps)):
             if self.store is not None:
                 eng.set_lora(True, 0.0 if t > start_noise else float(scale))
             io["t"].tensor.fill_(float(t))
-            p.prog.run(s)
+            (p.prog if (i == 0 or p.prog_text_cached is None) else p.prog_text_cached).run(s)
             d = lib.CfgDdimDesc(eps=io["eps"].ptr, x=smp.ptr, out=smp.ptr, out2=smp.ptr + half, nb=bs, chw=chw,
                                 guidance=float(guidance_scale), **self.sched.step_fields(t, ddim_steps))
             lib.call(lib.OP_CFG_DDIM, d, s)

@@ -182,7 +182,8 @@ class SliderTrainer:
         for i in range(k):
             t = self.t50[i]
             p_on.io["t"].tensor.fill_(float(t))
-            p_on.prog.run(s)
+            # the prompt embeddings do not change inside the loop: after the first step the text K/V are already there
+            (p_on.prog if (i == 0 or p_on.prog_text_cached is None) else p_on.prog_text_cached).run(s)
             self.unet_passes += 1
             self._cfg(p_on, smp.ptr, self.denoise_guidance, self.sched.step_fields(t, self.nsteps),
                       out2=smp.ptr + half, x=smp.ptr)
