@@ -74,6 +74,8 @@ __global__ __launch_bounds__(128 * WM, gemm_waves_per_simd(MI, NI, STAGES, LORA,
     // operand tile; every wave multiplies it with the X fragments it already holds, so T = X.A^T of the block's own
     // rows is available in registers for the epilogue without a separate pass over X (lora.py:108-112 fused).
     constexpr int LROWS = LORA ? 32 : 0;
+    static_assert(!LORA || 2 * WM * (2048 * NI + 2048 * MI) <= STAGES * (32 * MI * WM + 64 * NI + 32) * 128,
+                  "epilogue patches + adapter exchange must fit the operand stages");
     __shared__ __attribute__((aligned(16))) char smem[STAGES * (BM + BN + LROWS) * 128];
     char* sX = smem;                        // [STAGES][BM][128 B]
     char* sW = smem + STAGES * BM * 128;    // [STAGES][BN][128 B]
@@ -226,7 +228,7 @@ __global__ __launch_bounds__(128 * WM, gemm_waves_per_simd(MI, NI, STAGES, LORA,
         const char* cL = sL + buf * (32 * 128);
         bf16x8 xf[2][MI], wf[2][NI], lf[2];
         auto load_frags = [&](int set, int ks) {
-            if (LORA) lf[set] = *(const bf16x8*)(cL + lds_off(lrow, ks * 2 + lhi));
+            if (LORA && (ks & 1) == wn) lf[set] = *(const bf16x8*)(cL + lds_off(lrow, ks * 2 + lhi));
 #pragma unroll
             for (int i = 0; i < MI; ++i)
                 xf[set][i] = *(const bf16x8*)(cX + lds_off(wm * (32 * MI) + i * 32 + lrow, ks * 2 + lhi));
@@ -243,7 +245,7 @@ __global__ __launch_bounds__(128 * WM, gemm_waves_per_simd(MI, NI, STAGES, LORA,
 #pragma unroll
                 for (int j = 0; j < NI; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks & 1][j], xf[ks & 1][i], acc[i][j], 0, 0, 0);
-            if (LORA) {
+            if (LORA && (ks & 1) == wn) {     // the two waves that share these rows split the adapter's K steps (see epilogue)
 #pragma unroll
                 for (int i = 0; i < MI; ++i)
                     accl[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lf[ks & 1], xf[ks & 1][i], accl[i], 0, 0, 0);
@@ -369,7 +371,7 @@ __global__ __launch_bounds__(128 * WM, gemm_waves_per_simd(MI, NI, STAGES, LORA,
 #endif
             const char* cX = sX + slot * (BM * 128);
             const char* cW = sW + slot * (BN * 128);
-            if (LORA) lf[set] = *(const bf16x8*)(sL + slot * (32 * 128) + lds_off(lrow, ks * 2 + lhi));
+            if (LORA && set == wn) lf[set] = *(const bf16x8*)(sL + slot * (32 * 128) + lds_off(lrow, ks * 2 + lhi));   // set == ks & 1
 #pragma unroll
             for (int i = 0; i < MI; ++i)
                 xf[set][i] = *(const bf16x8*)(cX + lds_off(wm * (32 * MI) + i * 32 + lrow, ks * 2 + lhi));
@@ -392,7 +394,7 @@ __global__ __launch_bounds__(128 * WM, gemm_waves_per_simd(MI, NI, STAGES, LORA,
                     else asm volatile("" ::"v"(lf[set]), "v"(xf[set][i]));
 #else
                     if (j < NI) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[set][j], xf[set][i], acc[i][j], 0, 0, 0);
-                    else accl[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lf[set], xf[set][i], accl[i], 0, 0, 0);
+                    else if (set == wn) accl[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lf[set], xf[set][i], accl[i], 0, 0, 0);
 #endif
                     if (with_pieces) {
                         __builtin_amdgcn_sched_barrier(0);
@@ -483,7 +485,7 @@ __global__ __launch_bounds__(128 * WM, gemm_waves_per_simd(MI, NI, STAGES, LORA,
 #pragma unroll
                     for (int e = 0; e < 4; ++e) unsafeAtomicAdd(p.c32 + (long)m * p.N + n + e, acc[i][j][q * 4 + e]);
                 }
-            if (LORA && tile_n == 0 && wn == 0) {
+            if (LORA && tile_n == 0) {         // both waves of a row pair: each holds the partial of its own k-steps
                 // rank index of accl[i][r]: (r&3) + 8*(r>>2) + 4*lhi  ->  ranks 0-3 / 8-11 in the lhi=0 half, 4-7 in lhi=1
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
@@ -536,6 +538,21 @@ __global__ __launch_bounds__(128 * WM, gemm_waves_per_simd(MI, NI, STAGES, LORA,
     constexpr int S = 4 * NI;                  // 16-byte slots per staged row
     constexpr int LOG2S = NI == 2 ? 3 : 2;
     __syncthreads();                           // every wave is done reading the operand stages being reused below
+    if (LORA) {
+        // T = x . A^T of a row block was accumulated half by each of the two waves that own those rows (wn = 0 took the
+        // even k-steps, wn = 1 the odd ones: the adapter costs half an MFMA per k-step and wave instead of one); the
+        // partials are exchanged through LDS behind the staging patches.  Only registers 0-7 of accl carry ranks < 12.
+        float* ex = (float*)(smem + NW * (32 * S * 16));
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int r = 0; r < 8; ++r) ex[(wave * MI * 8 + i * 8 + r) * 64 + lane] = accl[i][r];
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int r = 0; r < 8; ++r) accl[i][r] += ex[((wave ^ 1) * MI * 8 + i * 8 + r) * 64 + lane];
+    }
     char* sE = smem + wave * (32 * S * 16);
     const bool have_t = LORA || p.lora_t != nullptr;
     const float lscale = have_t ? *p.lora_scale : 0.f;
