@@ -554,9 +554,40 @@ __global__ __launch_bounds__(128 * WM, gemm_waves_per_simd(MI, NI, STAGES, LORA,
             for (int r = 0; r < 8; ++r) accl[i][r] += ex[((wave ^ 1) * MI * 8 + i * 8 + r) * 64 + lane];
     }
     char* sE = smem + wave * (32 * S * 16);
-    const bool have_t = LORA || p.lora_t != nullptr;
-    const float lscale = have_t ? *p.lora_scale : 0.f;
+    const float lscale = (LORA || p.lora_t != nullptr) ? *p.lora_scale : 0.f;
     const int ncol0 = n0 + wn * (32 * NI);
+    // Fused adapter, forward form (lora_up [N][4]): the up-projection  scale * T . B^T  is one more MFMA per accumulator
+    // tile.  T (ranks x rows, already in the accumulator layout of a B operand up to a fixed permutation of the rank
+    // index) is scaled and rounded to bf16 - the reference's down-projection output is a bf16 tensor too - and the A
+    // operand holds, for output column n of group g, B[n][0..3] at the k positions of ranks 4g..4g+3 and zeros elsewhere.
+    // k index of a lane: 8*lhi + e  <->  rank: lhi = 0: e < 4 -> e, e >= 4 -> 8 + (e - 4);  lhi = 1: e < 4 -> 4 + e, else unused
+    const bool mfma_up = LORA && !p.lora_up_rmajor;
+    if (mfma_up) {
+        bf16x8 ua[NI];
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            const int n = ncol0 + j * 32 + lrow;
+            bf16x4 u4 = {(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
+            int g = -1;
+            if (n < p.N) { u4 = *(const bf16x4*)(p.lora_up + (long)n * 4); g = n / p.lora_cols_per_group; }
+            const bool lo = lhi == 0 ? g == 0 : g == 1;        // e < 4: ranks 0-3 (lhi 0) / 4-7 (lhi 1)
+            const bool hi = lhi == 0 && g == 2;                // e >= 4: ranks 8-11 (lhi 0 only)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                ua[j][e] = lo ? u4[e] : (__bf16)0.f;
+                ua[j][4 + e] = hi ? u4[e] : (__bf16)0.f;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            bf16x8 tb;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) tb[e] = (__bf16)(lscale * accl[i][e]);
+#pragma unroll
+            for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ua[j], tb, acc[i][j], 0, 0, 0);
+        }
+    }
+    const bool have_t = (LORA || p.lora_t != nullptr) && !mfma_up;      // the per-element forms below
     // wave-uniform: this wave's columns belong to the V block that slh_attn_fwd wants head-transposed
     const bool to_vt = p.vt != nullptr && ncol0 >= p.vt_col0;
 #pragma unroll
@@ -567,7 +598,7 @@ __global__ __launch_bounds__(128 * WM, gemm_waves_per_simd(MI, NI, STAGES, LORA,
         f32x4 tv[3];
 #pragma unroll
         for (int g = 0; g < 3; ++g) tv[g] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (LORA) {
+        if (LORA && (have_t || p.lora_t_out)) {
             // ranks 0-3 sit in registers 0-3 of the lhi=0 half, 4-7 in registers 0-3 of the lhi=1 half, 8-11 in
             // registers 4-7 of the lhi=0 half: one exchange with lane^32 gives every lane all of its row's T
 #pragma unroll
@@ -583,7 +614,7 @@ __global__ __launch_bounds__(128 * WM, gemm_waves_per_simd(MI, NI, STAGES, LORA,
                 for (int g = 0; g < 3; ++g)
                     if (g * 4 < p.lora_rank) *(f32x4*)(p.lora_t_out + (long)m * p.ld_t + g * 4) = tv[g];
             }
-        } else if (p.lora_t && mok) {
+        } else if (!LORA && p.lora_t && mok) {
 #pragma unroll
             for (int g = 0; g < 3; ++g)
                 if (g * 4 < p.ld_t) tv[g] = *(const f32x4*)(p.lora_t + (long)m * p.ld_t + g * 4);

@@ -94,12 +94,13 @@ def test_iteration_matches_reference_loop_on_oracle(dev, name, action, pred):
     cos = F.cosine_similarity(store.grads.cpu(), flat, dim=0).item()
     print(f"[parity] iteration: denoised rel_l2={r_den:.3e} target-eps rel_l2={r_tgt:.3e} loss {loss.item():.5e} vs "
           f"{ref_loss.item():.5e} grad cosine {cos:.5f} |g| {store.grads.norm().item():.3e} vs {flat.norm().item():.3e}")
-    # 1.3 x the worst values measured on MI355X over both cases and several runs (denoised 6.5e-3, target 1.31e-2,
-    # loss within 3.3 %, gradient cosine 0.9857-0.9959; the run-to-run floor of the engine itself is cosine 0.993)
+    # 1.3 x the worst values measured on MI355X over the cases and several runs (denoised 6.5e-3, target 1.31e-2,
+    # loss within 4.8 %, gradient cosine 0.9857-0.9959; the run-to-run floor of the engine itself is cosine 0.993 and the
+    # loss, a difference of four predictions, moves by 1-3 % between two runs of the same inputs)
     assert r_den < 8.5e-3 and r_tgt < 1.7e-2
     # (the SD-2.x-like net measured 6.2 %: its predictions sit at rel-L2 1.2-1.5e-2 like its torch-bf16 arm, and the loss is a
     # difference of four of them)
-    assert abs(loss.item() - ref_loss.item()) < (0.08 if name == "tiny_sd2" else 0.045) * ref_loss.item()
+    assert abs(loss.item() - ref_loss.item()) < (0.08 if name == "tiny_sd2" else 0.063) * ref_loss.item()
     assert cos > 0.98
     # AdamW moved every trainable parameter by about lr (first step: |update| ~ lr)
     delta = (store.params.float() - params0.float()).abs()
