@@ -17,6 +17,7 @@ ap.add_argument("--shapes", default="2048x1280x1280,2048x1280x5120,2048x3840x128
 ap.add_argument("--tiles", default="11,22,4012,422,4412,4322,322,412,421")
 ap.add_argument("--reps", type=int, default=40)
 ap.add_argument("--lora", type=int, default=0)
+ap.add_argument("--res", type=int, default=0, help="1: with bias and residual (timing of the epilogue's operand loads)")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 stream = torch.cuda.current_stream()
@@ -35,12 +36,18 @@ for shp in a.shapes.split(","):
     scale = torch.tensor([0.25], device=dev)
     if a.lora:
         ref = ref + 0.25 * (x.float() @ A.float().t()) @ up.float().t()
+    bias = torch.randn(N, device=dev).bfloat16()
+    resid = torch.randn(M, N, device=dev).bfloat16()
+    if a.res:
+        ref = ref + bias.float() + resid.float()
     fl = 2.0 * M * N * K
     out = []
     for tile in (int(t, 16) for t in a.tiles.split(",")):
         def desc(wp):
             d = lib.GemmDesc(a0=x.data_ptr(), w=wp.data_ptr(), c=c.data_ptr(), lda0=K, ca0=K, mode=0, stride=1, ldw=0,
                              M=M, N=N, K=K, ldc=N, rows_per_sample=M, tile=tile, w_layout=1)
+            if a.res:
+                d.bias, d.residual, d.ld_res = bias.data_ptr(), resid.data_ptr(), N
             if a.lora:
                 d.lora_down, d.lora_up, d.lora_scale = A.data_ptr(), up.data_ptr(), scale.data_ptr()
                 d.ld_t, d.lora_groups, d.lora_rank = 4, 1, 4
