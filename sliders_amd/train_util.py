@@ -132,9 +132,12 @@ def get_add_time_ids(height: int, width: int, dynamic_crops: bool = False, dtype
 
 def get_optimizer(name: str):
     name = name.lower()
-    if name.startswith("dadapt") or name.endswith("8bit") or name in ("lion", "prodigy"):
+    if name == "lion":
+        from .optim import Lion        # lion_pytorch.Lion's interface over the fused slh_lion kernel
+        return Lion
+    if name.startswith("dadapt") or name.endswith("8bit") or name == "prodigy":
         raise ValueError(f"optimizer {name} needs a package that is not installed in this image "
-                         f"(bitsandbytes / dadaptation / lion-pytorch / prodigyopt)")
+                         f"(bitsandbytes / dadaptation / prodigyopt)")
     if name == "adam":
         return torch.optim.Adam
     if name == "adamw":

@@ -528,6 +528,31 @@ def test_lion_bit_exact(dev):
         assert mism == 0 and mm == 0, "Lion not bit-exact"
 
 
+def test_lion_optimizer_class_matches_oracle(dev):
+    """train_util.get_optimizer("lion") (train_util.py:365-368) hands the reference-shaped loop a torch.optim.Optimizer
+    whose step is slh_lion: bit-equal to the oracle class on device tensors, two parameter tensors, three steps."""
+    from oracle.optim_oracle import Lion as OracleLion
+    from sliders_amd.train_util import get_optimizer
+    torch.manual_seed(16)
+    shapes = [(4, 320), (1280, 4)]
+    ps = [torch.nn.Parameter(bf(torch.randn(*sh) * 0.05).to(dev)) for sh in shapes]
+    qs = [torch.nn.Parameter(p_.detach().clone()) for p_ in ps]
+    opt = get_optimizer("lion")(ps, lr=2e-4, weight_decay=0.01)
+    ref = OracleLion(qs, lr=2e-4, betas=(0.9, 0.99), weight_decay=0.01)
+    for _ in range(3):
+        for p_, q_ in zip(ps, qs):
+            g = bf(torch.randn(*p_.shape) * 1e-3).to(dev)
+            p_.grad, q_.grad = g, g.clone()
+        opt.step(); ref.step()
+    torch.cuda.synchronize()
+    for p_, q_ in zip(ps, qs):
+        assert torch.equal(p_.detach().view(torch.int16), q_.detach().view(torch.int16))
+    cpu = torch.nn.Parameter(torch.zeros(4, dtype=torch.bfloat16))
+    cpu.grad = torch.zeros(4, dtype=torch.bfloat16)
+    with pytest.raises(RuntimeError):
+        get_optimizer("lion")([cpu]).step()                  # no CPU fallback
+
+
 def test_lora_wgrad(dev):
     torch.manual_seed(14)
     M, C, R = 1500, 320, 4
