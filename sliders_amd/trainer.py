@@ -22,6 +22,8 @@ import ctypes as C
 from dataclasses import dataclass
 from typing import Optional
 
+import os
+
 import torch
 
 from . import lib
@@ -88,6 +90,10 @@ class SliderTrainer:
         self.t1000 = self.sched.make_timesteps(1000)
         self.unet_passes = 0
         self.dedup_frozen = dedup_frozen
+        # the three frozen predictions and the training forward only share their input (the denoised latents): they run
+        # on two streams (SLIDERS_OVERLAP_FROZEN=0 serialises them again)
+        self.overlap_frozen = os.environ.get("SLIDERS_OVERLAP_FROZEN", "1") != "0"
+        self._side = torch.cuda.Stream(device=engine.device) if self.overlap_frozen else None
         self._states = {}
         self._use(batch_size, H, W)
 
@@ -190,18 +196,36 @@ class SliderTrainer:
         self.denoised.copy_(smp.tensor[:bs])
         t_cur = self.t1000[int(k * 1000 / self.nsteps)]
         # 2. frozen-model predictions, adapters off (train_lora_xl.py:236-295)
+        def frozen():
+            if self.dedup_frozen:
+                self._frozen_dedup(pair, t_cur)
+            else:
+                p_off = eng.plan(B, self.H, self.W, "off")
+                self._predict(p_off, self.denoised, pair.ctx_positive, pair.pooled_positive, t_cur, self.e_pos)
+                self._predict(p_off, self.denoised, pair.ctx_neutral, pair.pooled_neutral, t_cur, self.e_neu)
+                self._predict(p_off, self.denoised, pair.ctx_uncond, pair.pooled_uncond, t_cur, self.e_unc)
+
         eng.set_lora(False)
-        if self.dedup_frozen:
-            self._frozen_dedup(pair, t_cur)
+        frozen_done = None
+        if self.overlap_frozen:
+            # adapter-free plans have their own arena and launch no adapter work (they never read the scale the main
+            # stream is about to switch back on), so they can run beside step 3
+            eng.plan(3 * bs if self.dedup_frozen else B, self.H, self.W, "off")      # built (and arenas sized) on the main stream
+            eng.plan(B, self.H, self.W, "train")
+            main = torch.cuda.current_stream()
+            self._side.wait_stream(main)
+            with torch.cuda.stream(self._side):
+                frozen()
+                frozen_done = torch.cuda.Event()
+                frozen_done.record(self._side)
         else:
-            p_off = eng.plan(B, self.H, self.W, "off")
-            self._predict(p_off, self.denoised, pair.ctx_positive, pair.pooled_positive, t_cur, self.e_pos)
-            self._predict(p_off, self.denoised, pair.ctx_neutral, pair.pooled_neutral, t_cur, self.e_neu)
-            self._predict(p_off, self.denoised, pair.ctx_uncond, pair.pooled_uncond, t_cur, self.e_unc)
+            frozen()
         # 3. target prediction with the adapters on, kept for backward (train_lora_xl.py:302-322)
         eng.set_lora(True, 1.0)
         p_tr = eng.plan(B, self.H, self.W, "train")
         self._predict(p_tr, self.denoised, pair.ctx_target, pair.pooled_target, t_cur, self.e_tgt)
+        if frozen_done is not None:
+            torch.cuda.current_stream().wait_event(frozen_done)
         # 4. loss + its gradient, written straight into the backward plan's input (prompt_util.py:108-148)
         self.loss.zero_()
         bw = p_tr.backward

@@ -54,6 +54,7 @@ class UNetEngine:
         self._plans: Dict[Tuple, UNetPlan] = {}
         self._arena_bytes = arena_bytes
         self.arena: Optional[Arena] = None
+        self.arena_off: Optional[Arena] = None     # adapter-free plans live apart: the trainer runs its frozen pass on a second stream
         self.zarena = Arena(2048 << 20, self.device, "zero-init accumulators")   # GroupNorm statistics, loss, split-K partial sums
         self.train_plan: Optional[UNetPlan] = None
         self.one = torch.ones(1, dtype=torch.float32, device=self.device)
@@ -101,16 +102,21 @@ class UNetEngine:
             return 0, B
         return B // 2, B // 2
 
-    def _ensure_arena(self, need: int):
-        if self.arena is not None and self.arena.capacity >= need:
+    def _ensure_arena(self, need: int, off: bool = False):
+        cur = self.arena_off if off else self.arena
+        if cur is not None and cur.capacity >= need:
             return
-        # grow: every cached plan holds raw pointers into the old arena, so they are rebuilt lazily
-        self._plans.clear()
-        self.train_plan = None
-        self.arena = None
+        # grow: every cached plan of that arena holds raw pointers into the old one, so they are rebuilt lazily
+        self._plans = {k: v for k, v in self._plans.items() if (k[3] == "off") != off}
+        if not off:
+            self.train_plan = None
         torch.cuda.synchronize()
-        cap = max(need, self._arena_bytes or 0)
-        self.arena = Arena(cap + (1 << 20), self.device, "activations")
+        if off:
+            self.arena_off = None
+            self.arena_off = Arena(need + (1 << 20), self.device, "activations (adapter-free plans)")
+        else:
+            self.arena = None
+            self.arena = Arena(max(need, self._arena_bytes or 0) + (1 << 20), self.device, "activations")
 
     def plan(self, B: int, H: int, W: int, mode: str) -> UNetPlan:
         key = (B, H, W, mode)
@@ -121,17 +127,20 @@ class UNetEngine:
         # of the same shape (so 'on' -> 'train' does not trigger a regrow that invalidates cached plans)
         modes = {mode} | ({"train"} if (self.lora is not None and mode != "off") else set())
         need = max(self._virtual_size(B, H, W, m) for m in modes)
-        self._ensure_arena(need)
+        off = mode == "off"
+        self._ensure_arena(need, off)
         if mode == "train":
             self.weights.ensure_dgrad()
-        # all plans share the activation arena from offset 0: they never run concurrently
-        self.arena.reset(0)
-        p = UNetPlan(self.cfg, self.weights, self.arena, self.zarena, B, H, W, self.ctx_len,
+        # the plans of one arena share it from offset 0 (they never run concurrently); adapter-free plans have their own
+        # arena so that the frozen predictions of an iteration can overlap the training forward on a second stream
+        arena = self.arena_off if off else self.arena
+        arena.reset(0)
+        p = UNetPlan(self.cfg, self.weights, arena, self.zarena, B, H, W, self.ctx_len,
                      self.lora if mode != "off" else None, mode, self.lora_scale.data_ptr())
         if mode == "train":
             b0, nb = self._grad_samples(B)
             p.backward = BackwardPlan(p, b0, nb, self.one.data_ptr())
-        p.arena_end = self.arena.mark()
+        p.arena_end = arena.mark()
         self._plans[key] = p
         return p
 
