@@ -118,6 +118,35 @@ def test_planner_static_invariants(name, hw, method):
         assert counts["off"] < 1300     # one launch per fused op: ~1.15k for the whole SDXL UNet
 
 
+@pytest.mark.parametrize("name,hw", [("sdxl", 128), ("sd2", 64), ("sd1", 64)])
+def test_planner_fusions_of_the_no_grad_pass(name, hw):
+    """Launch-count invariants of the adapters-on no-grad pass (the one the denoise loop replays): with 64-wide heads
+    (SDXL, SD-2.x) every self-attention reads the V third of its fused q|k|v projection head-transposed straight from that
+    GEMM's epilogue (vt_out) - no transpose launch per block; SD-1.x (40/80/160-wide heads, zero-padded d-tiles) keeps the
+    transpose kernel.  With the batched text K/V path the plan also carries the program the loop replays from step 2 on."""
+    from sliders_amd.weights import WeightStore   # noqa: F401  (kv_all path needs the real offsets only on the GPU plan)
+    cfg = CONFIGS[name]()
+    store = LoraStore(cfg, train_method="noxattn", init="none")
+    store.temb_tcol = torch.zeros(1, dtype=torch.int32)
+    va, vz = Arena(1 << 50, None), Arena(1 << 40, None)
+    p = UNetPlan(cfg, _FakeWeights(cfg), va, vz, 2, hw, hw, 77, store, "on", 0x10)
+    ops = p.prog.ops
+    n_self = sum(1 for n in p.prog.op_names if n.endswith("attn1.sdpa"))
+    n_tr = sum(1 for o, _ in ops if o == lib.OP_TRANSPOSE_HEADS)
+    n_vt = sum(1 for o, d in ops if o == lib.OP_GEMM and d.vt_out)
+    assert n_self > 0
+    if name in ("sdxl", "sd2"):
+        assert n_vt == n_self and all(d.vt_D == 64 and d.vt_col0 == 2 * d.N // 3 for o, d in ops if o == lib.OP_GEMM and d.vt_out)
+        assert n_tr <= n_self          # what is left are the cross-attention V transposes (one per block here: fake weights have no batched K/V)
+    else:
+        assert n_vt == 0 and n_tr >= n_self
+    # train-mode plans keep V row-major for the attention backward
+    pt = UNetPlan(cfg, _FakeWeights(cfg), Arena(1 << 50, None), Arena(1 << 40, None), 2, hw, hw, 77, store, "train", 0x10)
+    assert not any(d.vt_out for o, d in pt.prog.ops if o == lib.OP_GEMM)
+    if p.prog_text_cached is not None:
+        assert p.prog_text_cached.n_ops == p.prog.n_ops - 2
+
+
 def test_checkpoint_file_is_reference_loadable(tmp_path):
     """save_weights writes a torch .pt OrderedDict with the reference's keys; it strict-loads into the oracle
     restatement of the reference's LoRANetwork (the notebooks' `network.load_state_dict(torch.load(path))`)."""
