@@ -387,7 +387,11 @@ typedef struct slh_sgemm_desc {
     int32_t bias_per_row;
     float alpha;            /* C = alpha * (X W^T) + bias + residual */
     int32_t upsample;       /* conv: 1 = the source is read through a nearest-2x upsample (Upsample2D), ho = 2*hs */
-    int32_t pad2_;
+    int32_t split_bf16;     /* 0: exact fp32 products (v_mfma_f32_32x32x2_f32).  1: every operand split into two bf16 halves,
+                               x.w ~= hi.hi + hi.lo + lo.hi on the bf16 matrix pipe with fp32 accumulation (16 mantissa bits per
+                               operand, ~5x fewer matrix cycles); needs K % 32 == 0 (and Cin % 32 == 0), else exact.  Bits 1-3 are
+                               profiling ablations (scripts/probe_sgemm.py): 2 skip the LDS staging, 4 skip the MFMAs, 8 skip the
+                               global loads after the prologue */
 } slh_sgemm_desc;
 int slh_sgemm(const slh_sgemm_desc* d, slh_stream_t stream);
 

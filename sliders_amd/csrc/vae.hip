@@ -16,6 +16,7 @@
 // The encoder runs twice per image-slider iteration (~1.1 TFLOP per 512x512 image): far from the hot loop's cost,
 // so these kernels are written for exact fp32 arithmetic first and MFMA-bound simplicity second.
 #include "common.h"
+#include <type_traits>
 #include "../../include/sliders_hip.h"
 
 namespace {
@@ -128,6 +129,206 @@ __global__ __launch_bounds__(256) void sgemm_kernel(const slh_sgemm_desc d) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int m = m0 + wm * 64 + i * 32 + lrow;
+        if (m >= d.M) continue;
+        const float rowb = (bias && d.bias_per_row) ? bias[m] : 0.f;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int n = n0 + wn * 64 + j * 32 + q * 8 + lhi * 4;
+                if (n >= d.N) continue;
+                f4 v = {acc[i][j][q * 4], acc[i][j][q * 4 + 1], acc[i][j][q * 4 + 2], acc[i][j][q * 4 + 3]};
+                v *= d.alpha;
+                if (bias) {
+                    if (d.bias_per_row) v += rowb;
+                    else v += *(const f4*)(bias + n);
+                }
+                if (res) v += *(const f4*)(res + (long)m * d.ldr + n);
+                *(f4*)(C + (long)m * d.ldc + n) = v;
+            }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// The same product with every fp32 operand split into two bf16 halves, x = hi + lo (hi = bf16(x), lo = bf16(x - hi), 16
+// mantissa bits kept), and  x.w ~= hi.hi + hi.lo + lo.hi  on the bf16 matrix pipe with fp32 accumulation: three
+// v_mfma_f32_32x32x16_bf16 (32 cycles each) replace eight v_mfma_f32_32x32x2_f32 (64 cycles each) per 16 k - 5.3x fewer
+// matrix cycles at a relative product error of ~2^-16.  (The reference's fp32 VAE convolutions run in TF32 - 10 mantissa
+// bits - on its own hardware: torch.backends.cudnn.allow_tf32 defaults to True.)  slh_sgemm_desc.split_bf16 selects it.
+// Tile 128 x 128 x 32; LDS holds four [128 rows][32 bf16] images (X hi/lo, W hi/lo), 64-byte rows whose 16-byte slot s is
+// stored at s ^ f(row), f(row) = ((row >> 1) ^ (row >> 4)) & 3: conflict-free for the ds_write_b128 of the staging pass
+// (8 consecutive rows per cycle) and for the ds_read_b128 lane groups of the fragment reads.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int TBK = 32;
+
+__device__ __forceinline__ int split_slot(int row, int slot) { return slot ^ (((row >> 1) ^ (row >> 4)) & 3); }
+
+// TM = 128 (4 waves as 2 x 2, 64 x 64 per wave) or 64 (32 x 64 per wave: twice the workgroups for the 64 x 64-pixel layers,
+// M = 4096, that would leave half the chip idle).  The LDS images are double-buffered: the global loads of step k+1 are
+// requested before the MFMAs of step k and split / stored into the other buffer after them - one barrier per step.
+template <int TM>
+__global__ __launch_bounds__(256, 2) void sgemm_bf16x3_kernel(const slh_sgemm_desc d) {
+    constexpr int MI = TM / 64;                                  // 32-row blocks per wave along M
+    constexpr int XIMG = TM * 64, WIMG = SBN * 64;               // bytes of one bf16 image
+    constexpr int BUF = 2 * XIMG + 2 * WIMG;
+    __shared__ __attribute__((aligned(16))) char smem[2 * BUF];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int tiles_n = (d.N + SBN - 1) / SBN;
+    const int tile_m = blockIdx.x / tiles_n, tile_n = blockIdx.x - tile_m * tiles_n;
+    const int m0 = tile_m * TM, n0 = tile_n * SBN;
+    // loader geometry: 8 consecutive lanes read the 128 contiguous bytes (32 floats) one tile row contributes to a K step,
+    // so a load instruction touches 8 cache lines (a lane-per-row mapping touches 64 and is bound by the address pipe);
+    // a thread handles k quad k4 of rows r8 + 32*e
+    constexpr int XE = TM / 32;                                  // rows per thread: X
+    const int r8 = tid >> 3, k4 = tid & 7;
+    const float* X = (const float*)d.x;
+    const float* W = (const float*)d.w;
+    const int cin = d.cin;
+    bool xok[XE];
+    long xoff[XE];                                               // dense: element offset of the row
+    int xb[XE], xoy[XE], xox[XE];                                // conv: sample / output pixel of the row
+#pragma unroll
+    for (int e = 0; e < XE; ++e) {
+        int xm = m0 + r8 + 32 * e;
+        xok[e] = xm < d.M;
+        xm = xok[e] ? xm : d.M - 1;
+        xoff[e] = (long)xm * d.ldx;
+        xb[e] = xoy[e] = xox[e] = 0;
+        if (d.mode == 1) {
+            const int hw = d.ho * d.wo;
+            xb[e] = xm / hw;
+            const int rem = xm - xb[e] * hw;
+            xoy[e] = rem / d.wo;
+            xox[e] = rem - xoy[e] * d.wo;
+        }
+    }
+    bool wok[4];
+    long woff[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        int wnr = n0 + r8 + 32 * e;
+        wok[e] = wnr < d.N;
+        woff[e] = (long)(wok[e] ? wnr : d.N - 1) * d.ldw;
+    }
+    auto load_x = [&](int k0, f4* v) {
+        const f4 z = {0.f, 0.f, 0.f, 0.f};
+        if (d.mode == 0) {
+#pragma unroll
+            for (int e = 0; e < XE; ++e) v[e] = xok[e] ? *(const f4*)(X + xoff[e] + k0 + 4 * k4) : z;
+        } else {
+            const int tap = k0 / cin, c0 = k0 - tap * cin;
+            const int ky = tap / 3, kx = tap - ky * 3;
+            const int sh = d.upsample ? 1 : 0;
+#pragma unroll
+            for (int e = 0; e < XE; ++e) {
+                const int iy = xoy[e] * d.stride + ky - d.pad, ix = xox[e] * d.stride + kx - d.pad;
+                const bool ok = xok[e] && iy >= 0 && iy < (d.hs << sh) && ix >= 0 && ix < (d.ws << sh);
+                v[e] = ok ? *(const f4*)(X + (((long)xb[e] * d.hs + (iy >> sh)) * d.ws + (ix >> sh)) * d.ldx + c0 + 4 * k4) : z;
+            }
+        }
+    };
+    auto load_w = [&](int k0, f4* v) {
+        const f4 z = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = wok[e] ? *(const f4*)(W + woff[e] + k0 + 4 * k4) : z;
+    };
+    // 4 floats -> 8 bytes of bf16 high parts and 8 bytes of bf16 remainders (half k4 & 1 of 16-byte slot k4 >> 1)
+    auto split_store4 = [&](const f4& a, char* hi_img, char* lo_img, int row) {
+        bf16x4 hi, lo;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const __bf16 xh = (__bf16)a[e];
+            hi[e] = xh;
+            lo[e] = (__bf16)(a[e] - (float)xh);
+        }
+        const int off = row * 64 + (split_slot(row, k4 >> 1) << 4) + ((k4 & 1) << 3);
+        *(bf16x4*)(hi_img + off) = hi;
+        *(bf16x4*)(lo_img + off) = lo;
+    };
+    f32x16 acc[MI][2];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    // Global loads run THREE K steps ahead of the MFMAs in three rotating register sets (a single step of MFMAs is ~0.3 us,
+    // a first-touch load from HBM / the other XCDs' writes ~2 us; with one step of prefetch the loop ran at the memory
+    // latency, 200 TF/s).  Invariant at the start of step k: set k % 3 is free (step k is in LDS), sets (k+1) % 3 and
+    // (k+2) % 3 hold steps k+1, k+2 in flight.
+    f4 xs[3][XE], ws[3][4];
+    auto store_stage = [&](auto set_c, int buf) {
+        constexpr int SET = decltype(set_c)::value;
+        char* base = smem + buf * BUF;
+#pragma unroll
+        for (int e = 0; e < XE; ++e) split_store4(xs[SET][e], base, base + XIMG, r8 + 32 * e);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) split_store4(ws[SET][e], base + 2 * XIMG, base + 2 * XIMG + WIMG, r8 + 32 * e);
+    };
+    const int lrow = lane & 31, lhi = lane >> 5;
+    const int nk = d.K / TBK;
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>;
+    load_x(0, xs[0]);
+    load_w(0, ws[0]);
+    if (nk > 1) { load_x(TBK, xs[1]); load_w(TBK, ws[1]); }
+    if (nk > 2) { load_x(2 * TBK, xs[2]); load_w(2 * TBK, ws[2]); }
+    store_stage(I0{}, 0);
+    __syncthreads();
+    int cur = 0;
+    auto step = [&](auto set_c, auto next_c, const int k) {
+        constexpr int SET = decltype(set_c)::value;
+        if (k + 3 < nk && !(d.split_bf16 & 8)) {   // into the set step k just vacated
+            load_x((k + 3) * TBK, xs[SET]);
+            load_w((k + 3) * TBK, ws[SET]);
+        }
+        const char* base = smem + cur * BUF;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 xh[MI], xl[MI], wh[2], wl[2];
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                const int row = wm * (32 * MI) + i * 32 + lrow;
+                const int off = row * 64 + (split_slot(row, 2 * ks + lhi) << 4);
+                xh[i] = *(const bf16x8*)(base + off);
+                xl[i] = *(const bf16x8*)(base + XIMG + off);
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int row = wn * 64 + j * 32 + lrow;
+                const int off = row * 64 + (split_slot(row, 2 * ks + lhi) << 4);
+                wh[j] = *(const bf16x8*)(base + 2 * XIMG + off);
+                wl[j] = *(const bf16x8*)(base + 2 * XIMG + WIMG + off);
+            }
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    if (d.split_bf16 & 4) { asm volatile("" ::"v"(wl[j]), "v"(xh[i]), "v"(wh[j]), "v"(xl[i])); continue; }
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl[j], xh[i], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[j], xl[i], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[j], xh[i], acc[i][j], 0, 0, 0);
+                }
+        }
+        if (k + 1 < nk && !(d.split_bf16 & 2)) store_stage(next_c, cur ^ 1);      // the other buffer: last read before the previous barrier
+        __syncthreads();
+        cur ^= 1;
+    };
+    for (int k = 0; k < nk; k += 3) {
+        step(I0{}, I1{}, k);
+        if (k + 1 < nk) step(I1{}, I2{}, k + 1);
+        if (k + 2 < nk) step(I2{}, I0{}, k + 2);
+    }
+    // acc[i][j][e] = C[m = m0 + wm*32*MI + i*32 + lrow][n = n0 + wn*64 + j*32 + (e&3) + 8*(e>>2) + 4*lhi]
+    const float* bias = (const float*)d.bias;
+    const float* res = (const float*)d.residual;
+    float* C = (float*)d.c;
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+        const int m = m0 + wm * (32 * MI) + i * 32 + lrow;
         if (m >= d.M) continue;
         const float rowb = (bias && d.bias_per_row) ? bias[m] : 0.f;
 #pragma unroll
@@ -362,7 +563,15 @@ extern "C" int slh_sgemm(const slh_sgemm_desc* d, slh_stream_t stream) {
         SLH_CHECK(d->mode == 0, "slh_sgemm: bad mode");
     }
     const int tiles = ((d->M + SBM - 1) / SBM) * ((d->N + SBN - 1) / SBN);
-    hipLaunchKernelGGL(sgemm_kernel, dim3(tiles), dim3(256), 0, (hipStream_t)stream, *d);
+    if ((d->split_bf16 & 1) && d->K % TBK == 0 && (d->mode == 0 || d->cin % TBK == 0)) {
+        if (tiles >= 256)
+            hipLaunchKernelGGL(sgemm_bf16x3_kernel<128>, dim3(tiles), dim3(256), 0, (hipStream_t)stream, *d);
+        else        // few 128-row tiles (the 64 x 64-pixel layers): 64-row tiles fill the chip
+            hipLaunchKernelGGL(sgemm_bf16x3_kernel<64>, dim3(((d->M + 63) / 64) * ((d->N + SBN - 1) / SBN)), dim3(256), 0,
+                               (hipStream_t)stream, *d);
+    } else {
+        hipLaunchKernelGGL(sgemm_kernel, dim3(tiles), dim3(256), 0, (hipStream_t)stream, *d);
+    }
     SLH_LAUNCH_CHECK("slh_sgemm");
     return 0;
 }

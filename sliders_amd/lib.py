@@ -83,7 +83,7 @@ TembLoraBwdDesc = _struct("TembLoraBwdDesc", _ptrs("g", "t", "up", "emb", "d_up"
 # image sliders: fp32 AutoencoderKL encoder (csrc/vae.hip)
 SgemmDesc = _struct("SgemmDesc", _ptrs("x", "w", "bias", "residual", "c")
                     + _ints("ldx", "ldw", "ldr", "ldc", "M", "N", "K", "mode", "cin", "batch", "hs", "ws", "ho", "wo", "stride",
-                            "pad", "bias_per_row") + [("alpha", c_f32)] + _ints("upsample", "pad2_"))
+                            "pad", "bias_per_row") + [("alpha", c_f32)] + _ints("upsample", "split_bf16"))
 Gn32Desc = _struct("Gn32Desc", _ptrs("x", "gamma", "beta", "stats", "y") + _ints("ldx", "ldy", "C", "batch", "hw", "groups")
                    + [("eps", c_f32)] + _ints("act"))
 Softmax32Desc = _struct("Softmax32Desc", _ptrs("x") + [("ld", c_i64)] + _ints("rows", "cols"))

@@ -99,11 +99,17 @@ class _VaeNet:
     """Weights + the op emitters shared by the encoder and the decoder command buffers."""
     PREFIXES: Tuple[str, ...] = ()
 
-    def __init__(self, state_dict: Dict[str, torch.Tensor], device="cuda:0", scaling_factor: float = VAE_SCALING["sdxl"]):
+    def __init__(self, state_dict: Dict[str, torch.Tensor], device="cuda:0", scaling_factor: float = VAE_SCALING["sdxl"],
+                 exact_fp32: bool = False):
+        """exact_fp32: every product on the exact-fp32 matrix instruction (slh_sgemm_desc.split_bf16 = 0).  Default: the
+        operands are split into two bf16 halves (16 mantissa bits, three bf16 MFMAs per product block, fp32 accumulation):
+        ~1e-5 relative to the fp32 result - two orders of magnitude tighter than the TF32 convolutions the reference's fp32
+        VAE runs with on its own hardware (torch.backends.cudnn.allow_tf32 = True by default) - at less than half the time."""
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise RuntimeError(f"{type(self).__name__} needs a ROCm GPU (there is no CPU fallback)")
         lib.load()
+        self.split_bf16 = 0 if exact_fp32 else 1
         self.scaling_factor = float(scaling_factor)
         self.w: Dict[str, torch.Tensor] = {}
         f = lambda t: t.to(device=self.device, dtype=torch.float32).contiguous()
@@ -151,7 +157,7 @@ class _VaeNet:
         d = lib.SgemmDesc(x=x.ptr, w=w_ptr or self._wp(name + ".weight"), bias=b_ptr or self._wp(name + ".bias"),
                           residual=residual.ptr if residual else 0, c=y.ptr, ldx=ci, ldw=9 * ci, ldr=co, ldc=co,
                           M=B * ho * wo, N=co, K=9 * ci, mode=1, cin=ci, batch=B, hs=h, ws=w, ho=ho, wo=wo, stride=stride,
-                          pad=1 if stride == 1 else 0, alpha=1.0, upsample=1 if upsample else 0)
+                          pad=1 if stride == 1 else 0, alpha=1.0, upsample=1 if upsample else 0, split_bf16=self.split_bf16)
         self._prog.add(lib.OP_SGEMM, d, name)
         return y, ho, wo
 
@@ -159,7 +165,8 @@ class _VaeNet:
                alpha=1.0, bias_per_row=0):
         y = out or self._act(M, N, name)
         d = lib.SgemmDesc(x=x_ptr, w=w_ptr, bias=bias_ptr, residual=residual.ptr if residual else 0, c=y.ptr, ldx=K, ldw=K,
-                          ldr=N, ldc=N, M=M, N=N, K=K, mode=0, alpha=alpha, bias_per_row=bias_per_row)
+                          ldr=N, ldc=N, M=M, N=N, K=K, mode=0, alpha=alpha, bias_per_row=bias_per_row,
+                          split_bf16=self.split_bf16)
         self._prog.add(lib.OP_SGEMM, d, name)
         return y
 
@@ -215,8 +222,9 @@ class _VaeNet:
 class VaeEncoder(_VaeNet):
     PREFIXES = ("encoder.", "quant_conv.")
 
-    def __init__(self, state_dict: Dict[str, torch.Tensor], device="cuda:0", scaling_factor: float = VAE_SCALING["sdxl"]):
-        super().__init__(state_dict, device, scaling_factor)
+    def __init__(self, state_dict: Dict[str, torch.Tensor], device="cuda:0", scaling_factor: float = VAE_SCALING["sdxl"],
+                 exact_fp32: bool = False):
+        super().__init__(state_dict, device, scaling_factor, exact_fp32)
         self.boc = []
         i = 0
         while f"encoder.down_blocks.{i}.resnets.0.conv1.weight" in state_dict:
@@ -308,8 +316,9 @@ class VaeDecoder(_VaeNet):
     GroupNorm + SiLU, conv_out) in fp32 -> image in [-1, 1]."""
     PREFIXES = ("decoder.", "post_quant_conv.")
 
-    def __init__(self, state_dict: Dict[str, torch.Tensor], device="cuda:0", scaling_factor: float = VAE_SCALING["sdxl"]):
-        super().__init__(state_dict, device, scaling_factor)
+    def __init__(self, state_dict: Dict[str, torch.Tensor], device="cuda:0", scaling_factor: float = VAE_SCALING["sdxl"],
+                 exact_fp32: bool = False):
+        super().__init__(state_dict, device, scaling_factor, exact_fp32)
         self.boc = []          # decoder order: widest first
         i = 0
         while f"decoder.up_blocks.{i}.resnets.0.conv1.weight" in state_dict:
