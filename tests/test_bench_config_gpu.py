@@ -84,10 +84,11 @@ def _check(name, got, e32, ebf, max_abs_bound):
     assert m_eng <= max_abs_bound, f"{name}: max abs error {m_eng:.3e} > {max_abs_bound:.1e}"
 
 
-@pytest.mark.parametrize("name,hw,need_gb,bound", [("sdxl", 128, 30, 1.85e-2), ("sd1", 64, 12, 2.0e-2)])
+@pytest.mark.parametrize("name,hw,need_gb,bound", [("sdxl", 128, 30, 1.85e-2), ("sd1", 64, 12, 2.6e-2)])
 def test_bench_config_forward_parity(dev, name, hw, need_gb, bound):
     """BASELINE configs[2] (SDXL 1024^2) and configs[1] (SD-1.x 512^2): adapters off and adapters on.
-    Measured on MI355X: SDXL rel_l2 8.3e-3 (bf16 arm 1.04e-2), max abs 1.42e-2; SD-1.x 9.6e-3 (1.13e-2), 1.54e-2."""
+    Measured on MI355X: SDXL rel_l2 8.3e-3 (bf16 arm 1.04e-2), max abs 1.42e-2; SD-1.x 9.5e-3 (1.13e-2), 1.54e-2 - 2.0e-2 over runs
+    (the bf16 arm's own max abs is 1.9e-2); the bounds are 1.3 x the largest value seen."""
     if _host_ram_gb() < need_gb:
         pytest.skip(f"fp32 oracle needs ~{need_gb} GB of host RAM")
     cfg = CONFIGS[name]()
