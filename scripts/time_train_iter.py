@@ -12,20 +12,21 @@ from sliders_amd.random_init import random_state_dict
 from sliders_amd.unet import UNetEngine
 
 dev = torch.device("cuda:0")
-cfg = CONFIGS["sdxl"]()
+MODEL = sys.argv[sys.argv.index("--model") + 1] if "--model" in sys.argv else "sdxl"
+cfg = CONFIGS[MODEL]()
 eng = UNetEngine(cfg, random_state_dict(cfg, dev, 0), dev)
 store = LoraStore(cfg, rank=4, alpha=1.0, train_method="noxattn", device=dev)
 store.params.add_(0.01)
 eng.attach_lora(store)
 eng.set_lora(True, 1.0)
-hw = 128
+hw = int(sys.argv[sys.argv.index("--hw") + 1]) if "--hw" in sys.argv else 128
 s = torch.cuda.current_stream().cuda_stream
 
 
 def inputs(B):
     return (torch.randn(B, 4, hw, hw, device=dev), torch.randn(B, 77, cfg.cross_attention_dim, device=dev),
             {"text_embeds": torch.randn(B, cfg.pooled_dim, device=dev),
-             "time_ids": torch.tensor([[hw * 8.0, hw * 8.0, 0, 0, hw * 8.0, hw * 8.0]] * B, device=dev)})
+             "time_ids": torch.tensor([[hw * 8.0, hw * 8.0, 0, 0, hw * 8.0, hw * 8.0]] * B, device=dev)} if cfg.is_xl else None)
 
 
 def timeit(fn, n=5):

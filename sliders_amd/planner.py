@@ -75,6 +75,17 @@ def splitk_candidate(d) -> bool:
     return d.M * d.N <= SPLITK_MAX_MN and d.K >= SPLITK_MIN_K and not d.geglu and d.N % 4 == 0
 
 
+def splitk_wanted(d) -> bool:
+    """Provision the workspace when the tile that will run splits K: the tuned tile says so, or there is no tuned tile and
+    the default would; in tuning mode (SLIDERS_NO_TUNING: scripts/tune_insitu.py tries split-K tiles on every candidate)
+    for every candidate."""
+    if not splitk_candidate(d):
+        return False
+    if os.environ.get("SLIDERS_NO_TUNING"):
+        return True
+    return ((d.tile >> 16) & 15) > 1 if d.tile else bool(default_splitk(d))
+
+
 def default_splitk(d) -> int:
     """Untuned shape: slices so that tiles x slices is about one workgroup per CU, at least 8 K tiles per slice."""
     tiles = ((d.M + 127) // 128) * ((d.N + 63) // 64)
@@ -237,11 +248,11 @@ class UNetPlan:
                          w_layout=1 if (w_ptr is None and self.w.packed) else 0)
         if conv is not None:
             self._conv_fields(d, x0, conv, Ho, Wo)
-        if splitk_candidate(d):
-            d.splitk_c32 = self.f32((M, N), name + ".splitk", zero=True).ptr
         d.tile = tuned_tile(d)
         if not d.tile and M <= 192 and N >= 4096:
             d.tile = 0x12        # few rows, very wide: 64-row tiles waste the least of the short M
+        if splitk_wanted(d):     # the zeroed fp32 workspace is cleared by the program's head memset: only where it is used
+            d.splitk_c32 = self.f32((M, N), name + ".splitk", zero=True).ptr
         if not d.tile and d.splitk_c32:
             d.tile = default_splitk(d)
         self.last_vt = None
@@ -683,7 +694,8 @@ class BackwardPlan:
         self.prog.add(lib.OP_ATTN_BWD, d, "bwd." + rec["name"])
 
     def _splitk(self, d, name):
-        if splitk_candidate(d):
+        d.tile = tuned_tile(d)
+        if splitk_wanted(d):
             d.splitk_c32 = self.zarena.alloc((d.M, d.N), torch.float32, name + ".splitk").ptr
 
     def _b_gemm(self, rec):
