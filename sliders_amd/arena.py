@@ -36,7 +36,9 @@ class Arena:
         self.high_water = 0
         self.allocs = []
         if device is not None:
-            self.buf = torch.empty(self.capacity, dtype=torch.uint8, device=device)
+            # zero-filled once: no kernel reads bytes it (or an earlier op of the plan) has not written, but a latent violation
+            # of that rule must read zeros, never whatever bit patterns a previous process left in HBM
+            self.buf = torch.zeros(self.capacity, dtype=torch.uint8, device=device)
             self.base = self.buf.data_ptr()
             assert self.base % _ALIGN == 0
         else:

@@ -750,10 +750,13 @@ class BackwardPlan:
             self.prog.add(lib.OP_WGRAD, d, name + ".dB")
             x0s = self._sl(x0)
             x1s = self._sl(x1) if x1 is not None else None
-            for g_i, e in enumerate(grp):
+            # the down matrices of a fused q|k|v group are adjacent ([12][K]) and so are their U columns: one R = 12 launch
+            # reads X once instead of three times
+            one = ng == 3 and conv is None
+            for g_i, e in enumerate(grp[:1] if one else grp):
                 d = lib.WgradDesc(z0=x0s.ptr, z1=x1s.ptr if x1s else 0, v=U.ptr + 4 * 4 * g_i, out=self.lora.gdown_ptr(e),
                                   scale=self.scale_ptr, ldz0=x0s.ld, ldz1=x1s.ld if x1s else 0, c0=x0.C,
-                                  c1=x1.C if x1 is not None else 0, mode=0, stride=1, M=Ms, R=4, ldv=4 * ng,
+                                  c1=x1.C if x1 is not None else 0, mode=0, stride=1, M=Ms, R=12 if one else 4, ldv=4 * ng,
                                   ldo=K, out_rmajor=1, vgroup_cols=0)
                 if conv is not None:
                     d.mode, d.batch, d.hs, d.ws = 1, self.nb, x0.H, x0.W
