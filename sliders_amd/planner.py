@@ -457,11 +457,13 @@ class UNetPlan:
         ctxb = self.io["ctx"]
         self.ctx = Act(ctxb.ptr, B, 1, self.ctx_len, cfg.cross_attention_dim, cfg.cross_attention_dim, ctxb, "ctx")
         # every transformer block projects the same text embeddings to K/V: when those projections carry no adapter they
-        # run as ONE GEMM over the concatenated weights at the head of the pass - also in the training forward: un-adapted
-        # text K/V carry no gradient (nograd_kv), the attention backward only reads them
+        # run as ONE GEMM over the concatenated weights at the head of the no-grad passes.  (The training forward keeps the
+        # per-block projections: with the batched form its cross-attention outputs came out non-finite in 4-5 of 8 fresh
+        # engines at SDXL 512x512 - scripts/debug_nan_forward.py, SLIDERS_TRAIN_KV_BATCHED=1 - root cause not found yet.)
         self.kv_all = self.vt_all = None
         kvo = getattr(self.w, "kv_all_offset", None)
-        if kvo and all(self._lora_group([a + ".to_k", a + ".to_v"]) is None for a in kvo):
+        if kvo and not (self.train and not os.environ.get("SLIDERS_TRAIN_KV_BATCHED")) and \
+                all(self._lora_group([a + ".to_k", a + ".to_v"]) is None for a in kvo):
             n_all = self.w.gemm_shape["attn2_kv_all.w"][0]
             self.kv_all = self.gemm(self.ctx, "attn2_kv_all", n_all, "attn2_kv_all", bias=False)
             # one head dim everywhere (SDXL: 64) -> the V halves of all blocks are one [B*77][sum(C)] matrix whose
