@@ -127,7 +127,7 @@ _ENTRY = {
 }
 
 EXPORTS = ["slh_version", "slh_last_error", "slh_run_program", "slh_desc_sizes", "slh_graph_capture", "slh_graph_launch",
-           "slh_graph_destroy"] + [v[0] for v in _ENTRY.values()]
+           "slh_graph_destroy", "slh_gemm_variant"] + [v[0] for v in _ENTRY.values()]
 
 
 class SlidersHipError(RuntimeError):
