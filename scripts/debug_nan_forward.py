@@ -14,7 +14,7 @@ hw = 64
 sd = random_state_dict(cfg, dev, 0, torch.bfloat16)
 mode = sys.argv[1] if len(sys.argv) > 1 else "train"
 bad = 0
-N = 8
+N = int(os.environ.get("NAN_TRIALS", "8"))
 for attempt in range(N):
     store = LoraStore(cfg, rank=4, alpha=1.0, train_method="noxattn", device=dev)
     g = torch.Generator().manual_seed(3)

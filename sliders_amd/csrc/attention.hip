@@ -87,7 +87,7 @@ __global__ __launch_bounds__(64 * NW, DT == 1 ? (NW == 4 ? 4 : 3) : ((DT == 2 &&
 
     stage(0, 0);
     for (int t = 0; t < nt; ++t) {
-        __syncthreads();
+        lds_dma_syncthreads();       // tile t landed (all waves), everybody is past tile t-1
         if (t + 1 < nt) stage((t + 1) & 1, t + 1);
         const char* cK = sK + (t & 1) * DT * 8192;
         const char* cV = sV + (t & 1) * DT * 8192;

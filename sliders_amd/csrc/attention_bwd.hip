@@ -112,7 +112,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const slh_attn_bwd_des
 
     stage(0, 0);
     for (int t = 0; t < nt; ++t) {
-        __syncthreads();
+        lds_dma_syncthreads();       // tile t landed (all waves), everybody is past tile t-1
         if (t + 1 < nt) stage((t + 1) & 1, t + 1);
         const char* cK = sK + (t & 1) * DT * 8192;
         const char* cV = sV + (t & 1) * DT * 8192;
@@ -227,12 +227,12 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const slh_attn_bwd_de
     if (NBUF == 2) stage(0, 0);
     for (int t = 0; t < nt; ++t) {
         if (NBUF == 2) {
-            __syncthreads();
+            lds_dma_syncthreads();    // tile t landed (all waves), everybody is past tile t-1
             if (t + 1 < nt) stage((t + 1) & 1, t + 1);
         } else {
             __syncthreads();          // everybody finished reading the single buffer
             stage(0, t);
-            __syncthreads();          // (drains this wave's LDS-DMA) tile t landed for all waves
+            lds_dma_syncthreads();    // tile t landed for all waves
         }
         const int bufo = (NBUF == 2 ? (t & 1) : 0) * DT * 8192;
         // per-query lse2 / delta straight from global (L1-resident; the arrays are padded by 64 floats)

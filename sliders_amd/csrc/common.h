@@ -51,6 +51,16 @@ __device__ __forceinline__ void glds16(const void* gsrc, void* lds_wave_base) {
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
+// Workgroup barrier that also drains this wave's LDS-DMA.  __syncthreads() alone is NOT enough after glds16: it is a
+// workgroup-scope fence + s_barrier, and on gfx9 (non-tgsplit) that fence waits lgkmcnt(0) only, while the LDS write of
+// a global_load_lds is tracked by vmcnt.  hipcc's own waitcnt insertion covers straight-line code but was seen to leave
+// the loop-carried case (prefetch tile t+1, barrier at the top of the next iteration) without any vmcnt wait - a tile
+// could be consumed before it landed (scripts/check_lds_dma_waits.py proves the wait is there in the compiled code).
+__device__ __forceinline__ void lds_dma_syncthreads() {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+}
+
 // The same copy issued from inline asm, i.e. INVISIBLE to hipcc's s_waitcnt bookkeeping.  An LDS-DMA that the compiler
 // can see makes it treat the LGKM counter as out-of-order ("pending flat"), and every ds_read consumer in the loop
 // then waits lgkmcnt(0) - which drains the fragment reads a software-pipelined K loop wants to keep in flight

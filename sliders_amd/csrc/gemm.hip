@@ -256,7 +256,7 @@ __global__ __launch_bounds__(128 * WM, gemm_waves_per_simd(MI, NI, STAGES, LORA,
     if constexpr (STAGES == 2) {
         if (!(p.probe & 8)) stage(0, kt_begin);
         for (int kt = 0; kt < nk; ++kt) {
-            __syncthreads();  // drains this wave's glds (vmcnt(0)) and orders all waves
+            lds_dma_syncthreads();  // drains this wave's glds (explicit vmcnt(0)) and orders all waves
             if (kt + 1 < nk && !(p.probe & 1)) stage((kt + 1) & 1, kt_begin + kt + 1);
             if (!(p.probe & 2)) compute(kt & 1);
         }

@@ -1,0 +1,52 @@
+"""Static checks on the compiled gfx950 code (CPU-only: hipcc cross-compiles, nothing is executed).
+
+LDS-DMA (global_load_lds) completion is tracked by vmcnt, and __syncthreads() does not wait on it; a prefetching loop
+that forgets the explicit wait reads tiles that have not landed - a timing-dependent corruption that no parity test
+catches reliably.  scripts/check_lds_dma_waits.py proves on the control-flow graph of every LDS-DMA kernel that each
+s_barrier is preceded by a vmcnt wait on all paths."""
+import os
+import shutil
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "scripts"))
+import check_lds_dma_waits as chk  # noqa: E402
+
+CSRC = os.path.join(ROOT, "sliders_amd", "csrc")
+
+RACY = """
+    s_load_dwordx2 s[0:1], s[4:5], 0x0
+    global_load_lds_dwordx4 v[2:3], off
+    s_waitcnt vmcnt(0)
+.LBB0_1:
+    s_waitcnt lgkmcnt(0)
+    s_barrier
+    global_load_lds_dwordx4 v[2:3], off
+    ds_read_b128 v[4:7], v8
+    s_cbranch_scc1 .LBB0_3
+    s_branch .LBB0_1
+.LBB0_3:
+    s_endpgm
+"""
+
+
+def test_checker_flags_a_loop_carried_unwaited_dma():
+    hits = chk.check_kernel(RACY)
+    assert len(hits) == 1 and hits[0][1].startswith("s_barrier")
+    fixed = RACY.replace("    s_waitcnt lgkmcnt(0)\n    s_barrier", "    s_waitcnt vmcnt(0)\n    s_barrier")
+    assert chk.check_kernel(fixed) == []
+
+
+@pytest.mark.skipif(shutil.which("hipcc") is None, reason="hipcc not on PATH")
+@pytest.mark.parametrize("src", ["attention.hip", "attention_bwd.hip", "gemm.hip"])
+def test_every_barrier_waits_for_lds_dma(src):
+    asm = chk.device_asm(os.path.join(CSRC, src))
+    checked = 0
+    for name, body in chk.kernels(asm):
+        if "global_load_lds" not in body or chk.is_counted_ring(name):
+            continue
+        checked += 1
+        assert chk.check_kernel(body) == [], name
+    assert checked >= 6
