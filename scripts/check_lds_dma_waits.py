@@ -38,6 +38,18 @@ def device_asm(src):
     raise RuntimeError("no device assembly for " + src)
 
 
+def kernel_resources(asm):
+    """{mangled name: {"scratch": bytes, "lds": bytes, "vgpr": n, "agpr_offset": n}} from the .amdhsa_kernel blocks"""
+    out = {}
+    for m in re.finditer(r"\.amdhsa_kernel (\S+)\n(.*?)\.end_amdhsa_kernel", asm, re.S):
+        def field(key, body=m.group(2)):
+            f = re.search(r"\.amdhsa_" + key + r"\s+(\d+)", body)
+            return int(f.group(1)) if f else -1
+        out[m.group(1)] = {"scratch": field("private_segment_fixed_size"), "lds": field("group_segment_fixed_size"),
+                           "vgpr": field("next_free_vgpr"), "agpr_offset": field("accum_offset")}
+    return out
+
+
 def kernels(asm):
     for m in re.finditer(r"^(_Z\S+):[^\n]*\n(.*?)\.end_amdhsa_kernel", asm, re.S | re.M):
         yield m.group(1), m.group(2)

@@ -15,6 +15,13 @@ sys.path.insert(0, os.path.join(ROOT, "scripts"))
 import check_lds_dma_waits as chk  # noqa: E402
 
 CSRC = os.path.join(ROOT, "sliders_amd", "csrc")
+_ASM = {}
+
+
+def _asm(src):
+    if src not in _ASM:
+        _ASM[src] = chk.device_asm(os.path.join(CSRC, src))
+    return _ASM[src]
 
 RACY = """
     s_load_dwordx2 s[0:1], s[4:5], 0x0
@@ -42,7 +49,7 @@ def test_checker_flags_a_loop_carried_unwaited_dma():
 @pytest.mark.skipif(shutil.which("hipcc") is None, reason="hipcc not on PATH")
 @pytest.mark.parametrize("src", ["attention.hip", "attention_bwd.hip", "gemm.hip"])
 def test_every_barrier_waits_for_lds_dma(src):
-    asm = chk.device_asm(os.path.join(CSRC, src))
+    asm = _asm(src)
     checked = 0
     for name, body in chk.kernels(asm):
         if "global_load_lds" not in body or chk.is_counted_ring(name):
@@ -50,3 +57,15 @@ def test_every_barrier_waits_for_lds_dma(src):
         checked += 1
         assert chk.check_kernel(body) == [], name
     assert checked >= 6
+
+
+@pytest.mark.skipif(shutil.which("hipcc") is None, reason="hipcc not on PATH")
+@pytest.mark.parametrize("src", sorted(f for f in os.listdir(CSRC) if f.endswith(".hip")))
+def test_no_kernel_spills_to_scratch(src):
+    """every kernel of the library fits its registers: a spill in a hot loop is a silent 2-10x (seen once this round:
+    an epilogue preload pushed one GEMM instantiation into scratch), and the launch-bounds / tile choices assume it"""
+    res = chk.kernel_resources(_asm(src))
+    assert res, src
+    for name, r in res.items():
+        assert r["scratch"] == 0, (name, r)
+        assert r["lds"] <= 160 * 1024, (name, r)
