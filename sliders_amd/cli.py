@@ -138,13 +138,17 @@ def optimizer_options(train_cfg) -> dict:
     return out
 
 
-def check_supported(config: config_util.RootConfig):
+def check_supported(config: config_util.RootConfig, image_slider: bool = False):
     """Reject, before any model is loaded, every config value the fused path would otherwise have to ignore."""
     t = config.train
     if config_util.parse_precision(t.precision) != torch.bfloat16:
         raise NotImplementedError(f"train.precision '{t.precision}': the MI355X hot path computes in bf16 (the reference's default)")
-    if t.noise_scheduler != "ddim":
-        raise NotImplementedError(f"train.noise_scheduler '{t.noise_scheduler}': only DDIM (model_util.py:237-246) is implemented")
+    name = t.noise_scheduler.lower().replace(" ", "_")
+    if name not in ("ddim", "ddpm", "lms", "euler_a"):            # model_util.py:230-277
+        raise ValueError(f"Unknown scheduler name: {name}")
+    if image_slider and name != "ddim":
+        raise NotImplementedError(f"train.noise_scheduler '{t.noise_scheduler}': the image-slider noising step (get_noisy_image, "
+                                  f"fused with the VAE encode) is built on the DDIM alpha table; text sliders accept ddpm / lms / euler_a")
     optimizer_options(t)
     LrSchedule(t.lr_scheduler, t.lr, t.iterations)
 
@@ -189,7 +193,8 @@ def train(config: config_util.RootConfig, prompts, device: int, xl: bool, synthe
                        max_denoising_steps=config.train.max_denoising_steps,
                        process_group=torch.distributed.group.WORLD if world > 1 else None,
                        prediction_type="v_prediction" if config.pretrained_model.v_pred else "epsilon",
-                       optimizer=opt["name"])
+                       optimizer=opt["name"], noise_scheduler=config.train.noise_scheduler,
+                       scheduler_seed=seed * 7919 + rank)
     if synthetic:
         pairs = _synthetic_pairs(eng.cfg, prompts, dev, seed)
     else:
@@ -226,7 +231,8 @@ def train(config: config_util.RootConfig, prompts, device: int, xl: bool, synthe
             ids = get_add_time_ids(height, width, dynamic_crops=True, dtype=torch.bfloat16)   # bf16 like the reference (quirk D.8)
             torch.random.set_rng_state(st)
             time_ids = ids.float().repeat(2 * s.batch_size, 1)
-        noise = samp.noise((s.batch_size, 4, height // 8, width // 8)).to(dev)
+        # get_initial_latents (train_util.py:55): unit noise times the scheduler's init_noise_sigma
+        noise = samp.noise((s.batch_size, 4, height // 8, width // 8)).to(dev) * tr.sched.init_noise_sigma
         lr = sched.current()
         loss = tr.iteration(pair, k, noise, lr=lr, time_ids=time_ids)
         sched.step()

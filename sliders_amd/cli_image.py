@@ -81,7 +81,7 @@ def open_image(path: str, size: int) -> torch.Tensor:
 
 
 def train(config, prompts, device: int, xl: bool, folder_main: str, folders, scales, synthetic: bool, seed: int = 0):
-    check_supported(config)
+    check_supported(config, image_slider=True)
     if not synthetic:
         check_model_files(config.pretrained_model.name_or_path)
     rank, world = world_info()
@@ -159,7 +159,7 @@ def main(xl: bool, argv=None):
     config.save.path += f"/{config.save.name}"
     prompts = prompt_util.load_prompts_from_yaml(config.prompts_file, attributes)
     folders, scales = parse_folders_scales(args.folders, args.scales)
-    check_supported(config)
+    check_supported(config, image_slider=True)
     if int(os.environ.get("WORLD_SIZE", "1")) > 1:
         torch.distributed.init_process_group("nccl")
         args.device = int(os.environ.get("LOCAL_RANK", "0"))

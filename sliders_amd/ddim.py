@@ -13,6 +13,8 @@ import torch
 
 
 class DDIMSchedule:
+    fused = True        # the step is slh_cfg_ddim; sliders_amd/schedulers.py holds the tensor-op schedulers (fused = False)
+
     def __init__(self, num_train_timesteps: int = 1000, beta_start: float = 0.00085, beta_end: float = 0.012,
                  prediction_type: str = "epsilon"):
         if prediction_type not in ("epsilon", "v_prediction"):

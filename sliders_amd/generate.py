@@ -46,6 +46,8 @@ def build_parser() -> argparse.ArgumentParser:
     p.add_argument("--start_noise", type=int, default=750)
     p.add_argument("--ddim_steps", type=int, default=50)
     p.add_argument("--guidance_scale", type=float, default=7.5)
+    p.add_argument("--scheduler", default="ddim", choices=["ddim", "lms", "euler_a", "ddpm"],
+                   help="ddim: fused HIP step; lms is what eval-scripts/generate_images_sd1.py:51 constructs")
     p.add_argument("--res", type=int, default=None)
     p.add_argument("--seed", type=int, default=0)
     p.add_argument("--device", type=int, default=0)
@@ -88,7 +90,7 @@ def main(argv=None):
         rank, alpha, method = parse_slider_name(a.lora_weight)
         store = LoraStore(eng.cfg, rank=rank, alpha=alpha, train_method=method, device=dev, init="none")
         store.load_state_dict(torch.load(a.lora_weight, map_location="cpu"), strict=True)
-    smp = SliderSampler(eng, store, dec)
+    smp = SliderSampler(eng, store, dec, scheduler=a.scheduler, scheduler_seed=a.seed)
     os.makedirs(a.out, exist_ok=True)
     from PIL import Image
     for s in (float(v) for v in a.scales.split(",")):

@@ -6,7 +6,8 @@ pipelines for this; here only the pieces the hot path needs).
    layout (renamed by `ldm_convert.py`) -> UNetEngine.
  * `load_text_encoders_xl / encode_prompts_xl`: CLIP text encoders through the installed `transformers`
    (they run once before the loop - train_lora_xl.py:121-156 - and are not on the hot path).
- * `create_noise_scheduler`: DDIM as configured at model_util.py:237-246; the other schedulers are out of scope.
+ * `create_noise_scheduler`: DDIM as configured at model_util.py:237-246 (fused HIP step); ddpm / lms / euler_a from
+   sliders_amd/schedulers.py.
 No checkpoints exist in the build image (HF_HUB_OFFLINE), so `synthetic_engine` provides seeded random-init
 weights with the real shapes for throughput runs and tests.
 """
@@ -24,11 +25,14 @@ from .unet import UNetEngine
 
 
 def create_noise_scheduler(scheduler_name: str = "ddim", prediction_type: str = "epsilon"):
-    """model_util.py:230-277.  DDIM with epsilon or v prediction; the reference's other choices (ddpm, lms, euler_a) draw
-    device-side noise per step / work in sigma space and are not implemented by the fused step."""
-    if scheduler_name.lower().replace(" ", "_") != "ddim":
-        raise ValueError(f"noise scheduler '{scheduler_name}': only ddim is implemented")
-    return DDIMScheduler(prediction_type=prediction_type)
+    """model_util.py:230-277.  "ddim" is the fused HIP step (train_util.DDIMScheduler over slh_cfg_ddim); "ddpm", "lms" and
+    "euler_a" are the tensor-op schedulers of sliders_amd/schedulers.py (same interface, device noise per step / sigma
+    space)."""
+    name = scheduler_name.lower().replace(" ", "_")
+    if name == "ddim":
+        return DDIMScheduler(prediction_type=prediction_type)
+    from . import schedulers
+    return schedulers.create(name, prediction_type)
 
 
 def load_unet_state(name_or_path: str):

@@ -22,6 +22,7 @@ from typing import Optional
 import torch
 
 from . import lib
+from . import schedulers
 from .ddim import DDIMSchedule
 from .lora_store import LoraStore
 from .unet import UNetEngine
@@ -30,18 +31,26 @@ from .vae import VaeDecoder
 
 class SliderSampler:
     def __init__(self, engine: UNetEngine, store: Optional[LoraStore] = None, decoder: Optional[VaeDecoder] = None,
-                 prediction_type: str = "epsilon"):
+                 prediction_type: str = "epsilon", scheduler: str = "ddim", scheduler_seed: int = 0):
+        """scheduler: "ddim" (fused HIP step; what the notebooks' pipelines are given), or "lms" (the scheduler
+        eval-scripts/generate_images_sd1.py:51 constructs), "euler_a", "ddpm" from sliders_amd/schedulers.py."""
         self.eng, self.store, self.decoder = engine, store, decoder
         if store is not None and engine.lora is not store:
             engine.attach_lora(store)
-        self.sched = DDIMSchedule(prediction_type=prediction_type)
+        if scheduler.lower().replace(" ", "_") == "ddim":
+            self.sched = DDIMSchedule(prediction_type=prediction_type)
+        else:
+            self.sched = schedulers.create(scheduler, prediction_type)
+            self.sched_generator = torch.Generator(device=engine.device)
+            self.sched_generator.manual_seed(int(scheduler_seed))
 
     @torch.no_grad()
     def sample_latents(self, ctx: torch.Tensor, noise: torch.Tensor, scale: float = 0.0, start_noise: int = 750,
                        ddim_steps: int = 50, guidance_scale: float = 7.5, pooled: Optional[torch.Tensor] = None,
                        time_ids: Optional[torch.Tensor] = None) -> torch.Tensor:
-        """ctx: (2*bs, 77, D) = cat([unconditional, text]); noise: (bs, 4, h, w) (already * init_noise_sigma = 1);
-        returns the final latents (bs, 4, h, w) bf16.  LoRA multiplier per step: 0 while t > start_noise, `scale` after."""
+        """ctx: (2*bs, 77, D) = cat([unconditional, text]); noise: (bs, 4, h, w) UNIT noise (it is multiplied by the
+        scheduler's init_noise_sigma here, generate_images_sd1.py:165); returns the final latents (bs, 4, h, w) bf16.
+        LoRA multiplier per step: 0 while t > start_noise, `scale` after."""
         eng = self.eng
         bs, _, h, w = noise.shape
         mode = "on" if self.store is not None else "off"
@@ -54,6 +63,8 @@ class SliderSampler:
             io["time_ids"].tensor.copy_(time_ids.to(device=eng.device, dtype=torch.float32).reshape(2 * bs, 6))
             io["add_in"].tensor[:, : eng.cfg.pooled_dim].copy_(pooled.to(torch.bfloat16))
         smp = io["sample"]
+        if not self.sched.fused:
+            return self._sample_unfused(p, noise, scale, start_noise, ddim_steps, guidance_scale)
         lat = noise.to(eng.device, torch.bfloat16)
         smp.tensor[:bs].copy_(lat)
         smp.tensor[bs:].copy_(lat)
@@ -71,6 +82,32 @@ class SliderSampler:
         if self.store is not None:
             eng.set_lora(False)
         return smp.tensor[:bs].clone()
+
+    def _sample_unfused(self, p, noise, scale, start_noise, steps, guidance_scale):
+        """generate_images_sd1.py:160-185 with a tensor-op scheduler: scale_model_input -> UNet replay -> guidance combine
+        (slh_cfg_ddim, do_step = 0) -> scheduler.step on the device latents"""
+        eng, sch, io = self.eng, self.sched, p.io
+        bs = noise.shape[0]
+        s = torch.cuda.current_stream().cuda_stream
+        sch.set_timesteps(steps, device=eng.device)
+        lat = (noise.to(eng.device, torch.float32) * sch.init_noise_sigma).to(torch.bfloat16)
+        eps = torch.empty_like(lat)
+        chw = lat[0].numel()
+        for i, t in enumerate(sch.timesteps):
+            if self.store is not None:
+                eng.set_lora(True, 0.0 if float(t) > start_noise else float(scale))
+            x = sch.scale_model_input(lat, t)
+            io["sample"].tensor[:bs].copy_(x)
+            io["sample"].tensor[bs:].copy_(x)
+            io["t"].tensor.fill_(float(t))
+            (p.prog if (i == 0 or p.prog_text_cached is None) else p.prog_text_cached).run(s)
+            d = lib.CfgDdimDesc(eps=io["eps"].ptr, x=0, out=eps.data_ptr(), out2=0, nb=bs, chw=chw,
+                                guidance=float(guidance_scale), do_step=0)
+            lib.call(lib.OP_CFG_DDIM, d, s)
+            lat = sch.step(eps, t, lat, generator=self.sched_generator).prev_sample
+        if self.store is not None:
+            eng.set_lora(False)
+        return lat
 
     @torch.no_grad()
     def generate(self, ctx, noise, **kw) -> torch.Tensor:

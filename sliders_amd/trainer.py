@@ -27,6 +27,7 @@ import os
 import torch
 
 from . import lib
+from . import schedulers
 from .ddim import DDIMSchedule
 from .lora_store import LoraStore
 from .parallel import allreduce_sum_, world_info
@@ -72,7 +73,8 @@ class SliderTrainer:
     def __init__(self, engine: UNetEngine, store: LoraStore, H: int, W: int, batch_size: int = 1,
                  lr: float = 2e-4, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.01,
                  max_denoising_steps: int = 50, denoise_guidance: float = 3.0, process_group=None,
-                 dedup_frozen: bool = True, prediction_type: str = "epsilon", optimizer: str = "adamw"):
+                 dedup_frozen: bool = True, prediction_type: str = "epsilon", optimizer: str = "adamw",
+                 noise_scheduler: str = "ddim", scheduler_seed: int = 0):
         self.eng, self.store = engine, store
         self.lr, self.betas, self.eps, self.wd = lr, betas, eps, weight_decay
         if optimizer not in ("adamw", "adam", "lion"):
@@ -80,14 +82,22 @@ class SliderTrainer:
         self.optimizer = optimizer
         self.nsteps = max_denoising_steps
         self.denoise_guidance = denoise_guidance
-        self.sched = DDIMSchedule(prediction_type=prediction_type)   # v_prediction: pretrained_model.v_pred (model_util.py:126)
+        # train.noise_scheduler (model_util.py:230-277); v_prediction: pretrained_model.v_pred (model_util.py:126)
+        if noise_scheduler.lower().replace(" ", "_") == "ddim":
+            self.sched = DDIMSchedule(prediction_type=prediction_type)
+        else:
+            self.sched = schedulers.create(noise_scheduler, prediction_type)
+            # ddpm / euler_a draw device noise in every step (the reference uses the global device RNG there)
+            self.sched_generator = torch.Generator(device=engine.device)
+            self.sched_generator.manual_seed(int(scheduler_seed))
         self.pg = process_group
         self.rank, self.world = world_info(process_group)
         self.grad_scale = 1.0
         engine.attach_lora(store) if engine.lora is not store else None
         self.loss = torch.zeros(1, dtype=torch.float32, device=engine.device)
-        self.t50 = self.sched.make_timesteps(max_denoising_steps)
-        self.t1000 = self.sched.make_timesteps(1000)
+        if self.sched.fused:
+            self.t50 = self.sched.make_timesteps(max_denoising_steps)
+            self.t1000 = self.sched.make_timesteps(1000)
         self.unet_passes = 0
         self.dedup_frozen = dedup_frozen
         # the three frozen predictions and the training forward only share their input (the denoised latents): with
@@ -119,6 +129,34 @@ class SliderTrainer:
         s[: self.bs].copy_(lat)
         s[self.bs:].copy_(lat)
 
+    def _model_input(self, lat, t):
+        """scheduler.scale_model_input (train_util.py:156, 234): identity for ddim / ddpm, 1/sqrt(sigma^2+1) for lms / euler_a"""
+        return lat if self.sched.fused else self.sched.scale_model_input(lat, t)
+
+    def _denoise_unfused(self, p_on, noise, k: int):
+        """train_util.diffusion[_xl] (train_util.py:175-196 / 263-294) for the tensor-op schedulers: UNet pass and guidance
+        combine are the HIP path, the scheduler step is sliders_amd/schedulers.py on the device latents.  Leaves the
+        scheduler on its 1000-step grid like train_lora_xl.py:229 and returns the timestep of the four predictions."""
+        sch, s = self.sched, _stream()
+        eps = self.e_tgt                    # scratch: the guided prediction of this step (overwritten again in step 3)
+        first = [True]
+
+        def predict(model_input, t):
+            self._load_latents(p_on, model_input)
+            p_on.io["t"].tensor.fill_(float(t))
+            # the prompt embeddings do not change inside the loop: after the first step the text K/V are already there
+            (p_on.prog if (first[0] or p_on.prog_text_cached is None) else p_on.prog_text_cached).run(s)
+            first[0] = False
+            self.unet_passes += 1
+            self._cfg(p_on, eps.data_ptr(), self.denoise_guidance)
+            return eps
+
+        lat = schedulers.denoise(sch, predict, noise.to(device=self.eng.device, dtype=torch.bfloat16), k, self.nsteps,
+                                 generator=self.sched_generator, device=self.eng.device)
+        self.denoised.copy_(lat)
+        sch.set_timesteps(1000, device=self.eng.device)
+        return sch.timesteps[int(k * 1000 / self.nsteps)]
+
     def _cfg(self, p, out, guidance, coeff=None, out2=None, x=None, eps_text=None):
         d = lib.CfgDdimDesc(eps=p.io["eps"].ptr, x=x or 0, out=out, out2=out2 or 0, eps_text=eps_text or 0,
                             nb=self.bs, chw=self.chw, guidance=guidance, do_step=0)
@@ -128,7 +166,7 @@ class SliderTrainer:
         lib.call(lib.OP_CFG_DDIM, d, _stream())
 
     def _predict(self, p, lat, ctx, pooled, t, out):
-        self._load_latents(p, lat)
+        self._load_latents(p, self._model_input(lat, t))
         self._load_cond(p, ctx, pooled)
         p.io["t"].tensor.fill_(float(t))
         p.prog.run(_stream())
@@ -144,8 +182,9 @@ class SliderTrainer:
         eng, bs = self.eng, self.bs
         p3 = eng.plan(3 * bs, self.H, self.W, "off")
         s = p3.io["sample"].tensor
+        lat_in = self._model_input(self.denoised, t_cur)
         for j in range(3):
-            s[j * bs:(j + 1) * bs].copy_(self.denoised)
+            s[j * bs:(j + 1) * bs].copy_(lat_in)
         ctx = p3.io["ctx"].tensor
         ctx[:bs].copy_(pair.ctx_uncond[:bs]); ctx[bs:2 * bs].copy_(pair.ctx_positive[bs:]); ctx[2 * bs:].copy_(pair.ctx_neutral[bs:])
         if eng.cfg.is_xl:
@@ -166,7 +205,8 @@ class SliderTrainer:
     # ---- one iteration ------------------------------------------------------------------------------
     def iteration(self, pair: PairEmbeds, k: int, noise: torch.Tensor, lr: Optional[float] = None,
                   time_ids: Optional[torch.Tensor] = None) -> torch.Tensor:
-        """noise: (bs,4,H,W) already scaled by init_noise_sigma (=1); its shape selects the resolution and batch of
+        """noise: (bs,4,H,W) already scaled by the scheduler's init_noise_sigma (train_util.py:55; 1 for ddim / ddpm, the
+        largest sigma for lms / euler_a: `trainer.sched.init_noise_sigma`); its shape selects the resolution and batch of
         this iteration.  lr: this step's learning rate (the host evaluates the LR schedule, train_lora_xl.py:346-347).
         time_ids: (2*bs, 6) SDXL micro-conditioning when it is not the default [H,W,0,0,H,W] (dynamic_crops).
         Returns the device loss scalar."""
@@ -182,19 +222,22 @@ class SliderTrainer:
         eng.set_lora(True, 1.0)
         p_on = eng.plan(B, self.H, self.W, "on")
         self._load_cond(p_on, pair.ctx_target, pair.pooled_target)
-        self._load_latents(p_on, noise.to(torch.bfloat16))
-        smp = p_on.io["sample"]
-        half = bs * self.chw * 2
-        for i in range(k):
-            t = self.t50[i]
-            p_on.io["t"].tensor.fill_(float(t))
-            # the prompt embeddings do not change inside the loop: after the first step the text K/V are already there
-            (p_on.prog if (i == 0 or p_on.prog_text_cached is None) else p_on.prog_text_cached).run(s)
-            self.unet_passes += 1
-            self._cfg(p_on, smp.ptr, self.denoise_guidance, self.sched.step_fields(t, self.nsteps),
-                      out2=smp.ptr + half, x=smp.ptr)
-        self.denoised.copy_(smp.tensor[:bs])
-        t_cur = self.t1000[int(k * 1000 / self.nsteps)]
+        if self.sched.fused:
+            self._load_latents(p_on, noise.to(torch.bfloat16))
+            smp = p_on.io["sample"]
+            half = bs * self.chw * 2
+            for i in range(k):
+                t = self.t50[i]
+                p_on.io["t"].tensor.fill_(float(t))
+                # the prompt embeddings do not change inside the loop: after the first step the text K/V are already there
+                (p_on.prog if (i == 0 or p_on.prog_text_cached is None) else p_on.prog_text_cached).run(s)
+                self.unet_passes += 1
+                self._cfg(p_on, smp.ptr, self.denoise_guidance, self.sched.step_fields(t, self.nsteps),
+                          out2=smp.ptr + half, x=smp.ptr)
+            self.denoised.copy_(smp.tensor[:bs])
+            t_cur = self.t1000[int(k * 1000 / self.nsteps)]
+        else:
+            t_cur = self._denoise_unfused(p_on, noise, k)
         # 2. frozen-model predictions, adapters off (train_lora_xl.py:236-295)
         def frozen():
             if self.dedup_frozen:

@@ -367,10 +367,14 @@ def test_optimizer_options_and_rejections():
     for bad in (dict(optimizer="lion", optimizer_args="eps=1e-6"), dict(optimizer="lion", optimizer_args="use_triton=True"),
                 dict(optimizer="prodigy"), dict(optimizer="adam8bit"), dict(optimizer="dadaptlion"),
                 dict(optimizer="adam", optimizer_args="weight_decay=0.01"), dict(optimizer_args="amsgrad=True"),
-                dict(precision="float32"), dict(precision="fp16"), dict(noise_scheduler="euler_a"),
-                dict(lr_scheduler="linear")):
+                dict(precision="float32"), dict(precision="fp16"), dict(lr_scheduler="linear")):
         with pytest.raises(NotImplementedError):
             check_supported(_cfg(**bad))
+    for name in ("ddim", "ddpm", "lms", "euler_a"):      # model_util.py:230-277: all four for text sliders
+        check_supported(_cfg(noise_scheduler=name))
+    check_supported(_cfg(), image_slider=True)
+    with pytest.raises(NotImplementedError):             # image sliders: the fused noising step is DDIM-table only
+        check_supported(_cfg(noise_scheduler="euler_a"), image_slider=True)
     with pytest.raises(ValueError):
         check_supported(_cfg(lr_scheduler="nope"))
     c = _cfg()
