@@ -44,3 +44,52 @@ class Lion:
             update = exp_avg.clone().mul_(b1).add(grad, alpha=1 - b1).sign_()
             p.add_(update, alpha=-self.lr)
             exp_avg.mul_(b2).add_(grad, alpha=1 - b2)
+
+
+class ProdigyF64:
+    """float64 numpy evaluation of Prodigy as released in prodigyopt 1.0 (train_util.py:369-372; package absent ->
+    PARITY UNPINNED), written from the paper's Algorithm 4 plus the release's conventions, independently of
+    sliders_amd/optim.py (no torch, one flat vector):
+
+        dlr      = d * lr * [sqrt(1 - beta2^(k+1)) / (1 - beta1^(k+1))  if use_bias_correction]
+        num     <- beta3 * num + (d/d0) * dlr * <g, x0 - x>                         (beta3 = sqrt(beta2))
+        m       <- beta1 * m + d (1 - beta1) g ;   v <- beta2 * v + d^2 (1 - beta2) g^2
+        s       <- beta3 * s + (d/d0) * (d if safeguard_warmup else dlr) * g
+        d_hat    = d_coef * num / ||s||_1 ;  first growth from d0: d = max(d, d_hat) ;  d_max = max(d_max, d_hat)
+        d_next   = min(d_max, d * growth_rate)
+        x       <- x (1 - wd * dlr) - dlr * m / (sqrt(v) + d_next * eps)            (decoupled decay; d_next as released)
+    """
+
+    def __init__(self, x0, lr=1.0, betas=(0.9, 0.999), beta3=None, eps=1e-8, weight_decay=0.0, use_bias_correction=False,
+                 safeguard_warmup=False, d0=1e-6, d_coef=1.0, growth_rate=float("inf")):
+        import numpy as np
+        self.np = np
+        self.x = np.array(x0, dtype=np.float64)
+        self.x0 = self.x.copy()
+        self.m, self.v, self.s = np.zeros_like(self.x), np.zeros_like(self.x), np.zeros_like(self.x)
+        self.lr, self.b1, self.b2 = lr, betas[0], betas[1]
+        self.b3 = beta3 if beta3 is not None else betas[1] ** 0.5
+        self.eps, self.wd, self.ubc, self.sw = eps, weight_decay, use_bias_correction, safeguard_warmup
+        self.d = self.d0 = self.d_max = d0
+        self.d_coef, self.growth, self.num, self.k = d_coef, growth_rate, 0.0, 0
+
+    def step(self, g):
+        np = self.np
+        g = np.asarray(g, dtype=np.float64)
+        d, d0 = self.d, self.d0
+        bc = (1 - self.b2 ** (self.k + 1)) ** 0.5 / (1 - self.b1 ** (self.k + 1)) if self.ubc else 1.0
+        dlr = d * self.lr * bc
+        self.num = self.b3 * self.num + (d / d0) * dlr * float(g @ (self.x0 - self.x))
+        self.m = self.b1 * self.m + d * (1 - self.b1) * g
+        self.v = self.b2 * self.v + d * d * (1 - self.b2) * g * g
+        self.s = self.b3 * self.s + (d / d0) * (d if self.sw else dlr) * g
+        l1 = float(np.abs(self.s).sum())
+        if l1 == 0:
+            return
+        d_hat = self.d_coef * self.num / l1
+        if d == d0:
+            d = max(d, d_hat)
+        self.d_max = max(self.d_max, d_hat)
+        d = min(self.d_max, d * self.growth)
+        self.x = self.x * (1 - self.wd * dlr) - dlr * self.m / (np.sqrt(self.v) + d * self.eps)
+        self.d, self.k = d, self.k + 1

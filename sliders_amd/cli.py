@@ -111,10 +111,10 @@ def optimizer_options(train_cfg) -> dict:
     optimizer kernels (slh_adamw for adam / adamw, slh_lion for lion).  Anything those kernels do not implement is an error,
     never silently ignored."""
     name = (train_cfg.optimizer or "adamw").lower()
-    if name not in ("adamw", "adam", "lion"):
-        raise NotImplementedError(f"train.optimizer '{train_cfg.optimizer}': the fused MI355X path implements adam / adamw / lion "
-                                  f"(prodigy, dadapt*, *8bit are adaptive-step / quantised-state methods of packages that are "
-                                  f"not in this image)")
+    if name not in ("adamw", "adam", "lion", "prodigy"):
+        raise NotImplementedError(f"train.optimizer '{train_cfg.optimizer}': implemented are adam / adamw / lion (fused kernels) and "
+                                  f"prodigy (sliders_amd.optim.Prodigy); dadapt* and *8bit belong to packages that are not in this "
+                                  f"image (dadaptation, bitsandbytes - the latter CUDA-only)")
     kw = {}
     if train_cfg.optimizer_args:
         for arg in train_cfg.optimizer_args.split(" "):
@@ -122,7 +122,10 @@ def optimizer_options(train_cfg) -> dict:
                 continue
             key, value = arg.split("=")
             kw[key] = ast.literal_eval(value)
-    if name == "lion":      # lion_pytorch.Lion defaults (requirements.txt:5)
+    if name == "prodigy":   # prodigyopt.Prodigy's own arguments and defaults (requirements.txt: prodigyopt==1.0)
+        out = {"betas": (0.9, 0.999), "beta3": None, "eps": 1e-8, "weight_decay": 0.0, "decouple": True,
+               "use_bias_correction": False, "safeguard_warmup": False, "d0": 1e-6, "d_coef": 1.0, "growth_rate": float("inf")}
+    elif name == "lion":    # lion_pytorch.Lion defaults (requirements.txt:5)
         out = {"betas": (0.9, 0.99), "weight_decay": 0.0}
     else:
         out = {"betas": (0.9, 0.999), "eps": 1e-8, "weight_decay": 0.01 if name == "adamw" else 0.0}
@@ -194,7 +197,8 @@ def train(config: config_util.RootConfig, prompts, device: int, xl: bool, synthe
                        process_group=torch.distributed.group.WORLD if world > 1 else None,
                        prediction_type="v_prediction" if config.pretrained_model.v_pred else "epsilon",
                        optimizer=opt["name"], noise_scheduler=config.train.noise_scheduler,
-                       scheduler_seed=seed * 7919 + rank)
+                       scheduler_seed=seed * 7919 + rank,
+                       optimizer_kwargs={k: v for k, v in opt.items() if k not in ("name", "betas", "eps", "weight_decay")})
     if synthetic:
         pairs = _synthetic_pairs(eng.cfg, prompts, dev, seed)
     else:

@@ -135,9 +135,11 @@ def get_optimizer(name: str):
     if name == "lion":
         from .optim import Lion        # lion_pytorch.Lion's interface over the fused slh_lion kernel
         return Lion
-    if name.startswith("dadapt") or name.endswith("8bit") or name == "prodigy":
-        raise ValueError(f"optimizer {name} needs a package that is not installed in this image "
-                         f"(bitsandbytes / dadaptation / prodigyopt)")
+    if name == "prodigy":
+        from .optim import Prodigy     # prodigyopt.Prodigy's interface, tensor ops on the parameter's device
+        return Prodigy
+    if name.startswith("dadapt") or name.endswith("8bit"):
+        raise ValueError(f"optimizer {name} needs a package that is not installed in this image (dadaptation / bitsandbytes)")
     if name == "adam":
         return torch.optim.Adam
     if name == "adamw":

@@ -74,12 +74,15 @@ class SliderTrainer:
                  lr: float = 2e-4, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.01,
                  max_denoising_steps: int = 50, denoise_guidance: float = 3.0, process_group=None,
                  dedup_frozen: bool = True, prediction_type: str = "epsilon", optimizer: str = "adamw",
-                 noise_scheduler: str = "ddim", scheduler_seed: int = 0):
+                 noise_scheduler: str = "ddim", scheduler_seed: int = 0, optimizer_kwargs: Optional[dict] = None):
         self.eng, self.store = engine, store
         self.lr, self.betas, self.eps, self.wd = lr, betas, eps, weight_decay
-        if optimizer not in ("adamw", "adam", "lion"):
-            raise NotImplementedError(f"optimizer '{optimizer}': fused flat kernels exist for adam / adamw (slh_adamw) and lion (slh_lion)")
+        if optimizer not in ("adamw", "adam", "lion", "prodigy"):
+            raise NotImplementedError(f"optimizer '{optimizer}': fused flat kernels exist for adam / adamw (slh_adamw) and lion "
+                                      f"(slh_lion); prodigy runs as sliders_amd.optim.Prodigy on the flat parameter buffer")
         self.optimizer = optimizer
+        self.optimizer_kwargs = dict(optimizer_kwargs or {})
+        self._prodigy = None
         self.nsteps = max_denoising_steps
         self.denoise_guidance = denoise_guidance
         # train.noise_scheduler (model_util.py:230-277); v_prediction: pretrained_model.v_pred (model_util.py:126)
@@ -288,6 +291,19 @@ class SliderTrainer:
     def optimizer_step(self):
         st = self.store
         st.opt_step += 1
+        if self.optimizer == "prodigy":     # prodigyopt 1.0 over the flat bf16 parameter buffer (train_util.py:369-372)
+            if self._prodigy is None:
+                from .optim import Prodigy
+                kw = {k: v for k, v in self.optimizer_kwargs.items()}
+                if self.eps:
+                    kw.setdefault("eps", self.eps)
+                self._prodigy = Prodigy([st.params], lr=self.lr, betas=self.betas, weight_decay=self.wd, **kw)
+            self._prodigy.param_groups[0]["lr"] = self.lr
+            # the reference's gradients have the parameter dtype (bf16); grad_scale carries the 1/world of the all-reduce
+            st.params.grad = (st.grads * self.grad_scale).to(st.params.dtype)
+            self._prodigy.step()
+            st.params.grad = None
+            return
         if self.optimizer == "lion":        # one moment (store.exp_avg); lion_pytorch 0.1.2 op order
             d = lib.LionDesc(param=st.params.data_ptr(), exp_avg=st.exp_avg.data_ptr(), grad=st.grads.data_ptr(), n=st.numel,
                              lr=self.lr, beta1=self.betas[0], beta2=self.betas[1], weight_decay=self.wd,

@@ -365,11 +365,15 @@ def test_optimizer_options_and_rejections():
     assert optimizer_options(_cfg(optimizer="Lion").train) == {"betas": (0.9, 0.99), "weight_decay": 0.0, "eps": 0.0, "name": "lion"}
     assert optimizer_options(_cfg(optimizer="lion", optimizer_args="weight_decay=0.02 betas=(0.95,0.98)").train)["betas"] == (0.95, 0.98)
     for bad in (dict(optimizer="lion", optimizer_args="eps=1e-6"), dict(optimizer="lion", optimizer_args="use_triton=True"),
-                dict(optimizer="prodigy"), dict(optimizer="adam8bit"), dict(optimizer="dadaptlion"),
+                dict(optimizer="prodigy", optimizer_args="amsgrad=True"), dict(optimizer="adam8bit"), dict(optimizer="dadaptlion"),
                 dict(optimizer="adam", optimizer_args="weight_decay=0.01"), dict(optimizer_args="amsgrad=True"),
                 dict(precision="float32"), dict(precision="fp16"), dict(lr_scheduler="linear")):
         with pytest.raises(NotImplementedError):
             check_supported(_cfg(**bad))
+    # prodigyopt.Prodigy's arguments and defaults (requirements.txt: prodigyopt==1.0), lr = 1 is the user's business
+    o = optimizer_options(_cfg(optimizer="Prodigy", optimizer_args="weight_decay=0.01 d_coef=2.0 safeguard_warmup=True").train)
+    assert o["name"] == "prodigy" and o["weight_decay"] == 0.01 and o["d_coef"] == 2.0 and o["safeguard_warmup"] is True
+    assert o["d0"] == 1e-6 and o["betas"] == (0.9, 0.999) and o["decouple"] is True and o["growth_rate"] == float("inf")
     for name in ("ddim", "ddpm", "lms", "euler_a"):      # model_util.py:230-277: all four for text sliders
         check_supported(_cfg(noise_scheduler=name))
     check_supported(_cfg(), image_slider=True)
