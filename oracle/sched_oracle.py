@@ -116,3 +116,19 @@ def lms_run(x, model_outs, n, prediction_type="epsilon", order=4):
         x = x + sum(cj * dj for cj, dj in zip(c, reversed(derivs)))
         xs.append(x)
     return xs
+
+
+# ---- Euler (deterministic), "leading" spacing with steps_offset: the SDXL checkpoints' scheduler_config -----------
+def leading_timesteps(n, offset=1):
+    return (np.arange(n) * (T // n))[::-1].astype(np.float64) + offset
+
+
+def leading_sigma_schedule(n, offset=1):
+    s = np.interp(leading_timesteps(n, offset), np.arange(T), sigmas_train())
+    return np.concatenate([s, [0.0]])
+
+
+def euler_step(x, model_out, i, sig, prediction_type="epsilon"):
+    """k-diffusion sample_euler with s_churn = 0: x + d * (sigma_next - sigma), d = (x - x0) / sigma"""
+    s = sig[i]
+    return x + (x - _x0(x, model_out, s, prediction_type)) / s * (sig[i + 1] - s)

@@ -45,7 +45,7 @@ for sched, opt, lr in (("ddpm", "adamw", 2e-4), ("euler_a", "adamw", 2e-4), ("lm
 store = LoraStore(cfg, rank=4, alpha=1.0, train_method="noxattn", device=dev)
 eng = UNetEngine(cfg, sd, dev)
 ctx, pooled = cat(emb["target"]), pc(pool["target"])
-for name in ("ddim", "lms", "euler_a", "ddpm"):
+for name in ("ddim", "lms", "euler", "euler_a", "ddpm"):
     smp = SliderSampler(eng, store, scheduler=name)
     lat = smp.sample_latents(ctx, torch.randn(1, 4, hw, hw, generator=torch.Generator().manual_seed(1)).to(dev), scale=1.0,
                              start_noise=750, ddim_steps=20, guidance_scale=7.5, pooled=pooled)

@@ -46,8 +46,9 @@ def build_parser() -> argparse.ArgumentParser:
     p.add_argument("--start_noise", type=int, default=750)
     p.add_argument("--ddim_steps", type=int, default=50)
     p.add_argument("--guidance_scale", type=float, default=7.5)
-    p.add_argument("--scheduler", default="ddim", choices=["ddim", "lms", "euler_a", "ddpm"],
-                   help="ddim: fused HIP step; lms is what eval-scripts/generate_images_sd1.py:51 constructs")
+    p.add_argument("--scheduler", default="ddim", choices=["ddim", "lms", "euler", "euler_a", "ddpm"],
+                   help="ddim: fused HIP step; lms: what eval-scripts/generate_images_sd1.py:51 constructs; euler: the SDXL "
+                        "checkpoints' scheduler_config (generate_images_xl.py)")
     p.add_argument("--res", type=int, default=None)
     p.add_argument("--seed", type=int, default=0)
     p.add_argument("--device", type=int, default=0)

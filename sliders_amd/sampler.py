@@ -32,13 +32,17 @@ from .vae import VaeDecoder
 class SliderSampler:
     def __init__(self, engine: UNetEngine, store: Optional[LoraStore] = None, decoder: Optional[VaeDecoder] = None,
                  prediction_type: str = "epsilon", scheduler: str = "ddim", scheduler_seed: int = 0):
-        """scheduler: "ddim" (fused HIP step; what the notebooks' pipelines are given), or "lms" (the scheduler
-        eval-scripts/generate_images_sd1.py:51 constructs), "euler_a", "ddpm" from sliders_amd/schedulers.py."""
+        """scheduler: "ddim" (fused HIP step), "lms" (what eval-scripts/generate_images_sd1.py:51 and the SD-1 notebook
+        construct), "euler" (the SDXL checkpoints' scheduler_config: what generate_images_xl.py's pipeline runs), "euler_a",
+        "ddpm" - the non-DDIM ones from sliders_amd/schedulers.py."""
         self.eng, self.store, self.decoder = engine, store, decoder
         if store is not None and engine.lora is not store:
             engine.attach_lora(store)
         if scheduler.lower().replace(" ", "_") == "ddim":
             self.sched = DDIMSchedule(prediction_type=prediction_type)
+        elif scheduler.lower() == "euler":     # the SDXL checkpoints' own scheduler (generate_images_xl.py pipelines)
+            self.sched = schedulers.EulerDiscreteScheduler(prediction_type=prediction_type)
+            self.sched_generator = None
         else:
             self.sched = schedulers.create(scheduler, prediction_type)
             self.sched_generator = torch.Generator(device=engine.device)

@@ -112,9 +112,16 @@ class _SigmaBase(_Base):
         self.set_timesteps(self.num_train_timesteps)
         self.num_inference_steps = None
 
+    timestep_spacing = "linspace"
+    steps_offset = 0
+
     def set_timesteps(self, n: int, device=None):
         self.num_inference_steps = n
-        timesteps = np.linspace(0, self.num_train_timesteps - 1, n, dtype=float)[::-1].copy()
+        if self.timestep_spacing == "linspace":
+            timesteps = np.linspace(0, self.num_train_timesteps - 1, n, dtype=float)[::-1].copy()
+        else:       # "leading" (+ steps_offset): what the SDXL checkpoints' scheduler_config.json selects
+            ratio = self.num_train_timesteps // n
+            timesteps = (np.arange(0, n) * ratio).round()[::-1].copy().astype(float) + self.steps_offset
         sigmas = (((1 - self.alphas_cumprod) / self.alphas_cumprod) ** 0.5).numpy()
         sigmas = np.interp(timesteps, np.arange(0, len(sigmas)), sigmas)
         sigmas = np.concatenate([sigmas, [0.0]]).astype(np.float32)
@@ -128,7 +135,9 @@ class _SigmaBase(_Base):
 
     @property
     def init_noise_sigma(self):
-        return self.sigmas.max()
+        if self.timestep_spacing in ("linspace", "trailing"):
+            return self.sigmas.max()
+        return (self.sigmas.max() ** 2 + 1) ** 0.5
 
     def index_of(self, timestep) -> int:
         hit = (self.timesteps == float(timestep)).nonzero()
@@ -165,6 +174,27 @@ class EulerAncestralDiscreteScheduler(_SigmaBase):
             noise = self._randn(model_output, generator)
         prev_sample = prev_sample + noise * sigma_up
         return SchedulerOutput(prev_sample, pred_original_sample)
+
+
+class EulerDiscreteScheduler(_SigmaBase):
+    """The scheduler the SDXL pipelines of generate_images_xl.py / XL-sliders-inference.ipynb run with (it comes from the
+    checkpoint's scheduler_config.json: EulerDiscreteScheduler, timestep_spacing "leading", steps_offset 1); s_churn = 0,
+    i.e. the deterministic Euler step.  Not one of train.noise_scheduler's names - inference only (SliderSampler)."""
+
+    def __init__(self, *a, timestep_spacing: str = "leading", steps_offset: int = 1, **k):
+        if timestep_spacing not in ("linspace", "leading"):
+            raise ValueError(f"timestep_spacing {timestep_spacing!r}: linspace and leading are implemented")
+        self.timestep_spacing, self.steps_offset = timestep_spacing, steps_offset
+        super().__init__(*a, **k)
+
+    def step(self, model_output: torch.Tensor, timestep, sample: torch.Tensor, generator=None, noise=None) -> SchedulerOutput:
+        step_index = self.index_of(timestep)
+        sigma = self.sigmas[step_index]
+        sigma_hat = sigma                      # gamma = 0 (s_churn = 0): no noise is mixed in
+        pred_original_sample = self._pred_original(model_output, sample, sigma_hat)
+        derivative = (sample - pred_original_sample) / sigma_hat
+        dt = self.sigmas[step_index + 1] - sigma_hat
+        return SchedulerOutput(sample + derivative * dt, pred_original_sample)
 
 
 class LMSDiscreteScheduler(_SigmaBase):

@@ -219,3 +219,28 @@ def test_denoise_loop_euler_matches_the_float64_oracle():
 
     got = S.denoise(sch, predict, _t(x0), k, n)
     np.testing.assert_allclose(got.numpy(), x, rtol=5e-4, atol=5e-4)
+
+
+@pytest.mark.parametrize("pred", PRED)
+def test_sdxl_euler_scheduler_tables_and_steps(pred):
+    """EulerDiscreteScheduler as the SDXL checkpoints configure it (leading spacing, steps_offset 1)"""
+    n = 50
+    sch = S.EulerDiscreteScheduler(prediction_type=pred)
+    sch.set_timesteps(n)
+    assert sch.timesteps[0] == 981.0 and sch.timesteps[-1] == 1.0 and len(sch.timesteps) == n
+    sig = so.leading_sigma_schedule(n)
+    np.testing.assert_allclose(sch.sigmas.numpy(), sig, rtol=2e-5, atol=1e-7)
+    np.testing.assert_allclose(float(sch.init_noise_sigma), np.sqrt(sig.max() ** 2 + 1), rtol=1e-5)
+    x, m, _ = _rand(21)
+    x = x * float(sch.init_noise_sigma)
+    for i in (0, 10, 49):
+        got = sch.step(_t(m), sch.timesteps[i], _t(x)).prev_sample
+        np.testing.assert_allclose(got.numpy(), so.euler_step(x, m, i, sig, pred), rtol=2e-4, atol=3e-5)
+    # epsilon prediction: the step is x + eps * (sigma_next - sigma), so a full run with eps = x / sigma_0 scales x by sigma/sigma_0
+    if pred == "epsilon":
+        y = _t(x)
+        for i in range(n):
+            y = sch.step(y / sch.sigmas[i], sch.timesteps[i], y).prev_sample
+        assert float(y.abs().max()) < 1e-4
+    with pytest.raises(ValueError):
+        S.EulerDiscreteScheduler(timestep_spacing="trailing")
