@@ -149,9 +149,12 @@ def check_supported(config: config_util.RootConfig, image_slider: bool = False):
     name = t.noise_scheduler.lower().replace(" ", "_")
     if name not in ("ddim", "ddpm", "lms", "euler_a"):            # model_util.py:230-277
         raise ValueError(f"Unknown scheduler name: {name}")
-    if image_slider and name != "ddim":
+    if image_slider and name not in ("ddim", "ddpm"):
+        # the image-slider loop never calls scheduler.step (imagesliders/train_util.py:200-235 uses .timesteps and .add_noise
+        # only): "ddpm" has the same leading timestep grid and the same add_noise as "ddim", so both run the fused
+        # alpha-table noising step; lms / euler_a noise in sigma space (x + sigma * noise, scaled model input)
         raise NotImplementedError(f"train.noise_scheduler '{t.noise_scheduler}': the image-slider noising step (get_noisy_image, "
-                                  f"fused with the VAE encode) is built on the DDIM alpha table; text sliders accept ddpm / lms / euler_a")
+                                  f"fused with the VAE encode) is built on the ddim / ddpm alpha table; text sliders also accept lms / euler_a")
     optimizer_options(t)
     LrSchedule(t.lr_scheduler, t.lr, t.iterations)
 

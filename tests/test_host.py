@@ -377,6 +377,7 @@ def test_optimizer_options_and_rejections():
     for name in ("ddim", "ddpm", "lms", "euler_a"):      # model_util.py:230-277: all four for text sliders
         check_supported(_cfg(noise_scheduler=name))
     check_supported(_cfg(), image_slider=True)
+    check_supported(_cfg(noise_scheduler="ddpm"), image_slider=True)     # same timestep grid and add_noise as ddim, no .step()
     with pytest.raises(NotImplementedError):             # image sliders: the fused noising step is DDIM-table only
         check_supported(_cfg(noise_scheduler="euler_a"), image_slider=True)
     with pytest.raises(ValueError):
