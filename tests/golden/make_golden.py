@@ -17,7 +17,10 @@ the GPU box, so these fixtures are how the oracle and the HIP path are pinned to
                         conv leaves included)                                               <- lora.py:68-97, 206-216
   schema.json           the reference's pydantic parse of tests/golden/{config,prompts}_sample.yaml
                                                                                            <- config_util.py, prompt_util.py
-Run:  python tests/golden/make_golden.py [census|tiny_forward|loss|schema|lora_init ...]   (needs /root/reference; not run
+  host_helpers.json     get_random_resolution_in_bucket / get_add_time_ids(dynamic_crops) / get_initial_latents /
+                        concat_embeddings under fixed seeds and the lr sequences of get_lr_scheduler
+                                                                                           <- train_util.py:20-57,136-141,298-419
+Run:  python tests/golden/make_golden.py [census|tiny_forward|loss|schema|lora_init|host_helpers ...]   (needs /root/reference; not run
       on the GPU box)
 """
 import contextlib
@@ -157,13 +160,6 @@ def schema():
     print("schema: ok", len(pr_plain), len(pr_attr))
 
 
-if __name__ == "__main__":
-    census()
-    tiny_forward()
-    loss()
-    schema()
-
-
 def lora_init():
     """Seeded initial adapter weights of the reference's own network (RNG order incl. the duplicate conv visits)."""
     out = {}
@@ -182,7 +178,44 @@ def lora_init():
         json.dump(out, f, indent=0, sort_keys=True)
 
 
+def host_helpers():
+    """The reference's host-side helpers of the loop under fixed seeds (train_util.py:20-57, 136-141, 298-333, 376-419):
+    which RNG they consume, in which order, and what they return."""
+    import types
+    out = {}
+    for seed in (0, 1, 7):
+        torch.manual_seed(seed)
+        out[f"bucket/{seed}"] = [list(reftrain.get_random_resolution_in_bucket(b)) for b in (512, 1024, 512, 768, 1024)]
+        torch.manual_seed(seed)
+        out[f"time_ids_dynamic/{seed}"] = [reftrain.get_add_time_ids(h, w, dynamic_crops=True).tolist()
+                                           for h, w in ((512, 512), (1024, 1024), (768, 512))]
+    out["time_ids_static"] = reftrain.get_add_time_ids(1024, 768, dynamic_crops=False).tolist()
+    out["time_ids_bf16"] = reftrain.get_add_time_ids(1000, 1001, dtype=torch.bfloat16).float().tolist()
+    g = torch.Generator().manual_seed(3)
+    sched = types.SimpleNamespace(init_noise_sigma=2.5)
+    lat = reftrain.get_initial_latents(sched, 2, 64, 96, 3, generator=g)
+    out["initial_latents"] = {"shape": list(lat.shape), "sum": float(lat.double().sum()), "first": float(lat.flatten()[0]),
+                              "repeat_equal": bool(torch.equal(lat[:2], lat[2:4]))}
+    a, b = torch.arange(6.0).view(1, 2, 3), 10 + torch.arange(6.0).view(1, 2, 3)
+    out["concat_embeddings"] = reftrain.concat_embeddings(a, b, 2).tolist()
+    # LR schedules (train_util.py:376-404): the lr the optimizer sees at iteration i, lr 2e-4, 1000 iterations
+    for name in ("constant", "cosine", "cosine_with_restarts", "step"):
+        p = torch.nn.Parameter(torch.zeros(1))
+        opt = torch.optim.AdamW([p], lr=2e-4)
+        sch = reftrain.get_lr_scheduler(name, opt, max_iterations=1000, lr_min=2e-4 / 100)
+        lrs = []
+        for i in range(1000):
+            lrs.append(opt.param_groups[0]["lr"])
+            opt.step()
+            sch.step()
+        out[f"lr/{name}"] = [lrs[i] for i in (0, 1, 9, 10, 99, 100, 101, 299, 300, 500, 699, 700, 999)]
+    with open(os.path.join(HERE, "host_helpers.json"), "w") as f:
+        json.dump(out, f, indent=0, sort_keys=True)
+    print("host_helpers:", sorted(out))
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["census", "tiny_forward", "loss", "schema", "lora_init"]
+    which = sys.argv[1:] or ["census", "tiny_forward", "loss", "schema", "lora_init", "host_helpers"]
     for w in which:
-        {"census": census, "tiny_forward": tiny_forward, "loss": loss, "schema": schema, "lora_init": lora_init}[w]()
+        {"census": census, "tiny_forward": tiny_forward, "loss": loss, "schema": schema, "lora_init": lora_init,
+         "host_helpers": host_helpers}[w]()

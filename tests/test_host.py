@@ -465,3 +465,36 @@ def test_generate_parses_the_slider_file_name_like_the_notebooks():
     assert parse_slider_name("unnamed.pt") == (4, 1.0, "noxattn")
     a = build_parser().parse_args(["--scales=-2,0,2", "--start_noise", "800", "--synthetic"])
     assert a.start_noise == 800 and a.ddim_steps == 50 and a.guidance_scale == 7.5
+
+
+def test_host_helpers_match_the_reference_run():
+    """tests/golden/host_helpers.json is the output of the reference's own train_util.py under fixed seeds
+    (tests/golden/make_golden.py host_helpers): the same RNG consumption, order and results here
+    (train_util.py:20-57, 136-141, 298-333, 376-419)."""
+    import json
+    import types
+    from sliders_amd import train_util as tu
+    from sliders_amd.cli import LrSchedule
+    gold = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "host_helpers.json")))
+    for seed in (0, 1, 7):
+        torch.manual_seed(seed)
+        assert [list(tu.get_random_resolution_in_bucket(b)) for b in (512, 1024, 512, 768, 1024)] == gold[f"bucket/{seed}"]
+        torch.manual_seed(seed)
+        got = [tu.get_add_time_ids(h, w, dynamic_crops=True).tolist() for h, w in ((512, 512), (1024, 1024), (768, 512))]
+        assert got == gold[f"time_ids_dynamic/{seed}"]
+    assert tu.get_add_time_ids(1024, 768, dynamic_crops=False).tolist() == gold["time_ids_static"]
+    assert tu.get_add_time_ids(1000, 1001, dtype=torch.bfloat16).float().tolist() == gold["time_ids_bf16"]     # quirk D.8
+    lat = tu.get_initial_latents(types.SimpleNamespace(init_noise_sigma=2.5), 2, 64, 96, 3, generator=torch.Generator().manual_seed(3))
+    g = gold["initial_latents"]
+    assert list(lat.shape) == g["shape"] and float(lat.double().sum()) == g["sum"] and float(lat.flatten()[0]) == g["first"]
+    assert torch.equal(lat[:2], lat[2:4]) == g["repeat_equal"]
+    a, b = torch.arange(6.0).view(1, 2, 3), 10 + torch.arange(6.0).view(1, 2, 3)
+    assert tu.concat_embeddings(a, b, 2).tolist() == gold["concat_embeddings"]
+    idx = (0, 1, 9, 10, 99, 100, 101, 299, 300, 500, 699, 700, 999)
+    for name in ("constant", "cosine", "cosine_with_restarts", "step"):
+        s = LrSchedule(name, 2e-4, 1000)
+        lrs = []
+        for i in range(1000):
+            lrs.append(s.current())
+            s.step()
+        assert [lrs[i] for i in idx] == gold[f"lr/{name}"], name
