@@ -98,7 +98,10 @@ def train(config, prompts, device: int, xl: bool, folder_main: str, folders, sca
         vae = load_vae_encoder(config.pretrained_model.name_or_path, dev, xl)
     torch.manual_seed(seed)
     store = LoraStore(eng.cfg, rank=config.network.rank, alpha=config.network.alpha,
-                      train_method=config.network.training_method, network_type="c3lier", device=dev, kaiming_a=5 ** 0.5)
+                      train_method=config.network.training_method,
+                      # train_lora-scale-xl.py:61-63: conv targets only for network.type c3lier; imagesliders/lora.py's list
+                      network_type="c3lier-image" if config.network.type == "c3lier" else "lierla", device=dev,
+                      kaiming_a=5 ** 0.5)
     opt = optimizer_options(config.train)
     hw = size // 8
     tr = ImageSliderTrainer(eng, store, vae, hw, hw, batch_size=1, lr=config.train.lr, betas=opt["betas"], eps=opt["eps"],

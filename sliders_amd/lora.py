@@ -39,10 +39,11 @@ class LoRANetwork:
         self.lora_dim = rank
         self.alpha = alpha
         self.unet = unet
-        c3lier = any(c in DEFAULT_TARGET_REPLACE for c in UNET_TARGET_REPLACE_MODULE_CONV)
-        self.store = LoraStore(unet.cfg, rank=rank, alpha=alpha, train_method=train_method,
-                               network_type="c3lier" if c3lier else "lierla", device=unet.device,
-                               kaiming_a=kaiming_a)
+        conv = [c for c in UNET_TARGET_REPLACE_MODULE_CONV if c in DEFAULT_TARGET_REPLACE]
+        # the image sliders' list has no DownBlock2D / UpBlock2D (imagesliders/lora.py:19-25): same leaves, one RNG draw each
+        ntype = "lierla" if not conv else ("c3lier" if "DownBlock2D" in conv else "c3lier-image")
+        self.store = LoraStore(unet.cfg, rank=rank, alpha=alpha, train_method=train_method, network_type=ntype,
+                               device=unet.device, kaiming_a=kaiming_a)
         self.unet_loras = self.store.entries
         print(f"create LoRA for U-Net: {len(self.unet_loras)} modules.")
         unet.attach_lora(self.store)

@@ -199,6 +199,10 @@ def build_tree(cfg: UNetConfig) -> Node:
 # ---- the reference's target selection, restated (lora.py:15-30, 164-218) -----------------------------
 UNET_TARGET_REPLACE_MODULE_TRANSFORMER = ["Attention"]
 UNET_TARGET_REPLACE_MODULE_CONV = ["ResnetBlock2D", "Downsample2D", "Upsample2D", "DownBlock2D", "UpBlock2D"]
+# trainscripts/imagesliders/lora.py:19-25 comments the two block classes out: the same leaves are reached (every conv under
+# a DownBlock2D / UpBlock2D also sits under a ResnetBlock2D / Downsample2D / Upsample2D), but none twice - so the image
+# sliders' network construction draws the RNG once per leaf, not once per visit (network_type "c3lier-image")
+UNET_TARGET_REPLACE_MODULE_CONV_IMAGE = ["ResnetBlock2D", "Downsample2D", "Upsample2D"]
 LORA_PREFIX_UNET = "lora_unet"
 TRAINING_METHODS = ("noxattn", "innoxattn", "selfattn", "xattn", "full", "xattn-strict", "noxattn-hspace",
                     "noxattn-hspace-last")
@@ -231,6 +235,10 @@ def lora_visits(cfg: UNetConfig, train_method: str, rank: int = 4, network_type:
     targets_cls = list(UNET_TARGET_REPLACE_MODULE_TRANSFORMER)
     if network_type == "c3lier":
         targets_cls += UNET_TARGET_REPLACE_MODULE_CONV
+    elif network_type == "c3lier-image":
+        targets_cls += UNET_TARGET_REPLACE_MODULE_CONV_IMAGE
+    elif network_type != "lierla":
+        raise ValueError(f"network type {network_type!r}: lierla, c3lier (text sliders) or c3lier-image (image sliders)")
     root = build_tree(cfg)
     out, names = [], set()
     for name, module in root.named_modules():

@@ -20,7 +20,9 @@ the GPU box, so these fixtures are how the oracle and the HIP path are pinned to
   host_helpers.json     get_random_resolution_in_bucket / get_add_time_ids(dynamic_crops) / get_initial_latents /
                         concat_embeddings under fixed seeds and the lr sequences of get_lr_scheduler
                                                                                            <- train_util.py:20-57,136-141,298-419
-Run:  python tests/golden/make_golden.py [census|tiny_forward|loss|schema|lora_init|host_helpers ...]   (needs /root/reference; not run
+  lora_init_image.json  the IMAGE sliders' LoRANetwork (trainscripts/imagesliders/lora.py) under torch.manual_seed(1234):
+                        module order + seeded lora_down weights                            <- imagesliders/lora.py:19-25,96,150-216
+Run:  python tests/golden/make_golden.py [census|tiny_forward|loss|schema|lora_init|host_helpers|lora_init_image ...]   (needs /root/reference; not run
       on the GPU box)
 """
 import contextlib
@@ -178,6 +180,36 @@ def lora_init():
         json.dump(out, f, indent=0, sort_keys=True)
 
 
+def lora_init_image():
+    """The IMAGE sliders' network (trainscripts/imagesliders/lora.py: conv target list without DownBlock2D / UpBlock2D, no
+    name de-duplication, kaiming a = sqrt(5)) under torch.manual_seed(1234): module order and seeded initial weights."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("reflora_image", "/root/reference/trainscripts/imagesliders/lora.py")
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    out = {}
+    for name in ("tiny_sdxl", "tiny_sd1"):
+        for method, ntype in (("noxattn", "c3lier"), ("full", "c3lier"), ("noxattn", "lierla")):
+            # DEFAULT_TARGET_REPLACE aliases UNET_TARGET_REPLACE_MODULE_TRANSFORMER (lora.py:29) and train_lora-scale-xl.py:61-63
+            # extends it in place for c3lier: reset to the literal before every build
+            mod.DEFAULT_TARGET_REPLACE[:] = ["Attention"]
+            if ntype == "c3lier":
+                mod.DEFAULT_TARGET_REPLACE += mod.UNET_TARGET_REPLACE_MODULE_CONV
+            net = build_unet(name, seed=0)
+            torch.manual_seed(1234)
+            nw = quiet(mod.LoRANetwork, net, rank=4, multiplier=1.0, alpha=1.0, train_method=method)
+            names = [m.lora_name for m in nw.unet_loras]
+            assert len(names) == len(set(names))
+            ent = {"order": names}
+            for m in nw.unet_loras:
+                w = m.lora_down.weight.detach().to(torch.bfloat16).float()
+                ent[m.lora_name] = [float(w.sum()), float(w.flatten()[0]), float(w.flatten()[-1])]
+            out[f"{name}/{method}/{ntype}"] = ent
+    with open(os.path.join(HERE, "lora_init_image.json"), "w") as f:
+        json.dump(out, f, indent=0, sort_keys=True)
+    print("lora_init_image:", {k: len(v) - 1 for k, v in out.items()})
+
+
 def host_helpers():
     """The reference's host-side helpers of the loop under fixed seeds (train_util.py:20-57, 136-141, 298-333, 376-419):
     which RNG they consume, in which order, and what they return."""
@@ -215,7 +247,7 @@ def host_helpers():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["census", "tiny_forward", "loss", "schema", "lora_init", "host_helpers"]
+    which = sys.argv[1:] or ["census", "tiny_forward", "loss", "schema", "lora_init", "host_helpers", "lora_init_image"]
     for w in which:
         {"census": census, "tiny_forward": tiny_forward, "loss": loss, "schema": schema, "lora_init": lora_init,
-         "host_helpers": host_helpers}[w]()
+         "host_helpers": host_helpers, "lora_init_image": lora_init_image}[w]()

@@ -311,3 +311,26 @@ def test_prodigy_argument_checks_and_get_optimizer():
     for name in ("dadaptadam", "adam8bit"):
         with pytest.raises(ValueError):
             get_optimizer(name)
+
+
+@pytest.mark.parametrize("name", ["tiny_sdxl", "tiny_sd1"])
+@pytest.mark.parametrize("method,ntype", [("noxattn", "c3lier"), ("full", "c3lier"), ("noxattn", "lierla")])
+def test_image_slider_network_order_and_seeded_init(name, method, ntype):
+    """The image sliders build their network with trainscripts/imagesliders/lora.py: conv target list WITHOUT DownBlock2D /
+    UpBlock2D (no duplicate visits, so one RNG draw per leaf), kaiming a = sqrt(5).  Golden: that file's own LoRANetwork
+    under torch.manual_seed(1234) (tests/golden/make_golden.py::lora_init_image); here: what cli_image.py constructs."""
+    gold = json.load(open(os.path.join(G, "lora_init_image.json")))[f"{name}/{method}/{ntype}"]
+    cfg = CONFIGS[name]()
+    torch.manual_seed(1234)
+    s = LoraStore(cfg, train_method=method, network_type="c3lier-image" if ntype == "c3lier" else "lierla", kaiming_a=5 ** 0.5)
+    assert [e.name for e in s.entries] == gold["order"]
+    sd = s.state_dict()
+    for nm in gold["order"]:
+        w = sd[nm + ".lora_down.weight"].float()
+        assert [float(w.sum()), float(w.flatten()[0]), float(w.flatten()[-1])] == gold[nm], nm
+        assert sd[nm + ".lora_up.weight"].abs().max() == 0
+    if ntype == "c3lier":       # same leaves as the text sliders' list, different RNG consumption
+        torch.manual_seed(1234)
+        t = LoraStore(cfg, train_method=method, network_type="c3lier", kaiming_a=5 ** 0.5)
+        assert [e.name for e in t.entries] == gold["order"]
+        assert not torch.equal(t.params, s.params)
