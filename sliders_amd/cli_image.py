@@ -130,9 +130,12 @@ def train(config, prompts, device: int, xl: bool, folder_main: str, folders, sca
             im = ims[pyrng.randint(0, len(ims) - 1)]
             img_low = open_image(f"{folder_main}/{folder1}/{im}", size)
             img_high = open_image(f"{folder_main}/{folder2}/{im}", size)
-        g = torch.Generator().manual_seed(pyrng.randint(0, 2 * 15))         # the reference's seed range (quirk D.12)
-        post_noise = torch.randn(1, 4, hw, hw, generator=g)                # one seed for both images: same draws
-        noise = torch.randn(1, 4, hw, hw, generator=g)
+        # one seed for both images, so both get the same draws (train_lora-scale-xl.py:222-246; seed range = quirk D.12).
+        # In the reference the diffusion noise is the FIRST draw of the re-seeded CPU generator (randn_tensor with the
+        # generator torch.manual_seed returned), while latent_dist.sample(None) draws from the device's own stream.
+        img_seed = pyrng.randint(0, 2 * 15)
+        noise = torch.randn(1, 4, hw, hw, generator=torch.Generator().manual_seed(img_seed))
+        post_noise = torch.randn(1, 4, hw, hw, generator=torch.Generator().manual_seed(img_seed + (1 << 20)))
         lr = sched.current()
         lh, ll = tr.iteration(pair, k, img_low.to(dev), img_high.to(dev), float(scale_to_look), post_noise.to(dev),
                               noise.to(dev), lr=lr)
