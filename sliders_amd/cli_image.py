@@ -20,6 +20,7 @@ import numpy as np
 import torch
 
 from . import config_util, prompt_util
+from .train_util import get_add_time_ids, get_random_resolution_in_bucket
 from .cli import LrSchedule, _encoded_pairs, _synthetic_pairs, check_model_files, check_supported, optimizer_options
 from .image_trainer import ImageSliderTrainer
 from .lora_store import LoraStore
@@ -136,9 +137,19 @@ def train(config, prompts, device: int, xl: bool, folder_main: str, folders, sca
         img_seed = pyrng.randint(0, 2 * 15)
         noise = torch.randn(1, 4, hw, hw, generator=torch.Generator().manual_seed(img_seed))
         post_noise = torch.randn(1, 4, hw, hw, generator=torch.Generator().manual_seed(img_seed + (1 << 20)))
+        # micro-conditioning from the PROMPT's resolution (bucketed when dynamic_resolution), not from the fixed image
+        # size, with optional dynamic crops, in bf16 like the reference (train_lora-scale-xl.py:196-200, 249-254; quirk D.8)
+        time_ids = None
+        if eng.cfg.is_xl:
+            height = width = s.resolution
+            if s.dynamic_resolution:
+                height, width = get_random_resolution_in_bucket(s.resolution)
+            if s.dynamic_crops or (height, width) != (size, size):
+                ids = get_add_time_ids(height, width, dynamic_crops=s.dynamic_crops, dtype=torch.bfloat16)
+                time_ids = ids.float().repeat(2, 1)
         lr = sched.current()
         lh, ll = tr.iteration(pair, k, img_low.to(dev), img_high.to(dev), float(scale_to_look), post_noise.to(dev),
-                              noise.to(dev), lr=lr)
+                              noise.to(dev), lr=lr, time_ids=time_ids)
         sched.step()
         if rank == 0 and (i % 10 == 0 or config.logging.verbose):
             print(f"it {i} k={k} scale={scale_to_look} lr={lr:.3e} Loss*1k: high {lh.item() * 1000:.4f} low {ll.item() * 1000:.4f}")
