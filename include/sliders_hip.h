@@ -81,19 +81,23 @@ typedef struct slh_gemm_desc {
                                 in memory, so every LDS-DMA instruction reads 1 KB of consecutive addresses); ldw unused */
     int32_t reserved_;       /* 0.  Non-zero values are profiling ablations (scripts/probe_gemm.py): 1 skip tile refills,
                                 2 skip MFMA work, 4 skip the epilogue, 8 skip the first fill, 16 return at once */
-    float* splitk_c32;       /* split-K workspace or NULL: [M][N] fp32, ZERO on entry.  With tile bits 16-19 = S > 1 the K
-                                range is cut into S slices, each workgroup adds its partial tile here with fp32 atomics and
-                                a second launch applies the epilogue (bias, rowbias, LoRA, residual) and writes c.  For the
-                                few-row, long-K products (1280-channel 3x3 convolutions at 8x8 / 16x16: 10-40 output tiles on
-                                256 CUs, 29 MB of weights each) this is what fills the chip. */
-    float* splitk_t32;       /* with lora_down: [M][ld_t] fp32, ZERO on entry, receives T (lora_t_out may alias it) */
+    float* splitk_c32;       /* split-K workspace or NULL: [splitk_slabs][M][N] fp32, any contents.  With tile bits 16-19 =
+                                S > 1 the K range is cut into S slices; each slice's workgroups write their partial tiles to
+                                slab number <slice> (plain stores - no fp32 atomics, whose arrival-order sums make a pass
+                                differ from run to run) and a second launch adds the slabs IN SLICE ORDER, applies the
+                                epilogue (bias, rowbias, LoRA, residual) and writes c.  For the few-row, long-K products
+                                (1280-channel 3x3 convolutions at 8x8 / 16x16: 10-40 output tiles on 256 CUs, 29 MB of
+                                weights each) this is what fills the chip. */
+    float* splitk_t32;       /* with lora_down and S > 1: [2*splitk_slabs][M][ld_t] fp32 slabs of the adapter's T (two
+                                per slice); the second launch reduces them and, if lora_t_out is set, writes T there */
     void* vt_out;            /* optional: the columns >= vt_col0 of the result (the V third of a fused q|k|v projection,
                                 diffusers Attention.to_v) are written HEAD-TRANSPOSED for slh_attn_fwd instead of into c:
                                 vt_out[((b*vt_heads + h)*Dp + d)*vt_ld + t] = C[b*vt_tokens + t][vt_col0 + h*vt_D + d],
                                 Dp = 64*ceil(vt_D/64) - exactly what slh_transpose_heads would produce from c, without
                                 the extra launch and the round trip of V through HBM.  Needs vt_D % 64 == 0 (no padded
                                 rows), vt_col0 % 128 == 0, vt_tokens % 8 == 0, M % 8 == 0; not with geglu / split-K */
-    int32_t vt_col0, vt_D, vt_heads, vt_tokens, vt_ld, vt_pad_;
+    int32_t vt_col0, vt_D, vt_heads, vt_tokens, vt_ld;
+    int32_t splitk_slabs;    /* slabs splitk_c32 holds (>= the S of tile) */
 } slh_gemm_desc;
 int slh_gemm(const slh_gemm_desc* d, slh_stream_t stream);
 /* (WM<<12)|(MI<<8)|(NI<<4)|mode of the kernel instantiation gemm_kernel<MI,NI,mode,..,WM> slh_gemm would launch for d
@@ -148,24 +152,30 @@ int slh_gemv(const slh_gemv_desc* d, slh_stream_t stream);
 typedef struct slh_gn_desc {
     const void* x0; const void* x1;
     const void* gamma; const void* beta; /* [C] bf16 */
-    float* stats;            /* [batch][groups][2] fp32 */
+    float* stats;            /* [batch][groups][2] fp32: (mean, rstd), written by slh_gn_stats */
     void* y;                 /* [batch*hw][ldy] bf16 */
     int32_t ldx0, ldx1, c0, c1;
     int32_t batch, hw, groups, ldy;
     float eps;
     int32_t act;             /* 0 none, 1 SiLU */
+    /* slh_gn_stats only.  The reduction is done in a fixed order (bit-reproducible, no fp32 atomics): every workgroup
+     * publishes one (sum, sum of squares) pair per group and the last one to arrive combines them in index order. */
+    float* partial;          /* [batch][slh_gn_row_blocks(c0+c1, hw, groups)][groups][2] fp32 scratch, any contents */
+    uint32_t* ticket;        /* [batch] arrival counters, ZERO before the launch (left zero by it) */
 } slh_gn_desc;
 int slh_gn_stats(const slh_gn_desc* d, slh_stream_t stream);
 int slh_gn_apply(const slh_gn_desc* d, slh_stream_t stream);
+/* workgroups per sample of slh_gn_stats / slh_gn_bwd_stats (sizes `partial`); -1 for an unsupported shape */
+int slh_gn_row_blocks(int channels, int hw, int groups);
 
 /* GroupNorm backward (dx only: gamma/beta are frozen).  Two launches like the forward:
- * bwd_stats accumulates per (b,g) sum(dyhat) and sum(dyhat*xhat) into bstats (zeroed by caller),
+ * bwd_stats reduces per (b,g) sum(dyhat) and sum(dyhat*xhat) into bstats (fixed order, see slh_gn_desc),
  * bwd_apply writes dx (+= into dx if accumulate).  dy is the gradient of the post-activation output. */
 typedef struct slh_gn_bwd_desc {
     const void* x0; const void* x1;
     const void* gamma; const void* beta;
-    const float* stats;      /* forward stats */
-    float* bstats;           /* [batch][groups][2] fp32 */
+    const float* stats;      /* forward stats (mean, rstd) */
+    float* bstats;           /* [batch][groups][2] fp32: (sum dxhat, sum dxhat*xhat), written by slh_gn_bwd_stats */
     const void* dy;          /* [batch*hw][lddy] bf16 */
     void* dx0; void* dx1;    /* gradient w.r.t. source 0 / 1 */
     int32_t ldx0, ldx1, c0, c1;
@@ -173,6 +183,8 @@ typedef struct slh_gn_bwd_desc {
     float eps;
     int32_t act;
     int32_t accumulate0, accumulate1; /* dx += instead of = */
+    float* bpartial;         /* slh_gn_bwd_stats: scratch like slh_gn_desc.partial */
+    uint32_t* bticket;       /* slh_gn_bwd_stats: [batch] zeroed arrival counters */
 } slh_gn_bwd_desc;
 int slh_gn_bwd_stats(const slh_gn_bwd_desc* d, slh_stream_t stream);
 int slh_gn_bwd_apply(const slh_gn_bwd_desc* d, slh_stream_t stream);
@@ -397,14 +409,17 @@ int slh_sgemm(const slh_sgemm_desc* d, slh_stream_t stream);
 
 typedef struct slh_gn32_desc {
     const void* x; const void* gamma; const void* beta;   /* fp32 */
-    float* stats;           /* [batch][groups][2] fp32, zeroed by the caller before slh_gn32_stats */
+    float* stats;           /* [batch][groups][2] fp32: (mean, rstd), written by slh_gn32_stats */
     void* y;                /* [batch*hw][ldy] fp32 */
     int32_t ldx, ldy, C, batch, hw, groups;
     float eps;
     int32_t act;            /* 0 none, 1 SiLU */
+    float* partial;         /* slh_gn32_stats: [batch][slh_gn32_row_blocks(hw)][groups][2] fp32 scratch (see slh_gn_desc) */
+    uint32_t* ticket;       /* slh_gn32_stats: [batch] arrival counters, zero before the launch */
 } slh_gn32_desc;
 int slh_gn32_stats(const slh_gn32_desc* d, slh_stream_t stream);
 int slh_gn32_apply(const slh_gn32_desc* d, slh_stream_t stream);
+int slh_gn32_row_blocks(int hw);
 
 typedef struct slh_softmax32_desc { float* x; int64_t ld; int32_t rows, cols; } slh_softmax32_desc;   /* in place */
 int slh_softmax32(const slh_softmax32_desc* d, slh_stream_t stream);

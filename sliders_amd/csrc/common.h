@@ -76,6 +76,93 @@ __device__ __forceinline__ unsigned lds_addr_of(const void* p) {
     return (unsigned)(uintptr_t)(const __attribute__((address_space(3))) char*)p;
 }
 
+// ---- fixed-order cross-workgroup reductions -----------------------------------------------------------------------
+// Every reduction whose result feeds bf16 activations (GroupNorm statistics, split-K partial sums) is done in a fixed
+// order: fp32 atomics commit in arrival order, the last bits of the sum then differ from run to run, a bf16 rounding
+// boundary flips somewhere, and ~1000 dependent kernels later two runs of the SAME pass differ by the whole bf16 error
+// budget (measured in rounds 1-2: rel-L2 7e-3 run to run).  The pattern (cdna_hip_programming.md §5 "in-launch split-K
+// reduction", sc1 form): every workgroup publishes its partial (value pairs, one 8-byte write-through store each),
+// drains its stores, takes a ticket; the workgroup that draws the last ticket reads all partials back (sc1 loads: L2
+// of any XCD is bypassed) and combines them in index order.  Which workgroup is last varies, the arithmetic does not.
+__device__ __forceinline__ void store_pair_sc1(float* p, float a, float b) {
+    const unsigned long long bits = ((unsigned long long)__builtin_bit_cast(unsigned, b) << 32) | __builtin_bit_cast(unsigned, a);
+    __hip_atomic_store((unsigned long long*)p, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ f32x2 load_pair_sc1(const float* p) {
+    const unsigned long long bits = __hip_atomic_load((const unsigned long long*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return f32x2{__builtin_bit_cast(float, (unsigned)bits), __builtin_bit_cast(float, (unsigned)(bits >> 32))};
+}
+// true in every thread of the workgroup that arrives last of `expected` at *ticket (zeroed by the caller before the
+// launch; the last arriver re-arms it).  lds_flag: one int of the kernel's LDS.
+__device__ __forceinline__ bool last_arriver(unsigned* ticket, unsigned expected, int* lds_flag) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's sc1 stores have reached the memory side
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int last = t == expected - 1;
+        if (last) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        *lds_flag = last;
+    }
+    __syncthreads();
+    return *lds_flag != 0;
+}
+
+// Fixed-order reduction of per-thread, per-channel (s, q) pairs to per-group pairs inside one workgroup.
+// lds: [2][rpi * C] floats.  Thread (chunk, rl) owns CH consecutive channels; afterwards the threads t = g * lpg
+// (g < groups) hold group g's sums in (S, Q) and the function returns true for exactly those threads.  The order of
+// every addition is a function of the launch geometry only - no LDS / global atomics (they commit in arrival order).
+template <int CH>
+__device__ __forceinline__ bool gn_block_reduce(float* lds, int C, int cg, int groups, int rpi, int lpg, int chunk, int rl,
+                                                const float* s, const float* q, float& S, float& Q) {
+    float* ls = lds;
+    float* lq = lds + rpi * C;
+    const int base = rl * C + chunk * CH;
+#pragma unroll
+    for (int e = 0; e < CH; e += 4) {
+        *(f32x4*)(ls + base + e) = f32x4{s[e], s[e + 1], s[e + 2], s[e + 3]};
+        *(f32x4*)(lq + base + e) = f32x4{q[e], q[e + 1], q[e + 2], q[e + 3]};
+    }
+    __syncthreads();
+    const int tid = threadIdx.x;
+    const int g = tid / lpg, j = tid & (lpg - 1);
+    float a = 0.f, b = 0.f;
+    if (g < groups) {
+        const int E = rpi * cg;
+        for (int idx = j; idx < E; idx += lpg) {
+            const int r = idx / cg;
+            const int o = r * C + g * cg + (idx - r * cg);
+            a += ls[o];
+            b += lq[o];
+        }
+    }
+    for (int o = lpg >> 1; o > 0; o >>= 1) {
+        a += __shfl_xor(a, o, 64);
+        b += __shfl_xor(b, o, 64);
+    }
+    S = a; Q = b;
+    return g < groups && j == 0;
+}
+
+// Sum of the `count` published pairs partial[(i * groups + g) * 2 ..] of group g = tid / lpg in index order (double);
+// valid in the threads t = g * lpg.
+__device__ __forceinline__ void gn_combine_partials(const float* partial, int count, int groups, int lpg, double& S, double& Q) {
+    const int tid = threadIdx.x;
+    const int g = tid / lpg, j = tid & (lpg - 1);
+    double a = 0.0, b = 0.0;
+    if (g < groups) {
+        for (int i = j; i < count; i += lpg) {
+            const f32x2 v = load_pair_sc1(partial + ((long)i * groups + g) * 2);
+            a += (double)v[0];
+            b += (double)v[1];
+        }
+    }
+    for (int o = lpg >> 1; o > 0; o >>= 1) {
+        a += __shfl_xor(a, o, 64);
+        b += __shfl_xor(b, o, 64);
+    }
+    S = a; Q = b;
+}
+
 // ---- host side -------------------------------------------------------------------------------
 void slh_set_error(const char* fmt, ...);
 #define SLH_CHECK(cond, ...)            \

@@ -471,7 +471,10 @@ __global__ __launch_bounds__(128 * WM, gemm_waves_per_simd(MI, NI, STAGES, LORA,
     // ---- epilogue ---------------------------------------------------------------------------------
     // acc[i][j][r] = C[m = m0 + wm*32*MI + i*32 + lrow][n = n0 + wn*32*NI + j*32 + (r&3) + 8*(r>>2) + 4*lhi]
     if (p.splitk > 1) {
-        // split-K: add this K slice's partial sums to the fp32 workspace; gemm_finalize_kernel applies the epilogue
+        // split-K: this K slice's partial sums go to ITS OWN fp32 slab of the workspace (plain 16-byte stores, no atomics:
+        // fp32 atomics commit in arrival order and the sum's last bits - hence bf16 roundings downstream - would differ
+        // from run to run); gemm_finalize_kernel adds the slabs in slice order and applies the epilogue
+        float* slab = p.c32 + (long)ks_id * p.M * p.N;
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
             const int m = m0 + wm * (32 * MI) + i * 32 + lrow;
@@ -482,16 +485,14 @@ __global__ __launch_bounds__(128 * WM, gemm_waves_per_simd(MI, NI, STAGES, LORA,
                 for (int q = 0; q < 4; ++q) {
                     const int n = n0 + wn * (32 * NI) + j * 32 + q * 8 + lhi * 4;
                     if (n >= p.N) continue;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) unsafeAtomicAdd(p.c32 + (long)m * p.N + n + e, acc[i][j][q * 4 + e]);
+                    *(f32x4*)(slab + (long)m * p.N + n) =
+                        f32x4{acc[i][j][q * 4], acc[i][j][q * 4 + 1], acc[i][j][q * 4 + 2], acc[i][j][q * 4 + 3]};
                 }
-            if (LORA && tile_n == 0) {         // both waves of a row pair: each holds the partial of its own k-steps
+            if (LORA && tile_n == 0) {         // both waves of a row pair: each holds the partial of its own k-steps -> 2 slabs per slice
                 // rank index of accl[i][r]: (r&3) + 8*(r>>2) + 4*lhi  ->  ranks 0-3 / 8-11 in the lhi=0 half, 4-7 in lhi=1
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    if (4 * lhi + e < p.lora_rank) unsafeAtomicAdd(p.t32 + (long)m * p.ld_t + 4 * lhi + e, accl[i][e]);
-                    if (lhi == 0 && 8 + e < p.lora_rank) unsafeAtomicAdd(p.t32 + (long)m * p.ld_t + 8 + e, accl[i][4 + e]);
-                }
+                float* ts = p.t32 + ((long)(ks_id * 2 + wn) * p.M + m) * p.ld_t;
+                if (4 * lhi < p.lora_rank) *(f32x4*)(ts + 4 * lhi) = f32x4{accl[i][0], accl[i][1], accl[i][2], accl[i][3]};
+                if (lhi == 0 && 8 < p.lora_rank) *(f32x4*)(ts + 8) = f32x4{accl[i][4], accl[i][5], accl[i][6], accl[i][7]};
             }
         }
         return;
@@ -733,15 +734,17 @@ __global__ __launch_bounds__(128 * WM, gemm_waves_per_simd(MI, NI, STAGES, LORA,
     }
 }
 
-// split-K second pass: C = epi(c32) with the epilogue of gemm_kernel (bias, per-sample row bias, LoRA up-projection of
-// the reduced T, residual), one thread per 4 consecutive columns of one row.
+// split-K second pass: C = epi(sum of the K slices' slabs, in slice order) with the epilogue of gemm_kernel (bias, per-sample
+// row bias, LoRA up-projection of the reduced T, residual), one thread per 4 consecutive columns of one row.
 __global__ __launch_bounds__(256) void gemm_finalize_kernel(const GemmArgs p) {
     const int nq = p.N >> 2;
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (long)p.M * nq) return;
     const int m = (int)(idx / nq);
     const int n = (int)(idx - (long)m * nq) * 4;
-    const f32x4 c4 = *(const f32x4*)(p.c32 + (long)m * p.N + n);
+    const long slab = (long)p.M * p.N;
+    f32x4 c4 = *(const f32x4*)(p.c32 + (long)m * p.N + n);
+    for (int k = 1; k < p.splitk; ++k) c4 += *(const f32x4*)(p.c32 + k * slab + (long)m * p.N + n);
     float v[4] = {c4[0], c4[1], c4[2], c4[3]};
     if (p.bias) {
         const bf16x4 b4 = *(const bf16x4*)(p.bias + n);
@@ -753,8 +756,29 @@ __global__ __launch_bounds__(256) void gemm_finalize_kernel(const GemmArgs p) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] += (float)b4[e];
     }
-    const float* T = p.lora_down ? p.t32 : p.lora_t;
-    if (T) {
+    if (p.lora_down) {
+        // fused adapter: T's slabs (two per K slice, see gemm_kernel) reduce in slab order
+        const float lscale = *p.lora_scale;
+        const long tslab = (long)p.M * p.ld_t;
+        const int g = n / p.lora_cols_per_group;
+        const float* tp = p.t32 + (long)m * p.ld_t + g * 4;
+        f32x4 t = *(const f32x4*)tp;
+        for (int k = 1; k < 2 * p.splitk; ++k) t += *(const f32x4*)(tp + k * tslab);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const bf16x4 u = *(const bf16x4*)(p.lora_up + (long)(n + e) * 4);
+            v[e] += lscale * (t[0] * (float)u[0] + t[1] * (float)u[1] + t[2] * (float)u[2] + t[3] * (float)u[3]);
+        }
+        if (p.lora_t_out && n == 0) {          // the backward wants T itself
+            for (int gg = 0; gg * 4 < p.lora_rank; ++gg) {
+                const float* tq = p.t32 + (long)m * p.ld_t + gg * 4;
+                f32x4 tt = *(const f32x4*)tq;
+                for (int k = 1; k < 2 * p.splitk; ++k) tt += *(const f32x4*)(tq + k * tslab);
+                *(f32x4*)(p.lora_t_out + (long)m * p.ld_t + gg * 4) = tt;
+            }
+        }
+    } else if (p.lora_t) {
+        const float* T = p.lora_t;
         const float lscale = *p.lora_scale;
         if (!p.lora_up_rmajor) {
             const int g = n / p.lora_cols_per_group;
@@ -947,13 +971,21 @@ extern "C" int slh_gemm(const slh_gemm_desc* d, slh_stream_t stream) {
     a.probe = d->reserved_;
     a.splitk = (d->tile >> 16) & 15;
     a.c32 = d->splitk_c32;
-    a.t32 = d->splitk_t32 ? d->splitk_t32 : d->lora_t_out;
+    a.t32 = d->splitk_t32;
     if (a.splitk > 1) {
-        SLH_CHECK(d->splitk_c32, "slh_gemm: split-K needs the zeroed fp32 workspace splitk_c32");
+        // every slice must be non-empty: each writes its whole slab, the finalize pass reads them all
+        const int nk = d->K / 64;
+        const int per = (nk + a.splitk - 1) / a.splitk;
+        a.splitk = (nk + per - 1) / per;
+    }
+    if (a.splitk > 1) {
+        SLH_CHECK(d->splitk_c32, "slh_gemm: split-K needs the fp32 slab workspace splitk_c32");
+        SLH_CHECK(d->splitk_slabs >= a.splitk, "slh_gemm: split-K into %d slices but the workspace holds %d slabs", a.splitk,
+                  d->splitk_slabs);
         SLH_CHECK(!d->geglu, "slh_gemm: split-K excludes the GEGLU epilogue");
         SLH_CHECK(!d->vt_out, "slh_gemm: split-K excludes the head-transposed V store");
-        SLH_CHECK(!d->lora_down || a.t32, "slh_gemm: split-K with a fused adapter needs splitk_t32 (or lora_t_out), zeroed");
-        if (a.splitk > d->K / 64) a.splitk = d->K / 64;
+        SLH_CHECK(!d->lora_down || a.t32, "slh_gemm: split-K with a fused adapter needs the slab workspace splitk_t32");
+        SLH_CHECK(((uintptr_t)d->splitk_c32 & 15) == 0 && ((uintptr_t)d->splitk_t32 & 15) == 0, "slh_gemm: slab alignment");
     } else {
         a.splitk = 1;
     }

@@ -13,7 +13,8 @@ namespace {
 constexpr int GN_ITERS = 8;  // rows per thread per block
 
 struct GnGeom {
-    int C, nchunk, rpi, threads, rows_per_block, row_blocks, cg;
+    int C, nchunk, rpi, threads, rows_per_block, row_blocks, cg, lpg;
+    unsigned lds_bytes;
 };
 
 static GnGeom gn_geom(int c0, int c1, int hw, int groups) {
@@ -25,6 +26,9 @@ static GnGeom gn_geom(int c0, int c1, int hw, int groups) {
     g.rows_per_block = g.rpi * GN_ITERS;
     g.row_blocks = (hw + g.rows_per_block - 1) / g.rows_per_block;
     g.cg = g.C / groups;
+    g.lpg = 1;                                   // lanes that share one group in the fixed-order reductions
+    while (g.lpg < 16 && 2 * g.lpg * groups <= g.threads) g.lpg *= 2;
+    g.lds_bytes = (unsigned)((2 * g.threads * 8 + 4) * sizeof(float));
     return g;
 }
 
@@ -32,45 +36,45 @@ __device__ __forceinline__ const __bf16* gn_src(const slh_gn_desc& d, long row, 
     return c < d.c0 ? (const __bf16*)d.x0 + row * d.ldx0 + c : (const __bf16*)d.x1 + row * d.ldx1 + (c - d.c0);
 }
 
-// accumulate 8 per-channel values into per-group LDS slots, merging runs of equal group first
-__device__ __forceinline__ void group_accumulate(float* lds2, int c, int cg, const float* s, const float* q) {
-    int gcur = c / cg;
-    float a = 0.f, b = 0.f;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        const int g = (c + e) / cg;
-        if (g != gcur) {
-            atomicAdd(&lds2[gcur * 2], a);
-            atomicAdd(&lds2[gcur * 2 + 1], b);
-            gcur = g; a = 0.f; b = 0.f;
-        }
-        a += s[e]; b += q[e];
-    }
-    atomicAdd(&lds2[gcur * 2], a);
-    atomicAdd(&lds2[gcur * 2 + 1], b);
-}
-
-__global__ void gn_stats_kernel(const slh_gn_desc d, int nchunk, int rpi, int rows_per_block, int cg) {
-    __shared__ float lg[2 * 64];
+// Statistics of one (sample, group): stats[b][g] = (mean, rstd).  Two-pass-safe in one pass: the sums run over
+// x - K_g with K_g = the group's first element (an actual sample of the data, so |mean - K_g| is a few standard
+// deviations at most and E[(x-K)^2] - E[x-K]^2 does not cancel, whatever DC offset the activations carry).
+__global__ void gn_stats_kernel(const slh_gn_desc d, int nchunk, int rpi, int rows_per_block, int cg, int lpg, int row_blocks) {
+    extern __shared__ __attribute__((aligned(16))) float gn_lds[];
     const int tid = threadIdx.x;
-    for (int i = tid; i < 2 * d.groups; i += blockDim.x) lg[i] = 0.f;
-    __syncthreads();
     const int chunk = tid % nchunk, rl = tid / nchunk;
     const int c = chunk * 8;
     const int b = blockIdx.y;
+    const int C = nchunk * 8;
     const int r0 = blockIdx.x * rows_per_block;
     const int r1 = min(d.hw, r0 + rows_per_block);
-    float s[8], q[8];
+    float ks[8], s[8], q[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) { s[e] = 0.f; q[e] = 0.f; }
+    for (int e = 0; e < 8; ++e) {
+        ks[e] = (float)*gn_src(d, (long)b * d.hw, ((c + e) / cg) * cg);
+        s[e] = 0.f; q[e] = 0.f;
+    }
     for (int r = r0 + rl; r < r1; r += rpi) {
         const bf16x8 v = *(const bf16x8*)gn_src(d, (long)b * d.hw + r, c);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { const float f = (float)v[e]; s[e] += f; q[e] += f * f; }
+        for (int e = 0; e < 8; ++e) { const float f = (float)v[e] - ks[e]; s[e] += f; q[e] += f * f; }
     }
-    group_accumulate(lg, c, cg, s, q);
-    __syncthreads();
-    for (int i = tid; i < 2 * d.groups; i += blockDim.x) atomicAdd(&d.stats[(long)b * d.groups * 2 + i], lg[i]);
+    float S, Q;
+    const bool owner = gn_block_reduce<8>(gn_lds, C, cg, d.groups, rpi, lpg, chunk, rl, s, q, S, Q);
+    float* part = d.partial + (long)b * row_blocks * d.groups * 2;
+    if (owner) store_pair_sc1(part + ((long)blockIdx.x * d.groups + tid / lpg) * 2, S, Q);
+    if (!last_arriver(d.ticket + b, (unsigned)row_blocks, (int*)(gn_lds + 2 * rpi * C))) return;
+    double Sd, Qd;
+    gn_combine_partials(part, row_blocks, d.groups, lpg, Sd, Qd);
+    const int g = tid / lpg;
+    if (g < d.groups && (tid & (lpg - 1)) == 0) {
+        const double n = (double)d.hw * (double)cg;
+        const double k = (double)(float)*gn_src(d, (long)b * d.hw, g * cg);
+        const double m = Sd / n;
+        const double var = fmax(Qd / n - m * m, 0.0);
+        d.stats[((long)b * d.groups + g) * 2] = (float)(k + m);
+        d.stats[((long)b * d.groups + g) * 2 + 1] = (float)(1.0 / sqrt(var + (double)d.eps));
+    }
 }
 
 __global__ void gn_apply_kernel(const slh_gn_desc d, int nchunk, int rpi, int rows_per_block, int cg) {
@@ -80,16 +84,14 @@ __global__ void gn_apply_kernel(const slh_gn_desc d, int nchunk, int rpi, int ro
     const int b = blockIdx.y;
     const int r0 = blockIdx.x * rows_per_block;
     const int r1 = min(d.hw, r0 + rows_per_block);
-    const float inv_n = 1.f / ((float)d.hw * (float)cg);
     float a[8], sft[8];
     const bf16x8 gm = *(const bf16x8*)((const __bf16*)d.gamma + c);
     const bf16x8 bt = *(const bf16x8*)((const __bf16*)d.beta + c);
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
         const int g = (c + e) / cg;
-        const float mean = d.stats[((long)b * d.groups + g) * 2] * inv_n;
-        const float var = fmaxf(d.stats[((long)b * d.groups + g) * 2 + 1] * inv_n - mean * mean, 0.f);
-        const float rstd = rsqrtf(var + d.eps);
+        const float mean = d.stats[((long)b * d.groups + g) * 2];
+        const float rstd = d.stats[((long)b * d.groups + g) * 2 + 1];
         a[e] = rstd * (float)gm[e];
         sft[e] = (float)bt[e] - mean * a[e];
     }
@@ -130,26 +132,24 @@ __device__ __forceinline__ void gnb_elem(const slh_gn_bwd_desc& d, const bf16x8&
     }
 }
 
-__global__ void gn_bwd_stats_kernel(const slh_gn_bwd_desc d, int nchunk, int rpi, int rows_per_block, int cg) {
-    __shared__ float lg[2 * 64];
+__global__ void gn_bwd_stats_kernel(const slh_gn_bwd_desc d, int nchunk, int rpi, int rows_per_block, int cg, int lpg,
+                                    int row_blocks) {
+    extern __shared__ __attribute__((aligned(16))) float gn_lds[];
     const int tid = threadIdx.x;
-    for (int i = tid; i < 2 * d.groups; i += blockDim.x) lg[i] = 0.f;
-    __syncthreads();
     const int chunk = tid % nchunk, rl = tid / nchunk;
     const int c = chunk * 8;
     const int b = blockIdx.y;
+    const int C = nchunk * 8;
     const int r0 = blockIdx.x * rows_per_block;
     const int r1 = min(d.hw, r0 + rows_per_block);
-    const float inv_n = 1.f / ((float)d.hw * (float)cg);
     float mean[8], rstd[8], gm[8], bt[8];
     const bf16x8 gmv = *(const bf16x8*)((const __bf16*)d.gamma + c);
     const bf16x8 btv = *(const bf16x8*)((const __bf16*)d.beta + c);
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
         const int g = (c + e) / cg;
-        mean[e] = d.stats[((long)b * d.groups + g) * 2] * inv_n;
-        const float var = fmaxf(d.stats[((long)b * d.groups + g) * 2 + 1] * inv_n - mean[e] * mean[e], 0.f);
-        rstd[e] = rsqrtf(var + d.eps);
+        mean[e] = d.stats[((long)b * d.groups + g) * 2];
+        rstd[e] = d.stats[((long)b * d.groups + g) * 2 + 1];
         gm[e] = (float)gmv[e]; bt[e] = (float)btv[e];
     }
     float s[8], q[8];
@@ -164,9 +164,18 @@ __global__ void gn_bwd_stats_kernel(const slh_gn_bwd_desc d, int nchunk, int rpi
 #pragma unroll
         for (int e = 0; e < 8; ++e) { s[e] += dxh[e]; q[e] += dxh[e] * xh[e]; }
     }
-    group_accumulate(lg, c, cg, s, q);
-    __syncthreads();
-    for (int i = tid; i < 2 * d.groups; i += blockDim.x) atomicAdd(&d.bstats[(long)b * d.groups * 2 + i], lg[i]);
+    float S, Q;
+    const bool owner = gn_block_reduce<8>(gn_lds, C, cg, d.groups, rpi, lpg, chunk, rl, s, q, S, Q);
+    float* part = d.bpartial + (long)b * row_blocks * d.groups * 2;
+    if (owner) store_pair_sc1(part + ((long)blockIdx.x * d.groups + tid / lpg) * 2, S, Q);
+    if (!last_arriver(d.bticket + b, (unsigned)row_blocks, (int*)(gn_lds + 2 * rpi * C))) return;
+    double Sd, Qd;
+    gn_combine_partials(part, row_blocks, d.groups, lpg, Sd, Qd);
+    const int g = tid / lpg;
+    if (g < d.groups && (tid & (lpg - 1)) == 0) {
+        d.bstats[((long)b * d.groups + g) * 2] = (float)Sd;
+        d.bstats[((long)b * d.groups + g) * 2 + 1] = (float)Qd;
+    }
 }
 
 __global__ void gn_bwd_apply_kernel(const slh_gn_bwd_desc d, int nchunk, int rpi, int rows_per_block, int cg) {
@@ -184,9 +193,8 @@ __global__ void gn_bwd_apply_kernel(const slh_gn_bwd_desc d, int nchunk, int rpi
     for (int e = 0; e < 8; ++e) {
         const int g = (c + e) / cg;
         const long si = ((long)b * d.groups + g) * 2;
-        mean[e] = d.stats[si] * inv_n;
-        const float var = fmaxf(d.stats[si + 1] * inv_n - mean[e] * mean[e], 0.f);
-        rstd[e] = rsqrtf(var + d.eps);
+        mean[e] = d.stats[si];
+        rstd[e] = d.stats[si + 1];
         gm[e] = (float)gmv[e]; bt[e] = (float)btv[e];
         m1[e] = d.bstats[si] * inv_n;
         m2[e] = d.bstats[si + 1] * inv_n;
@@ -318,12 +326,18 @@ static int gn_check(const char* who, int c0, int c1, int groups, int ldx0, int l
     return 0;
 }
 
+extern "C" int slh_gn_row_blocks(int channels, int hw, int groups) {
+    if (channels <= 0 || channels % 8 || hw <= 0 || groups <= 0 || channels % groups) return -1;
+    return gn_geom(channels, 0, hw, groups).row_blocks;
+}
+
 extern "C" int slh_gn_stats(const slh_gn_desc* d, slh_stream_t stream) {
     SLH_CHECK(d && d->x0 && d->stats, "slh_gn_stats: null pointer");
+    SLH_CHECK(d->partial && d->ticket, "slh_gn_stats: needs the partial-sum workspace and the zeroed ticket counters");
     if (gn_check("slh_gn_stats", d->c0, d->c1, d->groups, d->ldx0, d->ldx1, d->x1)) return -1;
     const GnGeom g = gn_geom(d->c0, d->c1, d->hw, d->groups);
-    hipLaunchKernelGGL(gn_stats_kernel, dim3(g.row_blocks, d->batch), dim3(g.threads), 0, (hipStream_t)stream, *d,
-                       g.nchunk, g.rpi, g.rows_per_block, g.cg);
+    hipLaunchKernelGGL(gn_stats_kernel, dim3(g.row_blocks, d->batch), dim3(g.threads), g.lds_bytes, (hipStream_t)stream, *d,
+                       g.nchunk, g.rpi, g.rows_per_block, g.cg, g.lpg, g.row_blocks);
     SLH_LAUNCH_CHECK("slh_gn_stats");
     return 0;
 }
@@ -341,10 +355,11 @@ extern "C" int slh_gn_apply(const slh_gn_desc* d, slh_stream_t stream) {
 
 extern "C" int slh_gn_bwd_stats(const slh_gn_bwd_desc* d, slh_stream_t stream) {
     SLH_CHECK(d && d->x0 && d->stats && d->bstats && d->dy, "slh_gn_bwd_stats: null pointer");
+    SLH_CHECK(d->bpartial && d->bticket, "slh_gn_bwd_stats: needs the partial-sum workspace and the zeroed ticket counters");
     if (gn_check("slh_gn_bwd_stats", d->c0, d->c1, d->groups, d->ldx0, d->ldx1, d->x1)) return -1;
     const GnGeom g = gn_geom(d->c0, d->c1, d->hw, d->groups);
-    hipLaunchKernelGGL(gn_bwd_stats_kernel, dim3(g.row_blocks, d->batch), dim3(g.threads), 0, (hipStream_t)stream,
-                       *d, g.nchunk, g.rpi, g.rows_per_block, g.cg);
+    hipLaunchKernelGGL(gn_bwd_stats_kernel, dim3(g.row_blocks, d->batch), dim3(g.threads), g.lds_bytes, (hipStream_t)stream,
+                       *d, g.nchunk, g.rpi, g.rows_per_block, g.cg, g.lpg, g.row_blocks);
     SLH_LAUNCH_CHECK("slh_gn_bwd_stats");
     return 0;
 }

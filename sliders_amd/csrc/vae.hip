@@ -351,32 +351,42 @@ __global__ __launch_bounds__(256, 2) void sgemm_bf16x3_kernel(const slh_sgemm_de
 
 // ---------------------------------------------------------------------------------------------------------------
 // GroupNorm fp32.  stats: grid (row blocks, batch); each block strides over its rows with one float4 column chunk per
-// thread, reduces per group in LDS, one atomicAdd pair per (block, group).  apply: y = xhat*gamma+beta (+SiLU).
+// thread, reduces per group in LDS in a fixed order and publishes one pair per (block, group); the last block to arrive
+// combines them in index order and writes (mean, rstd) - bit-reproducible, see common.h.  apply: y = xhat*gamma+beta (+SiLU).
 // ---------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void gn32_stats_kernel(const slh_gn32_desc d, int rows_per_block) {
-    __shared__ float lg[2 * 64];
+__global__ __launch_bounds__(256) void gn32_stats_kernel(const slh_gn32_desc d, int rows_per_block, int lpg, int row_blocks) {
+    extern __shared__ __attribute__((aligned(16))) float gn_lds[];
     const int tid = threadIdx.x;
-    for (int i = tid; i < 2 * d.groups; i += blockDim.x) lg[i] = 0.f;
-    __syncthreads();
     const int nchunk = d.C / 4, cg = d.C / d.groups;      // nchunk is a power of two <= 256 (checked on the host)
     const int b = blockIdx.y;
     const int r0 = blockIdx.x * rows_per_block, r1 = min(d.hw, r0 + rows_per_block);
     const float* X = (const float*)d.x;
     const int chunk = tid % nchunk, rl = tid / nchunk, rpi = 256 / nchunk;
-    {
-        float s = 0.f, q = 0.f;
-        const int c = chunk * 4;
-        for (int rr = r0 + rl; rr < r1; rr += rpi) {
-            const f4 v = *(const f4*)(X + ((long)b * d.hw + rr) * d.ldx + c);
+    const int c = chunk * 4;
+    const int g0 = c / cg;                     // cg is a multiple of 4: a float4 never straddles groups
+    const float k = X[(long)b * d.hw * d.ldx + g0 * cg];   // shift: the group's first element (see gn_stats_kernel, norm.hip)
+    float s[4] = {0.f, 0.f, 0.f, 0.f}, q[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int rr = r0 + rl; rr < r1; rr += rpi) {
+        const f4 v = *(const f4*)(X + ((long)b * d.hw + rr) * d.ldx + c);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { s += v[e]; q += v[e] * v[e]; }
-        }
-        const int g = c / cg;                  // cg is a multiple of 4: a float4 never straddles groups
-        atomicAdd(&lg[2 * g], s);
-        atomicAdd(&lg[2 * g + 1], q);
+        for (int e = 0; e < 4; ++e) { const float f = v[e] - k; s[e] += f; q[e] += f * f; }
     }
-    __syncthreads();
-    for (int i = tid; i < 2 * d.groups; i += blockDim.x) atomicAdd(&d.stats[(long)b * d.groups * 2 + i], lg[i]);
+    float S, Q;
+    const bool owner = gn_block_reduce<4>(gn_lds, d.C, cg, d.groups, rpi, lpg, chunk, rl, s, q, S, Q);
+    float* part = d.partial + (long)b * row_blocks * d.groups * 2;
+    if (owner) store_pair_sc1(part + ((long)blockIdx.x * d.groups + tid / lpg) * 2, S, Q);
+    if (!last_arriver(d.ticket + b, (unsigned)row_blocks, (int*)(gn_lds + 2 * rpi * d.C))) return;
+    double Sd, Qd;
+    gn_combine_partials(part, row_blocks, d.groups, lpg, Sd, Qd);
+    const int g = tid / lpg;
+    if (g < d.groups && (tid & (lpg - 1)) == 0) {
+        const double n = (double)d.hw * (double)cg;
+        const double kg = (double)X[(long)b * d.hw * d.ldx + g * cg];
+        const double m = Sd / n;
+        const double var = fmax(Qd / n - m * m, 0.0);
+        d.stats[((long)b * d.groups + g) * 2] = (float)(kg + m);
+        d.stats[((long)b * d.groups + g) * 2 + 1] = (float)(1.0 / sqrt(var + (double)d.eps));
+    }
 }
 
 __global__ __launch_bounds__(256) void gn32_apply_kernel(const slh_gn32_desc d) {
@@ -388,10 +398,8 @@ __global__ __launch_bounds__(256) void gn32_apply_kernel(const slh_gn32_desc d) 
     const int c = (int)(idx - row * nchunk) * 4;
     const int b = (int)(row / d.hw);
     const int g = c / cg;
-    const float inv_n = 1.f / ((float)d.hw * (float)cg);
-    const float mean = d.stats[((long)b * d.groups + g) * 2] * inv_n;
-    const float var = fmaxf(d.stats[((long)b * d.groups + g) * 2 + 1] * inv_n - mean * mean, 0.f);
-    const float rstd = 1.0f / sqrtf(var + d.eps);
+    const float mean = d.stats[((long)b * d.groups + g) * 2];
+    const float rstd = d.stats[((long)b * d.groups + g) * 2 + 1];
     const f4 v = *(const f4*)((const float*)d.x + row * d.ldx + c);
     const f4 gm = *(const f4*)((const float*)d.gamma + c), bt = *(const f4*)((const float*)d.beta + c);
     f4 o;
@@ -585,11 +593,19 @@ static int gn32_check(const slh_gn32_desc* d, const char* who) {
     return 0;
 }
 
+constexpr int GN32_ROWS_PER_BLOCK = 64;
+
+extern "C" int slh_gn32_row_blocks(int hw) { return hw > 0 ? (hw + GN32_ROWS_PER_BLOCK - 1) / GN32_ROWS_PER_BLOCK : -1; }
+
 extern "C" int slh_gn32_stats(const slh_gn32_desc* d, slh_stream_t stream) {
     if (gn32_check(d, "slh_gn32_stats")) return -1;
-    const int rows_per_block = 64;
-    hipLaunchKernelGGL(gn32_stats_kernel, dim3((d->hw + rows_per_block - 1) / rows_per_block, d->batch), dim3(256), 0,
-                       (hipStream_t)stream, *d, rows_per_block);
+    SLH_CHECK(d->partial && d->ticket, "slh_gn32_stats: needs the partial-sum workspace and the zeroed ticket counters");
+    const int row_blocks = slh_gn32_row_blocks(d->hw);
+    int lpg = 1;
+    while (lpg < 16 && 2 * lpg * d->groups <= 256) lpg *= 2;
+    const unsigned lds = (unsigned)((2 * 256 * 4 + 4) * sizeof(float));
+    hipLaunchKernelGGL(gn32_stats_kernel, dim3(row_blocks, d->batch), dim3(256), lds, (hipStream_t)stream, *d,
+                       GN32_ROWS_PER_BLOCK, lpg, row_blocks);
     SLH_LAUNCH_CHECK("slh_gn32_stats");
     return 0;
 }

@@ -34,7 +34,7 @@ GemmDesc = _struct("GemmDesc", _ptrs("a0", "a1", "w", "bias", "rowbias", "lora_t
                            "ho", "wo", "ldw", "M", "N", "K", "ld_rowbias", "rows_per_sample", "ld_t",
                            "lora_groups", "ld_res", "ldc", "geglu", "tile", "lora_rank", "lora_up_rmajor", "w_layout",
                            "reserved_") + _ptrs("splitk_c32", "splitk_t32", "vt_out")
-                   + _ints("vt_col0", "vt_D", "vt_heads", "vt_tokens", "vt_ld", "vt_pad_"))
+                   + _ints("vt_col0", "vt_D", "vt_heads", "vt_tokens", "vt_ld", "splitk_slabs"))
 SkinnyDesc = _struct("SkinnyDesc", _ptrs("a0", "a1", "w", "bias", "out")
                      + _ints("lda0", "lda1", "ca0", "ca1", "mode", "batch", "hs", "ws", "src_xform", "stride",
                              "ho", "wo", "M", "R", "K", "ldo", "out_kind", "w_kmajor"))
@@ -42,10 +42,10 @@ GemvDesc = _struct("GemvDesc", _ptrs("x", "w", "bias", "addend", "lora_t", "lora
                    + _ints("nb", "N", "K", "ldx", "ld_add", "ld_t", "ldy", "in_act", "out_f32"))
 GnDesc = _struct("GnDesc", _ptrs("x0", "x1", "gamma", "beta", "stats", "y")
                  + _ints("ldx0", "ldx1", "c0", "c1", "batch", "hw", "groups", "ldy") + [("eps", c_f32)]
-                 + _ints("act"))
+                 + _ints("act") + _ptrs("partial", "ticket"))
 GnBwdDesc = _struct("GnBwdDesc", _ptrs("x0", "x1", "gamma", "beta", "stats", "bstats", "dy", "dx0", "dx1")
                     + _ints("ldx0", "ldx1", "c0", "c1", "batch", "hw", "groups", "lddy", "lddx0", "lddx1")
-                    + [("eps", c_f32)] + _ints("act", "accumulate0", "accumulate1"))
+                    + [("eps", c_f32)] + _ints("act", "accumulate0", "accumulate1") + _ptrs("bpartial", "bticket"))
 LnDesc = _struct("LnDesc", _ptrs("x", "gamma", "beta", "y", "mean_rstd") + _ints("M", "C", "ldx", "ldy")
                  + [("eps", c_f32)])
 LnBwdDesc = _struct("LnBwdDesc", _ptrs("x", "gamma", "dy", "mean_rstd", "dx")
@@ -85,7 +85,7 @@ SgemmDesc = _struct("SgemmDesc", _ptrs("x", "w", "bias", "residual", "c")
                     + _ints("ldx", "ldw", "ldr", "ldc", "M", "N", "K", "mode", "cin", "batch", "hs", "ws", "ho", "wo", "stride",
                             "pad", "bias_per_row") + [("alpha", c_f32)] + _ints("upsample", "split_bf16"))
 Gn32Desc = _struct("Gn32Desc", _ptrs("x", "gamma", "beta", "stats", "y") + _ints("ldx", "ldy", "C", "batch", "hw", "groups")
-                   + [("eps", c_f32)] + _ints("act"))
+                   + [("eps", c_f32)] + _ints("act") + _ptrs("partial", "ticket"))
 Softmax32Desc = _struct("Softmax32Desc", _ptrs("x") + [("ld", c_i64)] + _ints("rows", "cols"))
 VaeConvDesc = _struct("VaeConvDesc", _ptrs("x", "w", "bias", "qw", "qb", "y") + _ints("batch", "h", "wd", "cin", "cout")
                       + [("inv_scaling", c_f32)])
@@ -127,7 +127,7 @@ _ENTRY = {
 }
 
 EXPORTS = ["slh_version", "slh_last_error", "slh_run_program", "slh_desc_sizes", "slh_graph_capture", "slh_graph_launch",
-           "slh_graph_destroy", "slh_gemm_variant"] + [v[0] for v in _ENTRY.values()]
+           "slh_graph_destroy", "slh_gemm_variant", "slh_gn_row_blocks", "slh_gn32_row_blocks"] + [v[0] for v in _ENTRY.values()]
 
 
 class SlidersHipError(RuntimeError):
@@ -183,6 +183,18 @@ def last_error() -> str:
 def check(rc: int, what: str = ""):
     if rc != 0:
         raise SlidersHipError(f"{what} failed (rc={rc}): {last_error()}")
+
+
+def gn_row_blocks(channels: int, hw: int, groups: int) -> int:
+    """Workgroups per sample of slh_gn_stats / slh_gn_bwd_stats: sizes their partial-sum workspace."""
+    n = load().slh_gn_row_blocks(channels, hw, groups)
+    if n <= 0:
+        raise SlidersHipError(f"slh_gn_row_blocks({channels}, {hw}, {groups}): unsupported shape")
+    return n
+
+
+def gn32_row_blocks(hw: int) -> int:
+    return load().slh_gn32_row_blocks(hw)
 
 
 def gemm_variant(desc) -> int:

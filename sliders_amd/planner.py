@@ -95,6 +95,26 @@ def default_splitk(d) -> int:
     return 0 if s < 2 else (s << 16) | 0x412
 
 
+SPLITK_TUNING_SLABS = 8          # slabs provisioned per candidate when the in-situ tuner may try any split factor
+
+
+def provision_splitk(plan, d, name: str):
+    """Give a product that will (or, in tuning mode, may) run split-K its slab workspace: one fp32 [M][N] slab per K slice
+    (each slice writes its own, the finalize launch adds them in slice order - bit-reproducible, nothing to zero) and, with a
+    fused adapter, two [M][ld_t] slabs per slice for T.  Fixes d.tile for untuned shapes."""
+    if not splitk_wanted(d):
+        return
+    if not d.tile:
+        d.tile = default_splitk(d)
+    slabs = SPLITK_TUNING_SLABS if os.environ.get("SLIDERS_NO_TUNING") else (d.tile >> 16) & 15
+    if slabs < 2:
+        return
+    d.splitk_slabs = slabs
+    d.splitk_c32 = plan.arena.alloc((slabs, d.M, d.N), torch.float32, name + ".splitk").ptr
+    if d.lora_down:
+        d.splitk_t32 = plan.arena.alloc((2 * slabs, d.M, d.ld_t), torch.float32, name + ".splitk_T").ptr
+
+
 def _src_parts(x: Src):
     if isinstance(x, tuple):
         return x[0], x[1]
@@ -225,9 +245,7 @@ class UNetPlan:
             R = sum(e.target.rank for e in grp)
             if fused:
                 # lora_down rides inside the GEMM (third operand tile); T is only written out for the backward
-                # (zero-initialised when the product may run split-K: the slices then accumulate into it)
-                may_split = M * N <= SPLITK_MAX_MN and K >= SPLITK_MIN_K and not geglu
-                T = self.f32((M, R), name + ".T", zero=may_split) if (self.train or may_split) else None
+                T = self.f32((M, R), name + ".T") if self.train else None
             else:
                 T = self.skinny(x, self.lora.down_ptr(grp[0]), R, K, conv, M, Ho, Wo, name + ".lora_down")
         d = lib.GemmDesc(a0=x0.ptr, a1=x1.ptr if x1 else 0,
@@ -237,7 +255,7 @@ class UNetPlan:
                          lora_t=T.ptr if (T and not fused) else 0, lora_up=self.lora.up_ptr(grp[0]) if grp else 0,
                          lora_down=self.lora.down_ptr(grp[0]) if fused else 0,
                          lora_t_out=T.ptr if (T and fused and self.train) else 0,
-                         splitk_t32=T.ptr if (T and fused) else 0, lora_rank=(4 * len(grp)) if fused else 0,
+                         lora_rank=(4 * len(grp)) if fused else 0,
                          lora_scale=self.lora_scale_ptr if grp else 0,
                          residual=residual.ptr if residual else 0, c=out.ptr,
                          lda0=x0.ld, lda1=x1.ld if x1 else 0, ca0=x0.C, ca1=x1.C if x1 else 0,
@@ -251,10 +269,7 @@ class UNetPlan:
         d.tile = tuned_tile(d)
         if not d.tile and M <= 192 and N >= 4096:
             d.tile = 0x12        # few rows, very wide: 64-row tiles waste the least of the short M
-        if splitk_wanted(d):     # the zeroed fp32 workspace is cleared by the program's head memset: only where it is used
-            d.splitk_c32 = self.f32((M, N), name + ".splitk", zero=True).ptr
-        if not d.tile and d.splitk_c32:
-            d.tile = default_splitk(d)
+        provision_splitk(self, d, name)
         self.last_vt = None
         if vt_heads and not self.train and not geglu and conv is None and os.environ.get("SLIDERS_NO_FUSED_VT") is None:
             Cq = N // 3
@@ -274,11 +289,15 @@ class UNetPlan:
         C = x0.C + (x1.C if x1 else 0)
         B, H, W = x0.B, x0.H, x0.W
         G = self.cfg.norm_num_groups
-        stats = self.f32((B, G, 2), name + ".stats", zero=True)
+        # statistics are reduced in a fixed order (bit-reproducible pass): per-workgroup partials + arrival tickets; only
+        # the tickets need the zeroed arena
+        stats = self.f32((B, G, 2), name + ".stats")
+        part = self.f32((B, lib.gn_row_blocks(C, H * W, G), G, 2), name + ".partial")
+        ticket = self.f32((B,), name + ".ticket", zero=True)
         y = self.act(B, H, W, C, name)
         d = lib.GnDesc(x0=x0.ptr, x1=x1.ptr if x1 else 0, gamma=self.w.ptr(wname + ".g"), beta=self.w.ptr(wname + ".b"),
                        stats=stats.ptr, y=y.ptr, ldx0=x0.ld, ldx1=x1.ld if x1 else 0, c0=x0.C, c1=x1.C if x1 else 0,
-                       batch=B, hw=H * W, groups=G, ldy=y.ld, eps=eps, act=act)
+                       batch=B, hw=H * W, groups=G, ldy=y.ld, eps=eps, act=act, partial=part.ptr, ticket=ticket.ptr)
         self.prog.add(lib.OP_GN_STATS, d, name + ".stats")
         self.prog.add(lib.OP_GN_APPLY, d, name + ".apply")
         if self.train:
@@ -457,12 +476,13 @@ class UNetPlan:
         ctxb = self.io["ctx"]
         self.ctx = Act(ctxb.ptr, B, 1, self.ctx_len, cfg.cross_attention_dim, cfg.cross_attention_dim, ctxb, "ctx")
         # every transformer block projects the same text embeddings to K/V: when those projections carry no adapter they
-        # run as ONE GEMM over the concatenated weights at the head of the no-grad passes.  (The training forward keeps the
-        # per-block projections: with the batched form its cross-attention outputs came out non-finite in 4-5 of 8 fresh
-        # engines at SDXL 512x512 - scripts/debug_nan_forward.py, SLIDERS_TRAIN_KV_BATCHED=1 - root cause not found yet.)
+        # run as ONE GEMM over the concatenated weights at the head of the pass - the training forward included (rounds 1-2
+        # kept per-block projections there because the batched layout exposed an LDS-DMA publish race in the attention
+        # kernels: profiles/r02_lds_dma_race_fix.txt; fixed, and green on the GPU suite x2 + 0/16 on the reproducer,
+        # profiles/r03_first_call.txt.  SLIDERS_TRAIN_KV_PER_BLOCK=1 restores the old form for A/B runs.)
         self.kv_all = self.vt_all = None
         kvo = getattr(self.w, "kv_all_offset", None)
-        if kvo and not (self.train and not os.environ.get("SLIDERS_TRAIN_KV_BATCHED")) and \
+        if kvo and not (self.train and os.environ.get("SLIDERS_TRAIN_KV_PER_BLOCK")) and \
                 all(self._lora_group([a + ".to_k", a + ".to_v"]) is None for a in kvo):
             n_all = self.w.gemm_shape["attn2_kv_all.w"][0]
             self.kv_all = self.gemm(self.ctx, "attn2_kv_all", n_all, "attn2_kv_all", bias=False)
@@ -626,7 +646,10 @@ class BackwardPlan:
             return
         gy, _ = self.grad(y, write=False)
         G = self.cfg.norm_num_groups
-        bst = self.zarena.alloc((self.nb, G, 2), torch.float32, "bwd." + rec["name"] + ".bstats")
+        bst = self.arena.alloc((self.nb, G, 2), torch.float32, "bwd." + rec["name"] + ".bstats")
+        bpart = self.arena.alloc((self.nb, lib.gn_row_blocks(x0.C + (x1.C if x1 is not None else 0), x0.HW, G), G, 2),
+                                 torch.float32, "bwd." + rec["name"] + ".bpartial")
+        btick = self.zarena.alloc((self.nb,), torch.float32, "bwd." + rec["name"] + ".bticket")
         x0s = self._sl(x0)
         x1s = self._sl(x1) if x1 is not None else None
         g0, a0 = self.grad(x0) if need0 else (None, False)
@@ -637,7 +660,7 @@ class BackwardPlan:
                           dx0=g0.ptr if g0 else 0, dx1=g1.ptr if g1 else 0, ldx0=x0s.ld, ldx1=x1s.ld if x1s else 0,
                           c0=x0.C, c1=x1.C if x1 is not None else 0, batch=self.nb, hw=x0.HW, groups=G, lddy=gy.ld,
                           lddx0=g0.ld if g0 else 0, lddx1=g1.ld if g1 else 0, eps=rec["eps"], act=rec["act"],
-                          accumulate0=1 if a0 else 0, accumulate1=1 if a1 else 0)
+                          accumulate0=1 if a0 else 0, accumulate1=1 if a1 else 0, bpartial=bpart.ptr, bticket=btick.ptr)
         self.prog.add(lib.OP_GN_BWD_STATS, d, "bwd." + rec["name"] + ".stats")
         self.prog.add(lib.OP_GN_BWD_APPLY, d, "bwd." + rec["name"] + ".apply")
 
@@ -698,8 +721,7 @@ class BackwardPlan:
 
     def _splitk(self, d, name):
         d.tile = tuned_tile(d)
-        if splitk_wanted(d):
-            d.splitk_c32 = self.zarena.alloc((d.M, d.N), torch.float32, name + ".splitk").ptr
+        provision_splitk(self, d, name)
 
     def _b_gemm(self, rec):
         y = rec["out"]
@@ -786,7 +808,6 @@ class BackwardPlan:
                 d.lora_t, d.ld_t, d.lora_up, d.lora_scale = U.ptr, 4 * len(grp), self.lora.down_ptr(grp[0]), self.scale_ptr
                 d.lora_groups, d.lora_rank, d.lora_up_rmajor = 1, 4 * len(grp), 1
             self._splitk(d, name)
-            d.tile = tuned_tile(d) or (default_splitk(d) if d.splitk_c32 else 0)
             self.prog.add(lib.OP_GEMM, d, name + ".dgrad")
             if x1 is not None:
                 if need0:
@@ -808,7 +829,6 @@ class BackwardPlan:
                              ldw=9 * N, M=self.nb * HL * WL, N=cin, K=9 * N, ld_res=tgt.ld, ldc=tgt.ld,
                              rows_per_sample=HL * WL, w_layout=1 if self.w.packed else 0)
             self._splitk(d, name)
-            d.tile = tuned_tile(d) or (default_splitk(d) if d.splitk_c32 else 0)
             self.prog.add(lib.OP_GEMM, d, name + ".dgrad")
             if grp is not None:
                 d2 = lib.LoraCdgradDesc(u=U.ptr, a_down=self.lora.down_ptr(grp[0]), scale=self.scale_ptr, gx=tgt.ptr,

@@ -36,7 +36,7 @@ class _Cfg(dict):
 
 class UNetEngine:
     def __init__(self, cfg: UNetConfig, state_dict: Dict[str, torch.Tensor], device="cuda:0",
-                 arena_bytes: Optional[int] = None, ctx_len: int = 77):
+                 arena_bytes: Optional[int] = None, ctx_len: int = 77, zarena_bytes: Optional[int] = None):
         self.cfg = cfg
         self.device = torch.device(device)
         if self.device.type != "cuda":
@@ -55,7 +55,11 @@ class UNetEngine:
         self._arena_bytes = arena_bytes
         self.arena: Optional[Arena] = None
         self.arena_off: Optional[Arena] = None     # adapter-free plans live apart: the trainer runs its frozen pass on a second stream
-        self.zarena = Arena(2048 << 20, self.device, "zero-init accumulators")   # GroupNorm statistics, loss, split-K partial sums
+        # zero-initialised words: the arrival tickets of the fixed-order GroupNorm reductions, the time-embedding adapter's
+        # column sums (~150 KB per cached (B, H, W) shape; GroupNorm statistics and split-K slabs need no zeroing any more).
+        # Plans never give their span back; when the arena runs low every cached plan is dropped and it restarts from 0.
+        self.zarena = Arena(int(zarena_bytes or (64 << 20)), self.device, "zero-init accumulators")
+        self.plan_flushes = 0
         self.train_plan: Optional[UNetPlan] = None
         self.one = torch.ones(1, dtype=torch.float32, device=self.device)
         self.grad_all_samples = False
@@ -123,6 +127,10 @@ class UNetEngine:
         p = self._plans.get(key)
         if p is not None:
             return p
+        # dynamic_resolution / per-prompt resolutions reach dozens of shapes (16 buckets on SD-1.x, 64 on SDXL): make room
+        # in the zero-init arena before it overflows (the plans of one shape - on, train, off - take Z_PER_SHAPE at most)
+        if self.zarena.capacity - self.zarena.mark() < min(self.Z_PER_SHAPE, self.zarena.capacity // 2):
+            self.flush_plans()
         # size the shared arena for the requested plan and, once adapters are attached, for the training plan
         # of the same shape (so 'on' -> 'train' does not trigger a regrow that invalidates cached plans)
         modes = {mode} | ({"train"} if (self.lora is not None and mode != "off") else set())
@@ -143,6 +151,16 @@ class UNetEngine:
         p.arena_end = arena.mark()
         self._plans[key] = p
         return p
+
+    Z_PER_SHAPE = 2 << 20
+
+    def flush_plans(self):
+        """Drop every cached plan (they hold raw pointers into the arenas) and restart the zero-init arena."""
+        torch.cuda.synchronize()
+        self._plans.clear()
+        self.train_plan = None
+        self.zarena.reset(0)
+        self.plan_flushes += 1
 
     def run_backward(self, p: Optional[UNetPlan] = None, d_eps: Optional[torch.Tensor] = None):
         """Backward of the last train-mode forward.  d_eps: gradient w.r.t. the returned epsilon for the

@@ -138,10 +138,13 @@ class _VaeNet:
 
     def _gn(self, x: Buf, C, hw, name, silu):
         B = self._B
-        stats = self._zarena.alloc((B, 32, 2), torch.float32, name + ".stats")
+        stats = self._arena.alloc((B, 32, 2), torch.float32, name + ".stats")
+        part = self._arena.alloc((B, lib.gn32_row_blocks(hw), 32, 2), torch.float32, name + ".partial")
+        ticket = self._zarena.alloc((B,), torch.float32, name + ".ticket")      # arrival counters of the fixed-order reduction
         y = self._act(B * hw, C, name)
         d = lib.Gn32Desc(x=x.ptr, gamma=self._wp(name + ".weight"), beta=self._wp(name + ".bias"), stats=stats.ptr, y=y.ptr,
-                         ldx=C, ldy=C, C=C, batch=B, hw=hw, groups=32, eps=1e-6, act=1 if silu else 0)
+                         ldx=C, ldy=C, C=C, batch=B, hw=hw, groups=32, eps=1e-6, act=1 if silu else 0,
+                         partial=part.ptr, ticket=ticket.ptr)
         self._prog.add(lib.OP_GN32_STATS, d, name + ".stats")
         self._prog.add(lib.OP_GN32_APPLY, d, name + ".apply")
         return y

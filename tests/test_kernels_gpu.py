@@ -281,47 +281,80 @@ def test_gemv(dev):
     report("gemv", y, ref, TOL)
 
 
-@pytest.mark.parametrize("C0,C1,act", [(320, 0, 1), (64, 0, 0), (1280, 640, 1), (2560, 0, 1), (960, 0, 1)])
-def test_groupnorm(dev, C0, C1, act):
+def _gn_workspace(dev, B, C, HW, G=32):
+    """Partial-sum scratch (deliberately filled with garbage: the kernel must not depend on its contents) + zeroed tickets."""
+    part = torch.full((B, lib.gn_row_blocks(C, HW, G), G, 2), float("nan"), device=dev)
+    return part, torch.zeros(B, dtype=torch.int32, device=dev)
+
+
+@pytest.mark.parametrize("C0,C1,act,mean,std", [(320, 0, 1, 0.5, 2.0), (64, 0, 0, 0.5, 2.0), (1280, 640, 1, 0.5, 2.0),
+                                                (2560, 0, 1, 0.5, 2.0), (960, 0, 1, 0.5, 2.0),
+                                                # DC offset >> spread (real checkpoints' early resnet activations): a one-pass
+                                                # E[x^2] - E[x]^2 in fp32 loses the variance here (bf16 spacing at 50 is 0.25, at 256 is 2)
+                                                (320, 0, 1, 50.0, 1.0), (640, 0, 0, 256.0, 4.0), (1280, 640, 1, -50.0, 1.0)])
+def test_groupnorm(dev, C0, C1, act, mean, std):
     torch.manual_seed(7)
     B, HW = 2, 300
     C = C0 + C1
-    x0 = bf(torch.randn(B * HW, C0, device=dev) * 2 + 0.5)
-    x1 = bf(torch.randn(B * HW, C1, device=dev)) if C1 else None
+    x0 = bf(torch.randn(B * HW, C0, device=dev) * std + mean)
+    x1 = bf(torch.randn(B * HW, C1, device=dev) * std + mean) if C1 else None
     g, bta = bf(torch.randn(C, device=dev)), bf(torch.randn(C, device=dev))
-    stats = torch.zeros(B, 32, 2, device=dev)
+    stats = torch.full((B, 32, 2), float("nan"), device=dev)
+    part, ticket = _gn_workspace(dev, B, C, HW)
     y = torch.zeros(B * HW, C, device=dev, dtype=torch.bfloat16)
     d = lib.GnDesc(x0=p(x0), x1=p(x1), gamma=p(g), beta=p(bta), stats=p(stats), y=p(y), ldx0=C0, ldx1=C1, c0=C0, c1=C1,
-                   batch=B, hw=HW, groups=32, ldy=C, eps=1e-5, act=act)
+                   batch=B, hw=HW, groups=32, ldy=C, eps=1e-5, act=act, partial=p(part), ticket=p(ticket))
     lib.call(lib.OP_GN_STATS, d, stream())
     lib.call(lib.OP_GN_APPLY, d, stream())
     torch.cuda.synchronize()
+    assert int(ticket.abs().sum()) == 0, "the last arriver re-arms the tickets"
     xc = torch.cat([x0, x1], 1) if C1 else x0
     ximg = xc.float().view(B, HW, C).permute(0, 2, 1)
-    ref = F.group_norm(ximg, 32, g.float(), bta.float(), 1e-5)
+    # the statistics themselves against fp64
+    xg = ximg.double().reshape(B, 32, -1)
+    mref, vref = xg.mean(-1), xg.var(-1, unbiased=False)
+    assert float((stats[..., 0].double() - mref).abs().max() / mref.abs().max().clamp_min(1.0)) < 1e-6
+    rref = 1.0 / torch.sqrt(vref + 1e-5)
+    assert float(((stats[..., 1].double() - rref) / rref).abs().max()) < 1e-5, "rstd (cancellation-safe statistics)"
+    ref = F.group_norm(ximg.double(), 32, g.double(), bta.double(), 1e-5).float()
     if act:
         ref = F.silu(bf(ref).float())
     ref = ref.permute(0, 2, 1).reshape(B * HW, C)
-    report(f"groupnorm C{C0}+{C1} act{act}", y, ref, TOL)
+    report(f"groupnorm C{C0}+{C1} act{act} mean{mean}", y, ref, TOL)
+    # bit-reproducible: the reduction order is fixed (no fp32 atomics)
+    s0, y0 = stats.clone(), y.clone()
+    for _ in range(3):
+        stats.fill_(float("nan"))
+        lib.call(lib.OP_GN_STATS, d, stream())
+        lib.call(lib.OP_GN_APPLY, d, stream())
+        torch.cuda.synchronize()
+        assert torch.equal(stats, s0) and torch.equal(y, y0)
     # backward (dx only)
     dy = bf(torch.randn(B * HW, C, device=dev))
-    bst = torch.zeros(B, 32, 2, device=dev)
+    bst = torch.full((B, 32, 2), float("nan"), device=dev)
+    bpart, bticket = _gn_workspace(dev, B, C, HW)
     dx0 = torch.zeros(B * HW, C0, device=dev, dtype=torch.bfloat16)
     dx1 = torch.zeros(B * HW, max(C1, 8), device=dev, dtype=torch.bfloat16)
     bd = lib.GnBwdDesc(x0=p(x0), x1=p(x1), gamma=p(g), beta=p(bta), stats=p(stats), bstats=p(bst), dy=p(dy),
                        dx0=p(dx0), dx1=p(dx1) if C1 else 0, ldx0=C0, ldx1=C1, c0=C0, c1=C1, batch=B, hw=HW, groups=32,
-                       lddy=C, lddx0=C0, lddx1=max(C1, 8), eps=1e-5, act=act)
+                       lddy=C, lddx0=C0, lddx1=max(C1, 8), eps=1e-5, act=act, bpartial=p(bpart), bticket=p(bticket))
     lib.call(lib.OP_GN_BWD_STATS, bd, stream())
     lib.call(lib.OP_GN_BWD_APPLY, bd, stream())
     torch.cuda.synchronize()
-    xi = ximg.clone().requires_grad_(True)
-    o = F.group_norm(xi, 32, g.float(), bta.float(), 1e-5)
+    xi = ximg.double().clone().requires_grad_(True)
+    o = F.group_norm(xi, 32, g.double(), bta.double(), 1e-5)
     if act:
         o = F.silu(o)
-    o.backward(dy.float().view(B, HW, C).permute(0, 2, 1))
-    gref = xi.grad.permute(0, 2, 1).reshape(B * HW, C)
+    o.backward(dy.double().view(B, HW, C).permute(0, 2, 1))
+    gref = xi.grad.permute(0, 2, 1).reshape(B * HW, C).float()
     got = torch.cat([dx0, dx1[:, :C1]], 1) if C1 else dx0
-    report(f"groupnorm_bwd C{C0}+{C1} act{act}", got, gref, 1.5e-2)
+    report(f"groupnorm_bwd C{C0}+{C1} act{act} mean{mean}", got, gref, 1.5e-2)
+    b0, g0 = bst.clone(), got.clone()
+    bst.fill_(float("nan"))
+    lib.call(lib.OP_GN_BWD_STATS, bd, stream())
+    lib.call(lib.OP_GN_BWD_APPLY, bd, stream())
+    torch.cuda.synchronize()
+    assert torch.equal(bst, b0) and torch.equal(torch.cat([dx0, dx1[:, :C1]], 1) if C1 else dx0, g0)
 
 
 @pytest.mark.parametrize("C", [64, 320, 640, 1280])
@@ -635,30 +668,42 @@ def test_gemm_fused_lora_down(dev, tile):
 
 @pytest.mark.parametrize("tile", [0x20412, 0x40421, 0x80422, 0x44412, 0x30011, 0x20022, 0xf0412])
 def test_gemm_splitk(dev, tile):
-    """Split-K (slh_gemm_desc.tile bits 16-19): K slices accumulate into the zeroed fp32 workspace, the second launch
-    applies the epilogue.  Dense + bias + residual, 3x3 convolution, fused LoRA down/up (T reduced too), two-source K."""
+    """Split-K (slh_gemm_desc.tile bits 16-19): every K slice writes its own fp32 slab (whatever the workspace held), the
+    second launch adds the slabs in slice order and applies the epilogue - bit-reproducible.  Dense + bias + residual,
+    3x3 convolution, fused LoRA down/up (T reduced too, and written out for the backward), two-source K."""
     torch.manual_seed(tile & 0xff)
+    S = (tile >> 16) & 15
     M, N, K = 300, 320, 1280
     x = bf(torch.randn(M, K, device=dev))
     w = bf(torch.randn(N, K, device=dev) / math.sqrt(K))
     bias = bf(torch.randn(N, device=dev))
     res = bf(torch.randn(M, N, device=dev))
     c = torch.zeros(M, N, device=dev, dtype=torch.bfloat16)
-    ws = torch.zeros(M, N, device=dev)
+    ws = torch.full((S, M, N), float("nan"), device=dev)
     d = lib.GemmDesc(a0=p(x), w=p(w), bias=p(bias), residual=p(res), c=p(c), lda0=K, ca0=K, mode=0, stride=1, ldw=K,
-                     M=M, N=N, K=K, ld_res=N, ldc=N, rows_per_sample=M, tile=tile, splitk_c32=p(ws))
+                     M=M, N=N, K=K, ld_res=N, ldc=N, rows_per_sample=M, tile=tile, splitk_c32=p(ws), splitk_slabs=S)
     lib.call(lib.OP_GEMM, d, stream())
     torch.cuda.synchronize()
     report(f"splitk dense tile{tile:x}", c, x.float() @ w.float().t() + bias.float() + res.float(), TOL)
+    c0 = c.clone()
+    for _ in range(3):
+        c.zero_()
+        lib.call(lib.OP_GEMM, d, stream())
+        torch.cuda.synchronize()
+        assert torch.equal(c, c0), "split-K must be bit-reproducible"
+    d.splitk_slabs = 1
+    with pytest.raises(lib.SlidersHipError, match="slabs"):
+        lib.call(lib.OP_GEMM, d, stream())
     # fused adapter: T is reduced across the slices as well
     A = bf(torch.randn(8, K, device=dev) / math.sqrt(K))
     up = bf(torch.randn(N, 4, device=dev))
     scale = torch.tensor([0.25], device=dev)
-    ws.zero_()
-    T32 = torch.zeros(M, 8, device=dev)
+    ws.fill_(float("nan"))
+    T32 = torch.full((2 * S, M, 8), float("nan"), device=dev)
+    Tout = torch.full((M, 8), float("nan"), device=dev)
     d = lib.GemmDesc(a0=p(x), w=p(w), bias=p(bias), c=p(c), lora_down=p(A), lora_up=p(up), lora_scale=p(scale), lda0=K, ca0=K,
                      mode=0, stride=1, ldw=K, M=M, N=N, K=K, ldc=N, rows_per_sample=M, ld_t=8, lora_groups=2, lora_rank=8,
-                     tile=tile, splitk_c32=p(ws), splitk_t32=p(T32))
+                     tile=tile, splitk_c32=p(ws), splitk_t32=p(T32), splitk_slabs=S, lora_t_out=p(Tout))
     lib.call(lib.OP_GEMM, d, stream())
     torch.cuda.synchronize()
     T = x.float() @ A.float().t()
@@ -666,7 +711,7 @@ def test_gemm_splitk(dev, tile):
     for g in range(2):
         ref[:, g * 160:(g + 1) * 160] += 0.25 * T[:, 4 * g:4 * g + 4] @ up.float()[g * 160:(g + 1) * 160].t()
     report(f"splitk fused lora tile{tile:x}", c, ref, TOL)
-    report(f"splitk fused lora T tile{tile:x}", T32, T, 1e-5)
+    report(f"splitk fused lora T tile{tile:x}", Tout, T, 1e-5)
     # 3x3 convolution, two sources, stride 1
     B, H, W, C0, C1, Co = 2, 8, 8, 128, 64, 128
     i0, i1 = bf(torch.randn(B, C0, H, W, device=dev)), bf(torch.randn(B, C1, H, W, device=dev))
@@ -675,10 +720,10 @@ def test_gemm_splitk(dev, tile):
     x0, x1 = bf(_to_pix(i0.float())), bf(_to_pix(i1.float()))
     Mc = B * H * W
     cc = torch.zeros(Mc, Co, device=dev, dtype=torch.bfloat16)
-    wsc = torch.zeros(Mc, Co, device=dev)
+    wsc = torch.full((S, Mc, Co), float("nan"), device=dev)
     d = lib.GemmDesc(a0=p(x0), a1=p(x1), w=p(_pack_conv(w4)), c=p(cc), lda0=C0, lda1=C1, ca0=C0, ca1=C1, mode=1, batch=B, hs=H,
                      ws=W, stride=1, ho=H, wo=W, ldw=9 * (C0 + C1), M=Mc, N=Co, K=9 * (C0 + C1), ldc=Co, rows_per_sample=H * W,
-                     tile=tile, splitk_c32=p(wsc))
+                     tile=tile, splitk_c32=p(wsc), splitk_slabs=S)
     lib.call(lib.OP_GEMM, d, stream())
     torch.cuda.synchronize()
     report(f"splitk conv 2src tile{tile:x}", cc, ref, TOL)

@@ -172,4 +172,68 @@ def test_full_size_forward_parity(dev, name):
     print(f"[parity] full-size {name} 256x256: engine rel_l2={r:.3e} max_abs={(got - e32).abs().max():.3e} "
           f"eps rms={e32.pow(2).mean().sqrt():.3f} (fp32 oracle forward {time.time() - t0:.1f}s on {os.cpu_count()} cores)")
     assert torch.isfinite(got).all()
-    assert r < 1.1e-2 and (got - e32).abs().max().item() < 1.9e-2      # measured 7.9e-3 / 8.3e-3 and 1.25e-2 / 1.41e-2
+    # rel-L2: measured 7.9e-3 - 8.3e-3.  max-abs is a tail statistic of 8192 outputs whose per-element error is
+    # ~ rel_l2 * rms: its natural range is 2 - 4 sigma (1.25e-2 ... 2.0e-2 seen over boxes in rounds 1-2, while the pass still
+    # differed run to run), so it is bounded at 6 sigma of the ALLOWED rel-L2 instead of at 1.3 x one sample
+    rms = e32.pow(2).mean().sqrt().item()
+    assert r < 1.1e-2 and (got - e32).abs().max().item() < 6 * 1.1e-2 * rms
+
+
+@pytest.mark.parametrize("name,hw", [("tiny_sdxl", 16), ("tiny_sd1", 16), ("tiny_sd2", 16)])
+def test_forward_is_bit_reproducible(dev, name, hw):
+    """Every reduction that feeds bf16 activations runs in a fixed order (GroupNorm statistics: per-workgroup partials
+    combined by the last arriver in index order; split-K: one slab per slice added in slice order; no fp32 atomics), so
+    the same pass on the same inputs gives the same BITS: across replays of one command buffer and across two engines (different arena addresses).  Rounds 1-2 measured rel-L2 7e-3
+    between two runs of one pass - the whole bf16 error budget (profiles/r03_first_call.txt)."""
+    cfg = CONFIGS[name]()
+    net = build_unet(name, seed=0)
+    sd = net.state_dict()
+    x, ctx, kw = make_inputs(cfg, 2, hw)
+    outs = {}
+    for e_i in range(2):
+        eng = UNetEngine(cfg, sd, dev)
+        store = LoraStore(cfg, rank=4, alpha=1.0, train_method="noxattn", device=dev)
+        g = torch.Generator().manual_seed(5)
+        for e in store.entries:
+            store.params[e.up_off:e.up_off + e.up_numel] = (torch.randn(e.up_numel, generator=g) * 0.03).to(dev, torch.bfloat16)
+        eng.attach_lora(store)
+        if e_i == 1:            # shift the second engine's allocations
+            eng(*[t.to(dev) if torch.is_tensor(t) else t for t in (x[:1], torch.tensor(3), ctx[:1])],
+                {k: v[:1].to(dev) for k, v in kw.items()} if kw else None, mode="off")
+        for mode in ("off", "on", "train"):
+            eng.set_lora(mode != "off", 1.5)
+            for rep in range(3):
+                got = run_engine(eng, x, 321, ctx, kw, dev, mode=mode)
+                key = mode
+                if key in outs:
+                    assert torch.equal(got, outs[key]), f"{name} mode {mode} engine {e_i} replay {rep}: pass is not bit-reproducible"
+                else:
+                    outs[key] = got
+        del eng
+    assert not torch.equal(outs["on"], outs["off"])
+
+
+def test_many_shapes_recycle_the_zero_init_arena(dev):
+    """dynamic_resolution / per-prompt resolutions reach dozens of (H, W) shapes; plans never give their span of the
+    zero-init arena back, so the engine drops its cached plans and restarts that arena before it overflows (round 2 aborted
+    with MemoryError after 10-15 shapes).  Results do not depend on whether a plan was rebuilt."""
+    cfg = CONFIGS["tiny_sdxl"]()
+    sd = build_unet("tiny_sdxl", seed=0).state_dict()
+    eng = UNetEngine(cfg, sd, dev, zarena_bytes=96 << 10)
+    eng.Z_PER_SHAPE = 32 << 10
+    shapes = [(8, 8), (8, 16), (16, 8), (16, 16), (8, 24), (24, 8), (16, 24), (24, 16), (24, 24), (8, 32), (32, 8), (32, 32)]
+    first = {}
+    for rnd in range(2):
+        for (h, w) in shapes:
+            g = torch.Generator().manual_seed(h * 100 + w)
+            x = torch.randn(2, 4, h, w, generator=g)
+            ctx = torch.randn(2, 77, cfg.cross_attention_dim, generator=g)
+            kw = {"text_embeds": torch.randn(2, cfg.pooled_dim, generator=g),
+                  "time_ids": torch.tensor([[h * 8.0, w * 8.0, 0, 0, h * 8.0, w * 8.0]] * 2)}
+            got = run_engine(eng, x, 500, ctx, kw, dev, mode="off")
+            assert torch.isfinite(got).all()
+            if rnd == 0:
+                first[(h, w)] = got
+            else:
+                assert torch.equal(got, first[(h, w)])
+    assert eng.plan_flushes >= 1, "the test must exercise the recycling path"
