@@ -13,6 +13,10 @@ loss, backward into the adapters, (all-reduce,) AdamW.  The metric counts UNet d
 Weights are seeded random-init with the real SDXL shapes and text embeddings are seeded randn (no checkpoints
 exist offline) - throughput does not depend on the values.
 
+"extra_configs" (N=1 default run only): the same loop on BASELINE configs[1] (SD-1.x 512x512 text slider) and configs[4] (SDXL
+image slider, 512x512 pairs, VAE encode on the GPU, with "vae_roofline" for the fp32 VAE GEMM in both arithmetic modes), timed by
+this process after the contract line.
+
 Extra JSON objects: "roofline" for the dominant kernel (bf16 MFMA GEMM instantiation with the largest share
 of a UNet pass; algorithmic FLOPs / HIP-event time, measured live on the launch stream) and "cpu_baseline"
 (the CPU oracle = PyTorch restatement of the reference's diffusers UNet, bf16 oneDNN, one UNet denoise step of
@@ -44,6 +48,9 @@ def parse():
                     help="text: BASELINE configs[2] (the contract line); image: configs[4], SDXL image slider, 512x512 pairs, VAE encode on the GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true",
+                    help="skip the extra_configs objects (BASELINE configs[1] SD-1.x 512x512 text slider, configs[4] SDXL image slider)")
+    ap.add_argument("--vae-exact-fp32", action="store_true", help="image workload: exact-fp32 MFMA VAE instead of the bf16 hi/lo split")
     ap.add_argument("--seed", type=int, default=0)
     return ap.parse_args()
 
@@ -193,6 +200,55 @@ def measure_roofline(eng, plan):
     }
 
 
+def measure_vae_roofline(vae, vae_sd, image, res_px):
+    """The VAE encoder's GEMM kernel (slh_sgemm: 3x3 convolutions and the mid-block attention of AutoencoderKL in fp32,
+    imagesliders/train_util.py:200-235) in BOTH arithmetic modes on the same image: exact fp32 (v_mfma_f32_32x32x2_f32,
+    peak 157.3 TFLOP/s) and the default bf16 hi/lo split (three bf16 MFMAs per product: peak 2500 / 3 TFLOP/s)."""
+    from sliders_amd import lib
+    from sliders_amd.vae import VaeEncoder
+    stream = torch.cuda.current_stream()
+    s = stream.cuda_stream
+    out = {}
+    for mode, enc in (("split_bf16", vae if vae.split_bf16 else None), ("exact_fp32", vae if not vae.split_bf16 else None)):
+        if enc is None:
+            enc = VaeEncoder(vae_sd, vae.device, vae.scaling_factor, exact_fp32=(mode == "exact_fp32"))
+        enc.encode_moments(image)
+        plan = enc.plan(1, res_px, res_px)
+        torch.cuda.synchronize()
+        t0 = time.time()
+        for _ in range(3):
+            plan.prog.run(s)
+        torch.cuda.synchronize()
+        enc_ms = (time.time() - t0) / 3 * 1e3
+        ms = flops = 0.0
+        n = 0
+        evs = []
+        for opcode, d in plan.prog.ops:
+            if opcode == lib.OP_SGEMM:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(stream)
+                lib.call(opcode, d, s)
+                e1.record(stream)
+                evs.append((d, e0, e1))
+            elif opcode in lib._ENTRY:
+                lib.call(opcode, d, s)
+            else:
+                one = lib.Program()
+                one.add(opcode, d)
+                one.run(s)
+        torch.cuda.synchronize()
+        for d, e0, e1 in evs:
+            ms += e0.elapsed_time(e1); flops += 2.0 * d.M * d.N * d.K; n += 1
+        peak = 157.3 if mode == "exact_fp32" else MFMA_PEAK_TFLOPS / 3.0
+        ach = flops / (ms * 1e-3) / 1e12
+        out[mode] = {"bound": "mfma", "kernel": "sgemm_kernel", "achieved": round(ach, 1), "peak": round(peak, 1), "unit": "TFLOP/s",
+                     "frac": round(ach / peak, 4), "launches": n, "sgemm_ms_per_encode": round(ms, 3),
+                     "encode_ms": round(enc_ms, 3), "algorithmic_tflop_per_encode": round(flops / 1e12, 4)}
+    out["note"] = ("one %dx%d image; fp32 algorithmic FLOPs 2*M*N*K of every slh_sgemm launch / HIP-event time, op-by-op replay of the "
+                   "encoder's command buffer; split mode executes 3 bf16 MFMA FLOPs per algorithmic FLOP" % (res_px, res_px))
+    return out
+
+
 def _mem_limit_gb():
     for path in ("/sys/fs/cgroup/memory.max", "/sys/fs/cgroup/memory/memory.limit_in_bytes"):
         try:
@@ -324,13 +380,34 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    if world > 1 or os.environ.get("BENCH_FORCE_PROCESS_GROUP"):      # the second form: the torchrun path on one GPU (tests/test_rccl_gpu.py)
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local)
         torch.distributed.init_process_group("nccl", device_id=torch.device("cuda", local))
-    dev = torch.device("cuda", local if world > 1 else 0)
+    dev = torch.device("cuda", local if torch.distributed.is_initialized() else 0)
     torch.cuda.set_device(dev)
+    res = run_config(a, dev, world, rank, main_line=True)
+    if rank == 0 and world == 1 and not a.no_extra and a.workload == "text" and a.model == "sdxl" and a.res == 1024:
+        # the other single-GPU configurations of BASELINE.json, timed by the same process right after the contract line
+        # (untimed for the contract): configs[1] and configs[4]
+        extra = []
+        for model, res_px, workload in (("sd1", 512, "text"), ("sdxl", 512, "image")):
+            b = argparse.Namespace(**vars(a))
+            b.model, b.res, b.workload, b.steps, b.warmup, b.no_cpu_baseline = model, res_px, workload, max(a.steps, 6), 1, True
+            torch.cuda.empty_cache()
+            try:
+                extra.append(run_config(b, dev, world, rank, main_line=False))
+            except Exception as e:          # the contract line must survive whatever an extra configuration does
+                extra.append({"config": {"workload": f"{model} {workload} {res_px}"}, "error": f"{type(e).__name__}: {e}"})
+        res["extra_configs"] = extra
+    if rank == 0:
+        print(json.dumps(res), flush=True)
+    if torch.distributed.is_initialized():
+        torch.distributed.barrier()      # ranks > 0 wait for rank 0's (untimed) roofline replay before tearing down
+        torch.distributed.destroy_process_group()
 
+
+def run_config(a, dev, world, rank, main_line):
     from sliders_amd.config import CONFIGS
     from sliders_amd.lora_store import LoraStore
     from sliders_amd.random_init import random_state_dict
@@ -373,7 +450,8 @@ def main():
         # results it never uses; they are not executed here and NOT counted: 2 UNet denoise steps per iteration.
         from sliders_amd.image_trainer import ImageSliderTrainer
         from sliders_amd.vae import VAE_SCALING, VaeEncoder, random_vae_state_dict
-        vae = VaeEncoder(random_vae_state_dict(device=dev, seed=a.seed), dev, VAE_SCALING["sdxl" if cfg.is_xl else "sd1"])
+        vae_sd = random_vae_state_dict(device=dev, seed=a.seed)
+        vae = VaeEncoder(vae_sd, dev, VAE_SCALING["sdxl" if cfg.is_xl else "sd1"], exact_fp32=a.vae_exact_fp32)
         tri = ImageSliderTrainer(eng, store, vae, hw, hw, batch_size=1, lr=2e-4)
         gi = torch.Generator().manual_seed(99 + rank)
         imgs = [VaeEncoder.preprocess(torch.randint(0, 256, (a.res, a.res, 3), generator=gi, dtype=torch.uint8)).to(dev)
@@ -387,8 +465,10 @@ def main():
             return -2                    # +4 below -> 2 steps
         tr = tri
 
+    dist_on = torch.distributed.is_available() and torch.distributed.is_initialized()
+
     def barrier():
-        if world > 1:
+        if dist_on:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
@@ -401,13 +481,13 @@ def main():
         unet_steps += one_step(a.warmup + i) + 4
     barrier()
     dt = time.time() - t0
-    if world > 1:
+    if dist_on:
         tdt = torch.tensor([dt], device=dev)
         torch.distributed.all_reduce(tdt, op=torch.distributed.ReduceOp.MAX)
         dt = float(tdt.item())
     loss = float(tr.loss_low.item() if a.workload == "image" else tr.loss.item())
     value_no_dedup = None
-    if a.workload == "text" and rank == 0 and world == 1:
+    if a.workload == "text" and rank == 0 and world == 1 and main_line:
         # the headline counts the de-duplicated B=3 frozen pass as the 3 predictions the reference executes; the same loop
         # with the three CFG-pair passes actually run, for comparison (not the contract value)
         tr.dedup_frozen = False
@@ -431,7 +511,8 @@ def main():
                                 f"(CFG pair), DDIM-50 partial denoise k~U{{1..49}} + 4 predictions + backward + AdamW")
                                if a.workload == "text" else
                                (f"{a.model} image slider rank=4 alpha=1 noxattn+c3lier, {a.res}x{a.res} image pair, batch 1 (CFG pair): "
-                                f"2 fp32 VAE encodes + add_noise on the GPU, 2 predictions with grad (+scale / -scale), 2 backward "
+                                f"2 fp32 VAE encodes ({'exact-fp32 MFMA' if a.vae_exact_fp32 else 'fp32 operands as bf16 hi+lo halves, 3 bf16 MFMAs per product, fp32 accumulation'}) "
+                                f"+ add_noise on the GPU, 2 predictions with grad (+scale / -scale), 2 backward "
                                 f"passes, AdamW; 2 UNet denoise steps per iteration (the reference's 2 unused no-grad predictions are "
                                 f"not run and not counted)"),
                    "bench_step": "one training iteration", "unet_denoise_steps_timed": unet_steps * world,
@@ -444,14 +525,12 @@ def main():
     if rank == 0 and not a.no_roofline:
         eng.set_lora(True, 1.0)
         res["roofline"] = measure_roofline(eng, eng.plan(2, hw, hw, "on" if a.workload == "text" else "train"))
+        if a.workload == "image":
+            res["vae_roofline"] = measure_vae_roofline(vae, vae_sd, imgs[0], a.res)
     if rank == 0 and world == 1:
         if not a.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(a.model, hw)
-    if rank == 0:
-        print(json.dumps(res), flush=True)
-    if world > 1:
-        torch.distributed.barrier()      # ranks > 0 wait for rank 0's (untimed) roofline replay before tearing down
-        torch.distributed.destroy_process_group()
+    return res
 
 
 if __name__ == "__main__":

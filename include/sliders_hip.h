@@ -160,13 +160,16 @@ typedef struct slh_gn_desc {
     int32_t act;             /* 0 none, 1 SiLU */
     /* slh_gn_stats only.  The reduction is done in a fixed order (bit-reproducible, no fp32 atomics): every workgroup
      * publishes one (sum, sum of squares) pair per group and the last one to arrive combines them in index order. */
-    float* partial;          /* [batch][slh_gn_row_blocks(c0+c1, hw, groups)][groups][2] fp32 scratch, any contents */
-    uint32_t* ticket;        /* [batch] arrival counters, ZERO before the launch (left zero by it) */
+    /* with R = slh_gn_row_blocks(c0+c1, hw, groups) workgroups per sample and L = slh_gn_clusters(R) clusters of them
+     * (two-level combine: the serial tail behind the last workgroup stays two round trips at any tensor size): */
+    float* partial;          /* [batch][R + L][groups][2] fp32 scratch, any contents */
+    uint32_t* ticket;        /* [batch][1 + L] arrival counters, ZERO before the launch (left zero by it) */
 } slh_gn_desc;
 int slh_gn_stats(const slh_gn_desc* d, slh_stream_t stream);
 int slh_gn_apply(const slh_gn_desc* d, slh_stream_t stream);
-/* workgroups per sample of slh_gn_stats / slh_gn_bwd_stats (sizes `partial`); -1 for an unsupported shape */
+/* workgroups per sample of slh_gn_stats / slh_gn_bwd_stats, and the clusters they form; -1 for an unsupported shape */
 int slh_gn_row_blocks(int channels, int hw, int groups);
+int slh_gn_clusters(int row_blocks);
 
 /* GroupNorm backward (dx only: gamma/beta are frozen).  Two launches like the forward:
  * bwd_stats reduces per (b,g) sum(dyhat) and sum(dyhat*xhat) into bstats (fixed order, see slh_gn_desc),
@@ -184,7 +187,7 @@ typedef struct slh_gn_bwd_desc {
     int32_t act;
     int32_t accumulate0, accumulate1; /* dx += instead of = */
     float* bpartial;         /* slh_gn_bwd_stats: scratch like slh_gn_desc.partial */
-    uint32_t* bticket;       /* slh_gn_bwd_stats: [batch] zeroed arrival counters */
+    uint32_t* bticket;       /* slh_gn_bwd_stats: zeroed arrival counters like slh_gn_desc.ticket */
 } slh_gn_bwd_desc;
 int slh_gn_bwd_stats(const slh_gn_bwd_desc* d, slh_stream_t stream);
 int slh_gn_bwd_apply(const slh_gn_bwd_desc* d, slh_stream_t stream);
@@ -414,8 +417,9 @@ typedef struct slh_gn32_desc {
     int32_t ldx, ldy, C, batch, hw, groups;
     float eps;
     int32_t act;            /* 0 none, 1 SiLU */
-    float* partial;         /* slh_gn32_stats: [batch][slh_gn32_row_blocks(hw)][groups][2] fp32 scratch (see slh_gn_desc) */
-    uint32_t* ticket;       /* slh_gn32_stats: [batch] arrival counters, zero before the launch */
+    float* partial;         /* slh_gn32_stats: [batch][R + L][groups][2] fp32 scratch, R = slh_gn32_row_blocks(hw),
+                               L = slh_gn_clusters(R) (see slh_gn_desc) */
+    uint32_t* ticket;       /* slh_gn32_stats: [batch][1 + L] arrival counters, zero before the launch */
 } slh_gn32_desc;
 int slh_gn32_stats(const slh_gn32_desc* d, slh_stream_t stream);
 int slh_gn32_apply(const slh_gn32_desc* d, slh_stream_t stream);

@@ -107,11 +107,14 @@ def train(config, prompts, device: int, xl: bool, folder_main: str, folders, sca
     hw = size // 8
     tr = ImageSliderTrainer(eng, store, vae, hw, hw, batch_size=1, lr=config.train.lr, betas=opt["betas"], eps=opt["eps"],
                             weight_decay=opt["weight_decay"], max_denoising_steps=config.train.max_denoising_steps,
-                            process_group=torch.distributed.group.WORLD if world > 1 else None, optimizer=opt["name"])
+                            process_group=torch.distributed.group.WORLD if world > 1 else None, optimizer=opt["name"],
+                            optimizer_kwargs={k: v for k, v in opt.items() if k not in ("name", "betas", "eps", "weight_decay")})
     pairs = (_synthetic_pairs(eng.cfg, prompts, dev, seed) if synthetic else
              _encoded_pairs(eng.cfg, prompts, config.pretrained_model.name_or_path, dev,
                             config_util.parse_precision(config.train.precision)))
-    samp = StepSampler(seed, rank, world, len(pairs), config.train.max_denoising_steps)
+    # k ~ U{1 .. max-1} for the XL script (train_lora-scale-xl.py:191-193) but U{1 .. max-2} for the SD-1.x one, whose
+    # randint has max_denoising_steps - 1 as its exclusive bound (train_lora-scale.py:186-188)
+    samp = StepSampler(seed, rank, world, len(pairs), config.train.max_denoising_steps - (0 if xl else 1))
     sched = LrSchedule(config.train.lr_scheduler, config.train.lr, config.train.iterations)
     pyrng = random.Random(seed * 7919 + rank)              # image / scale choice is rank-local (different data per rank)
     save_path = Path(config.save.path)

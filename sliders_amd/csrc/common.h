@@ -144,16 +144,23 @@ __device__ __forceinline__ bool gn_block_reduce(float* lds, int C, int cg, int g
 }
 
 // Sum of the `count` published pairs partial[(i * groups + g) * 2 ..] of group g = tid / lpg in index order (double);
-// valid in the threads t = g * lpg.
+// valid in the threads t = g * lpg.  The loads are independent sc1 (L2-bypassing) reads of ~1-2 us each: they are issued
+// 16 at a time, only the additions are ordered.
 __device__ __forceinline__ void gn_combine_partials(const float* partial, int count, int groups, int lpg, double& S, double& Q) {
     const int tid = threadIdx.x;
     const int g = tid / lpg, j = tid & (lpg - 1);
     double a = 0.0, b = 0.0;
     if (g < groups) {
-        for (int i = j; i < count; i += lpg) {
-            const f32x2 v = load_pair_sc1(partial + ((long)i * groups + g) * 2);
-            a += (double)v[0];
-            b += (double)v[1];
+        constexpr int U = 16;
+        for (int i0 = j; i0 < count; i0 += U * lpg) {
+            f32x2 v[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int i = i0 + u * lpg;
+                v[u] = i < count ? load_pair_sc1(partial + ((long)i * groups + g) * 2) : f32x2{0.f, 0.f};
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) { a += (double)v[u][0]; b += (double)v[u][1]; }
         }
     }
     for (int o = lpg >> 1; o > 0; o >>= 1) {
@@ -161,6 +168,33 @@ __device__ __forceinline__ void gn_combine_partials(const float* partial, int co
         b += __shfl_xor(b, o, 64);
     }
     S = a; Q = b;
+}
+
+// Two-level fixed-order reduction of one sample's published pairs (GroupNorm statistics kernels).  The row blocks of a
+// sample form clusters of GN_CLUSTER; the last block to arrive in a cluster adds its cluster's pairs (level 1) and
+// publishes one pair per group, the last CLUSTER to finish adds those (level 2).  Each level is one batch of 16 loads
+// per lane, so the serial tail behind the last workgroup is two L2-bypassing round trips, whatever the tensor size
+// (a flat combine of 1024 row blocks cost 50 us of dependent loads).
+//   part   : [row_blocks + nclusters][groups][2]   level-1 pairs, then level-2 pairs
+//   ticket : [1 + nclusters]                       ticket[0] = level 2, ticket[1 + c] = cluster c
+// Returns true in the threads t = g * lpg (g < groups) of the ONE workgroup that ends up with the sample's totals.
+constexpr int GN_CLUSTER = 32;
+__device__ __forceinline__ bool gn_two_level_reduce(float* part, unsigned* ticket, int row_blocks, int rb, int groups, int lpg,
+                                                    bool owner, float S1, float Q1, int* lds_flag, double& S, double& Q) {
+    const int tid = threadIdx.x;
+    const int g = tid / lpg;
+    const int ncl = (row_blocks + GN_CLUSTER - 1) / GN_CLUSTER;
+    const int cl = rb / GN_CLUSTER;
+    if (owner) store_pair_sc1(part + ((long)rb * groups + g) * 2, S1, Q1);
+    const int first = cl * GN_CLUSTER;
+    const int members = min(GN_CLUSTER, row_blocks - first);
+    if (!last_arriver(ticket + 1 + cl, (unsigned)members, lds_flag)) return false;
+    gn_combine_partials(part + (long)first * groups * 2, members, groups, lpg, S, Q);
+    if (ncl == 1) return g < groups && (tid & (lpg - 1)) == 0;
+    if (g < groups && (tid & (lpg - 1)) == 0) store_pair_sc1(part + ((long)(row_blocks + cl) * groups + g) * 2, (float)S, (float)Q);
+    if (!last_arriver(ticket, (unsigned)ncl, lds_flag)) return false;
+    gn_combine_partials(part + (long)row_blocks * groups * 2, ncl, groups, lpg, S, Q);
+    return g < groups && (tid & (lpg - 1)) == 0;
 }
 
 // ---- host side -------------------------------------------------------------------------------

@@ -49,25 +49,42 @@ __global__ void gn_stats_kernel(const slh_gn_desc d, int nchunk, int rpi, int ro
     const int r0 = blockIdx.x * rows_per_block;
     const int r1 = min(d.hw, r0 + rows_per_block);
     float ks[8], s[8], q[8];
+    if (cg >= 8) {          // 8 consecutive channels touch at most two groups: two shift loads
+        const int ga = c / cg, gb = (c + 7) / cg;
+        const float ka = (float)*gn_src(d, (long)b * d.hw, ga * cg), kb = (float)*gn_src(d, (long)b * d.hw, gb * cg);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        ks[e] = (float)*gn_src(d, (long)b * d.hw, ((c + e) / cg) * cg);
-        s[e] = 0.f; q[e] = 0.f;
+        for (int e = 0; e < 8; ++e) ks[e] = (c + e) / cg == ga ? ka : kb;
+    } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) ks[e] = (float)*gn_src(d, (long)b * d.hw, ((c + e) / cg) * cg);
     }
-    for (int r = r0 + rl; r < r1; r += rpi) {
-        const bf16x8 v = *(const bf16x8*)gn_src(d, (long)b * d.hw + r, c);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { const float f = (float)v[e] - ks[e]; s[e] += f; q[e] += f * f; }
+    for (int e = 0; e < 8; ++e) { s[e] = 0.f; q[e] = 0.f; }
+    {
+        // all of the thread's rows are requested before the first one is used (HBM latency paid once, not GN_ITERS times)
+        bf16x8 v[GN_ITERS];
+#pragma unroll
+        for (int it = 0; it < GN_ITERS; ++it) {
+            const int r = r0 + rl + it * rpi;
+            if (r < r1) v[it] = *(const bf16x8*)gn_src(d, (long)b * d.hw + r, c);
+        }
+#pragma unroll
+        for (int it = 0; it < GN_ITERS; ++it) {
+            const int r = r0 + rl + it * rpi;
+            if (r < r1) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { const float f = (float)v[it][e] - ks[e]; s[e] += f; q[e] += f * f; }
+            }
+        }
     }
     float S, Q;
     const bool owner = gn_block_reduce<8>(gn_lds, C, cg, d.groups, rpi, lpg, chunk, rl, s, q, S, Q);
-    float* part = d.partial + (long)b * row_blocks * d.groups * 2;
-    if (owner) store_pair_sc1(part + ((long)blockIdx.x * d.groups + tid / lpg) * 2, S, Q);
-    if (!last_arriver(d.ticket + b, (unsigned)row_blocks, (int*)(gn_lds + 2 * rpi * C))) return;
+    const int ncl = (row_blocks + GN_CLUSTER - 1) / GN_CLUSTER;
     double Sd, Qd;
-    gn_combine_partials(part, row_blocks, d.groups, lpg, Sd, Qd);
+    const bool fin = gn_two_level_reduce(d.partial + (long)b * (row_blocks + ncl) * d.groups * 2, d.ticket + (long)b * (1 + ncl),
+                                         row_blocks, blockIdx.x, d.groups, lpg, owner, S, Q, (int*)(gn_lds + 2 * rpi * C), Sd, Qd);
     const int g = tid / lpg;
-    if (g < d.groups && (tid & (lpg - 1)) == 0) {
+    if (fin) {
         const double n = (double)d.hw * (double)cg;
         const double k = (double)(float)*gn_src(d, (long)b * d.hw, g * cg);
         const double m = Sd / n;
@@ -95,13 +112,21 @@ __global__ void gn_apply_kernel(const slh_gn_desc d, int nchunk, int rpi, int ro
         a[e] = rstd * (float)gm[e];
         sft[e] = (float)bt[e] - mean * a[e];
     }
-    for (int r = r0 + rl; r < r1; r += rpi) {
+    bf16x8 v[GN_ITERS];
+#pragma unroll
+    for (int it = 0; it < GN_ITERS; ++it) {
+        const int r = r0 + rl + it * rpi;
+        if (r < r1) v[it] = *(const bf16x8*)gn_src(d, (long)b * d.hw + r, c);
+    }
+#pragma unroll
+    for (int it = 0; it < GN_ITERS; ++it) {
+        const int r = r0 + rl + it * rpi;
+        if (r >= r1) continue;
         const long row = (long)b * d.hw + r;
-        const bf16x8 v = *(const bf16x8*)gn_src(d, row, c);
         bf16x8 o;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            float y = (float)v[e] * a[e] + sft[e];
+            float y = (float)v[it][e] * a[e] + sft[e];
             if (d.act == 1) y = silu_f(round_bf16(y));  // reference rounds the GroupNorm output to bf16 before SiLU
             o[e] = (__bf16)y;
         }
@@ -166,13 +191,12 @@ __global__ void gn_bwd_stats_kernel(const slh_gn_bwd_desc d, int nchunk, int rpi
     }
     float S, Q;
     const bool owner = gn_block_reduce<8>(gn_lds, C, cg, d.groups, rpi, lpg, chunk, rl, s, q, S, Q);
-    float* part = d.bpartial + (long)b * row_blocks * d.groups * 2;
-    if (owner) store_pair_sc1(part + ((long)blockIdx.x * d.groups + tid / lpg) * 2, S, Q);
-    if (!last_arriver(d.bticket + b, (unsigned)row_blocks, (int*)(gn_lds + 2 * rpi * C))) return;
+    const int ncl = (row_blocks + GN_CLUSTER - 1) / GN_CLUSTER;
     double Sd, Qd;
-    gn_combine_partials(part, row_blocks, d.groups, lpg, Sd, Qd);
+    const bool fin = gn_two_level_reduce(d.bpartial + (long)b * (row_blocks + ncl) * d.groups * 2, d.bticket + (long)b * (1 + ncl),
+                                         row_blocks, blockIdx.x, d.groups, lpg, owner, S, Q, (int*)(gn_lds + 2 * rpi * C), Sd, Qd);
     const int g = tid / lpg;
-    if (g < d.groups && (tid & (lpg - 1)) == 0) {
+    if (fin) {
         d.bstats[((long)b * d.groups + g) * 2] = (float)Sd;
         d.bstats[((long)b * d.groups + g) * 2 + 1] = (float)Qd;
     }
@@ -330,6 +354,8 @@ extern "C" int slh_gn_row_blocks(int channels, int hw, int groups) {
     if (channels <= 0 || channels % 8 || hw <= 0 || groups <= 0 || channels % groups) return -1;
     return gn_geom(channels, 0, hw, groups).row_blocks;
 }
+
+extern "C" int slh_gn_clusters(int row_blocks) { return row_blocks > 0 ? (row_blocks + GN_CLUSTER - 1) / GN_CLUSTER : -1; }
 
 extern "C" int slh_gn_stats(const slh_gn_desc* d, slh_stream_t stream) {
     SLH_CHECK(d && d->x0 && d->stats, "slh_gn_stats: null pointer");

@@ -373,13 +373,12 @@ __global__ __launch_bounds__(256) void gn32_stats_kernel(const slh_gn32_desc d, 
     }
     float S, Q;
     const bool owner = gn_block_reduce<4>(gn_lds, d.C, cg, d.groups, rpi, lpg, chunk, rl, s, q, S, Q);
-    float* part = d.partial + (long)b * row_blocks * d.groups * 2;
-    if (owner) store_pair_sc1(part + ((long)blockIdx.x * d.groups + tid / lpg) * 2, S, Q);
-    if (!last_arriver(d.ticket + b, (unsigned)row_blocks, (int*)(gn_lds + 2 * rpi * d.C))) return;
+    const int ncl = (row_blocks + GN_CLUSTER - 1) / GN_CLUSTER;
     double Sd, Qd;
-    gn_combine_partials(part, row_blocks, d.groups, lpg, Sd, Qd);
+    const bool fin = gn_two_level_reduce(d.partial + (long)b * (row_blocks + ncl) * d.groups * 2, d.ticket + (long)b * (1 + ncl),
+                                         row_blocks, blockIdx.x, d.groups, lpg, owner, S, Q, (int*)(gn_lds + 2 * rpi * d.C), Sd, Qd);
     const int g = tid / lpg;
-    if (g < d.groups && (tid & (lpg - 1)) == 0) {
+    if (fin) {
         const double n = (double)d.hw * (double)cg;
         const double kg = (double)X[(long)b * d.hw * d.ldx + g * cg];
         const double m = Sd / n;

@@ -127,7 +127,7 @@ _ENTRY = {
 }
 
 EXPORTS = ["slh_version", "slh_last_error", "slh_run_program", "slh_desc_sizes", "slh_graph_capture", "slh_graph_launch",
-           "slh_graph_destroy", "slh_gemm_variant", "slh_gn_row_blocks", "slh_gn32_row_blocks"] + [v[0] for v in _ENTRY.values()]
+           "slh_graph_destroy", "slh_gemm_variant", "slh_gn_row_blocks", "slh_gn_clusters", "slh_gn32_row_blocks"] + [v[0] for v in _ENTRY.values()]
 
 
 class SlidersHipError(RuntimeError):
@@ -185,16 +185,22 @@ def check(rc: int, what: str = ""):
         raise SlidersHipError(f"{what} failed (rc={rc}): {last_error()}")
 
 
-def gn_row_blocks(channels: int, hw: int, groups: int) -> int:
-    """Workgroups per sample of slh_gn_stats / slh_gn_bwd_stats: sizes their partial-sum workspace."""
-    n = load().slh_gn_row_blocks(channels, hw, groups)
-    if n <= 0:
+def gn_workspace(channels: int, hw: int, groups: int):
+    """(rows of the [rows][groups][2] fp32 partial-sum scratch, zeroed uint32 tickets) PER SAMPLE of slh_gn_stats /
+    slh_gn_bwd_stats (include/sliders_hip.h, slh_gn_desc)."""
+    l = load()
+    r = l.slh_gn_row_blocks(channels, hw, groups)
+    if r <= 0:
         raise SlidersHipError(f"slh_gn_row_blocks({channels}, {hw}, {groups}): unsupported shape")
-    return n
+    c = l.slh_gn_clusters(r)
+    return r + c, 1 + c
 
 
-def gn32_row_blocks(hw: int) -> int:
-    return load().slh_gn32_row_blocks(hw)
+def gn32_workspace(hw: int):
+    l = load()
+    r = l.slh_gn32_row_blocks(hw)
+    c = l.slh_gn_clusters(r)
+    return r + c, 1 + c
 
 
 def gemm_variant(desc) -> int:

@@ -64,7 +64,7 @@ class Act:
 
 Src = Union[Act, Tuple[Act, Act]]
 
-SPLITK_MAX_MN = 1 << 20          # output elements up to which a split-K workspace is provisioned (4 MB fp32)
+SPLITK_MAX_MN = 6 << 20          # output elements up to which split-K is considered (one 24 MB fp32 slab per slice at most)
 SPLITK_MIN_K = 2048
 
 
@@ -81,7 +81,7 @@ def splitk_wanted(d) -> bool:
     for every candidate."""
     if not splitk_candidate(d):
         return False
-    if os.environ.get("SLIDERS_NO_TUNING"):
+    if os.environ.get("SLIDERS_NO_TUNING") or os.environ.get("SLIDERS_SPLITK_ALL"):
         return True
     return ((d.tile >> 16) & 15) > 1 if d.tile else bool(default_splitk(d))
 
@@ -104,9 +104,10 @@ def provision_splitk(plan, d, name: str):
     fused adapter, two [M][ld_t] slabs per slice for T.  Fixes d.tile for untuned shapes."""
     if not splitk_wanted(d):
         return
-    if not d.tile:
+    if not d.tile and d.M * d.N <= (1 << 20):      # the untuned default only for the small products it was measured on
         d.tile = default_splitk(d)
-    slabs = SPLITK_TUNING_SLABS if os.environ.get("SLIDERS_NO_TUNING") else (d.tile >> 16) & 15
+    tuning = os.environ.get("SLIDERS_NO_TUNING") or os.environ.get("SLIDERS_SPLITK_ALL")
+    slabs = max(SPLITK_TUNING_SLABS if tuning else 0, (d.tile >> 16) & 15)
     if slabs < 2:
         return
     d.splitk_slabs = slabs
@@ -292,8 +293,9 @@ class UNetPlan:
         # statistics are reduced in a fixed order (bit-reproducible pass): per-workgroup partials + arrival tickets; only
         # the tickets need the zeroed arena
         stats = self.f32((B, G, 2), name + ".stats")
-        part = self.f32((B, lib.gn_row_blocks(C, H * W, G), G, 2), name + ".partial")
-        ticket = self.f32((B,), name + ".ticket", zero=True)
+        prow, ntick = lib.gn_workspace(C, H * W, G)
+        part = self.f32((B, prow, G, 2), name + ".partial")
+        ticket = self.f32((B, ntick), name + ".ticket", zero=True)
         y = self.act(B, H, W, C, name)
         d = lib.GnDesc(x0=x0.ptr, x1=x1.ptr if x1 else 0, gamma=self.w.ptr(wname + ".g"), beta=self.w.ptr(wname + ".b"),
                        stats=stats.ptr, y=y.ptr, ldx0=x0.ld, ldx1=x1.ld if x1 else 0, c0=x0.C, c1=x1.C if x1 else 0,
@@ -647,9 +649,9 @@ class BackwardPlan:
         gy, _ = self.grad(y, write=False)
         G = self.cfg.norm_num_groups
         bst = self.arena.alloc((self.nb, G, 2), torch.float32, "bwd." + rec["name"] + ".bstats")
-        bpart = self.arena.alloc((self.nb, lib.gn_row_blocks(x0.C + (x1.C if x1 is not None else 0), x0.HW, G), G, 2),
-                                 torch.float32, "bwd." + rec["name"] + ".bpartial")
-        btick = self.zarena.alloc((self.nb,), torch.float32, "bwd." + rec["name"] + ".bticket")
+        prow, ntick = lib.gn_workspace(x0.C + (x1.C if x1 is not None else 0), x0.HW, G)
+        bpart = self.arena.alloc((self.nb, prow, G, 2), torch.float32, "bwd." + rec["name"] + ".bpartial")
+        btick = self.zarena.alloc((self.nb, ntick), torch.float32, "bwd." + rec["name"] + ".bticket")
         x0s = self._sl(x0)
         x1s = self._sl(x1) if x1 is not None else None
         g0, a0 = self.grad(x0) if need0 else (None, False)

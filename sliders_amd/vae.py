@@ -95,6 +95,21 @@ class _Plan:
         self.prog, self.io, self.arena = prog, io, arena
 
 
+# The vae/diffusion_pytorch_model.safetensors of CompVis/stable-diffusion-v1-4 and runwayml/stable-diffusion-v1-5 (the
+# reference's SD-1.x defaults) still carry the mid-block attention under its deprecated names; diffusers renames them at load
+# time (modeling_utils._convert_deprecated_attention_blocks), and so must anything that reads the file directly.
+_DEPRECATED_ATTN = {"query": "to_q", "key": "to_k", "value": "to_v", "proj_attn": "to_out.0"}
+_ATTN_W = tuple(f"attentions.0.{n}.weight" for n in ("to_q", "to_k", "to_v", "to_out.0"))
+
+
+def normalize_vae_key(k: str) -> str:
+    parts = k.split(".")
+    if len(parts) >= 2 and "attentions" in parts and parts[-2] in _DEPRECATED_ATTN:
+        parts[-2] = _DEPRECATED_ATTN[parts[-2]]
+        return ".".join(parts)
+    return k
+
+
 class _VaeNet:
     """Weights + the op emitters shared by the encoder and the decoder command buffers."""
     PREFIXES: Tuple[str, ...] = ()
@@ -117,6 +132,9 @@ class _VaeNet:
         for k, v in state_dict.items():
             if not k.startswith(self.PREFIXES):
                 continue
+            k = normalize_vae_key(k)
+            if k.endswith(_ATTN_W) and v.ndim == 4:       # pre-0.18 checkpoints keep the attention projections as 1x1 convs
+                v = v.reshape(v.shape[0], v.shape[1])
             if k.endswith(".weight") and v.ndim == 4 and v.shape[2] == 3:
                 self.w[k] = c3(v)
             elif k.endswith(".weight") and v.ndim == 4:
@@ -139,8 +157,9 @@ class _VaeNet:
     def _gn(self, x: Buf, C, hw, name, silu):
         B = self._B
         stats = self._arena.alloc((B, 32, 2), torch.float32, name + ".stats")
-        part = self._arena.alloc((B, lib.gn32_row_blocks(hw), 32, 2), torch.float32, name + ".partial")
-        ticket = self._zarena.alloc((B,), torch.float32, name + ".ticket")      # arrival counters of the fixed-order reduction
+        prow, ntick = lib.gn32_workspace(hw)
+        part = self._arena.alloc((B, prow, 32, 2), torch.float32, name + ".partial")
+        ticket = self._zarena.alloc((B, ntick), torch.float32, name + ".ticket")      # arrival counters of the fixed-order reduction
         y = self._act(B * hw, C, name)
         d = lib.Gn32Desc(x=x.ptr, gamma=self._wp(name + ".weight"), beta=self._wp(name + ".bias"), stats=stats.ptr, y=y.ptr,
                          ldx=C, ldy=C, C=C, batch=B, hw=hw, groups=32, eps=1e-6, act=1 if silu else 0,

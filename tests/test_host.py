@@ -498,3 +498,49 @@ def test_host_helpers_match_the_reference_run():
             lrs.append(s.current())
             s.step()
         assert [lrs[i] for i in idx] == gold[f"lr/{name}"], name
+
+
+def test_vae_checkpoints_with_deprecated_attention_names_are_normalised():
+    """SD-1.4 / 1.5 VAE files name the mid-block attention query / key / value / proj_attn (1x1 convs in the oldest ones);
+    diffusers renames them at load time, VaeEncoder / VaeDecoder read the file directly and must do the same."""
+    from sliders_amd.vae import normalize_vae_key, random_vae_state_dict
+    new = random_vae_state_dict(boc=(32, 64), decoder=True)
+    back = {"to_q": "query", "to_k": "key", "to_v": "value", "to_out.0": "proj_attn"}
+    old = {}
+    for k, v in new.items():
+        ko = k
+        for n, o in back.items():
+            if f".attentions.0.{n}." in k:
+                ko = k.replace(f".attentions.0.{n}.", f".attentions.0.{o}.")
+        old[ko] = v
+    assert any(".query." in k for k in old) and any(".proj_attn." in k for k in old)
+    assert {normalize_vae_key(k) for k in old} == set(new)
+    assert all(normalize_vae_key(k) == k for k in new)
+    # names that merely contain the words elsewhere stay untouched
+    assert normalize_vae_key("encoder.down_blocks.0.resnets.0.conv1.weight") == "encoder.down_blocks.0.resnets.0.conv1.weight"
+
+
+def test_step_sampler_ranks_agree_on_shared_draws_including_dynamic_resolution():
+    """Data parallel: k and everything drawn from the shared stream (dynamic_resolution bucket, dynamic_crops seed) must be
+    identical on every rank in every step - the ranks do the same amount of work and all-reduce once - while the pair index
+    differs by rank (sliders_amd/cli.py:225-240 relies on this)."""
+    from sliders_amd.parallel import StepSampler
+    from sliders_amd.train_util import get_random_resolution_in_bucket
+    seqs = []
+    for rank in range(2):
+        s = StepSampler(7, rank, 2, 8, 50)
+        out = []
+        for _ in range(20):
+            k, pi = s.next()
+            st = torch.random.get_rng_state()
+            torch.manual_seed(int(torch.randint(0, 2 ** 31 - 1, (1,), generator=s.shared).item()))
+            hw = get_random_resolution_in_bucket(1024)
+            torch.random.set_rng_state(st)
+            out.append((k, pi, hw))
+        seqs.append(out)
+    assert [(k, hw) for k, _, hw in seqs[0]] == [(k, hw) for k, _, hw in seqs[1]]
+    assert all(a[1] != b[1] for a, b in zip(*seqs))
+    assert all(1 <= k <= 49 for k, _, _ in seqs[0])
+    # the SD-1.x image-slider script draws k from 1 .. max-2 (train_lora-scale.py:186-188)
+    s = StepSampler(1, 0, 1, 3, 49)
+    assert max(s.next()[0] for _ in range(400)) == 48

@@ -283,8 +283,8 @@ def test_gemv(dev):
 
 def _gn_workspace(dev, B, C, HW, G=32):
     """Partial-sum scratch (deliberately filled with garbage: the kernel must not depend on its contents) + zeroed tickets."""
-    part = torch.full((B, lib.gn_row_blocks(C, HW, G), G, 2), float("nan"), device=dev)
-    return part, torch.zeros(B, dtype=torch.int32, device=dev)
+    prow, ntick = lib.gn_workspace(C, HW, G)
+    return torch.full((B, prow, G, 2), float("nan"), device=dev), torch.zeros(B, ntick, dtype=torch.int32, device=dev)
 
 
 @pytest.mark.parametrize("C0,C1,act,mean,std", [(320, 0, 1, 0.5, 2.0), (64, 0, 0, 0.5, 2.0), (1280, 640, 1, 0.5, 2.0),

@@ -194,10 +194,11 @@ def test_forward_is_bit_reproducible(dev, name, hw):
         eng = UNetEngine(cfg, sd, dev)
         store = LoraStore(cfg, rank=4, alpha=1.0, train_method="noxattn", device=dev)
         g = torch.Generator().manual_seed(5)
-        for e in store.entries:
+        for e in store.entries:       # both halves from the seeded generator (the store's own init draws from the global RNG)
             store.params[e.up_off:e.up_off + e.up_numel] = (torch.randn(e.up_numel, generator=g) * 0.03).to(dev, torch.bfloat16)
+            store.params[e.down_off:e.down_off + e.down_numel] = (torch.randn(e.down_numel, generator=g) * 0.05).to(dev, torch.bfloat16)
         eng.attach_lora(store)
-        if e_i == 1:            # shift the second engine's allocations
+        if e_i == 1:            # a different allocation / planning history on the second engine
             eng(*[t.to(dev) if torch.is_tensor(t) else t for t in (x[:1], torch.tensor(3), ctx[:1])],
                 {k: v[:1].to(dev) for k, v in kw.items()} if kw else None, mode="off")
         for mode in ("off", "on", "train"):

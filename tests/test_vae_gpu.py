@@ -83,8 +83,9 @@ def test_gn32_and_softmax32(dev):
     for act, off in ((0, 0.5), (1, 0.5), (1, 300.0)):       # 300: DC offset >> spread, the one-pass variance hazard
         x = torch.randn(B * HW, C, device=dev) * 2 + off
         stats = torch.full((B, 32, 2), float("nan"), device=dev)
-        part = torch.full((B, lib.gn32_row_blocks(HW), 32, 2), float("nan"), device=dev)    # scratch: contents must not matter
-        ticket = torch.zeros(B, dtype=torch.int32, device=dev)
+        prow, ntick = lib.gn32_workspace(HW)
+        part = torch.full((B, prow, 32, 2), float("nan"), device=dev)    # scratch: contents must not matter
+        ticket = torch.zeros(B, ntick, dtype=torch.int32, device=dev)
         y = torch.zeros_like(x)
         d = lib.Gn32Desc(x=p(x), gamma=p(gm), beta=p(bt), stats=p(stats), y=p(y), ldx=C, ldy=C, C=C, batch=B, hw=HW, groups=32,
                          eps=1e-6, act=act, partial=p(part), ticket=p(ticket))
