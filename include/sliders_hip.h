@@ -98,6 +98,18 @@ typedef struct slh_gemm_desc {
                                 rows), vt_col0 % 128 == 0, vt_tokens % 8 == 0, M % 8 == 0; not with geglu / split-K */
     int32_t vt_col0, vt_D, vt_heads, vt_tokens, vt_ld;
     int32_t splitk_slabs;    /* slabs splitk_c32 holds (>= the S of tile) */
+    /* LayerNorm folded into the products around it (BasicTransformerBlock.norm1/2/3 of the no-grad passes: no LayerNorm
+     * launch, no round trip of the normalised tensor through HBM).
+     *   producer (the GEMM that writes the tensor LayerNorm reads): ln_out [N/64][M][2] fp32 (chunk-major: a wave's 32 rows
+     *     are contiguous for both sides) receives (mean, M2) of every 64-column chunk of every row of the bf16 result;
+     *     needs a 128-column tile, no GEGLU / vt_out / split-K.
+     *   consumer (dense, single source, K = LayerNorm width <= 1280): ln_in = the producer's ln_out, ln_in_chunks = K/64;
+     *     w must hold W * gamma, ln_s [N] fp32 its row sums, ln_b [N] fp32 = bias + W . beta (bias must be NULL):
+     *     c = rstd_m * (a . w^T - mean_m * ln_s) + ln_b, the row's mean / rstd merged from the chunks in a fixed order. */
+    float* ln_out;
+    const float* ln_in; const float* ln_s; const float* ln_b;
+    int32_t ln_in_chunks;
+    float ln_eps;
 } slh_gemm_desc;
 int slh_gemm(const slh_gemm_desc* d, slh_stream_t stream);
 /* (WM<<12)|(MI<<8)|(NI<<4)|mode of the kernel instantiation gemm_kernel<MI,NI,mode,..,WM> slh_gemm would launch for d

@@ -67,6 +67,10 @@ def valid(d, tile):
             return False
     if d.geglu and ni != 2:
         return False
+    if d.ln_out and (ni != 2 or (tile >> 16) & 15):        # folded LayerNorm: the producer writes 64-column chunk statistics
+        return False
+    if d.ln_in and (tile >> 16) & 15:
+        return False
     if wm == 4 and d.M * d.N < 256 * 128 * 32:
         return False
     return True

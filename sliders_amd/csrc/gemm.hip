@@ -39,6 +39,10 @@ struct GemmArgs {
     int splitk;
     __bf16* vt; int vt_col0, vt_D, vt_heads, vt_tokens, vt_ld;   // head-transposed store of the V columns (slh_gemm_desc.vt_out)
     int store16;  // c and ldc allow 16-byte row stores
+    // LayerNorm folded into the product (slh_gemm_desc.ln_*): producer side writes per-row chunk statistics of its
+    // bf16-rounded output, consumer side normalises the A operand algebraically (weights pre-scaled by gamma)
+    float* ln_out; const float* ln_in; const float* ln_s; const float* ln_b;
+    int ln_in_chunks; float ln_eps;
     int probe;   // diagnostics (slh_gemm_desc.reserved_): 1 skip tile refills, 2 skip MFMA work, 4 skip the epilogue,
                  // 8 skip the first tile fill, 16 return at once
 };
@@ -220,6 +224,46 @@ __global__ __launch_bounds__(128 * WM, gemm_waves_per_simd(MI, NI, STAGES, LORA,
     }
     const int lrow = lane & 31, lhi = lane >> 5;
 
+    // LayerNorm of the A operand, folded (consumer side).  The producer of A left per-row (mean, M2) pairs of 64-column
+    // chunks (ln_in, laid out [chunk][row], written by its epilogue below); they are requested here, ahead of the first operand tiles, merged
+    // in chunk order (Chan's update: cancellation-free) into the row's mean and 1/sigma, and applied in the epilogue:
+    //   LN(x) . W^T = rstd * (x . W'^T - mean * s) + b',   W' = W * gamma, s = row sums of W', b' = bias + W . beta
+    constexpr int LN_MAXC = 20;
+    float ln_mean[MI], ln_rstd[MI];
+    f32x2 ln_pairs[MI][MODE == 0 ? LN_MAXC : 1];
+    const bool ln_on = MODE == 0 && p.ln_in != nullptr;
+    if (MODE == 0 && ln_on) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            int m = m0 + wm * (32 * MI) + i * 32 + lrow;
+            m = m < p.M ? m : p.M - 1;
+            const f32x2* src = (const f32x2*)p.ln_in + m;        // chunk-major [chunks][M]: the 32 rows of a wave-load are contiguous
+#pragma unroll
+            for (int c = 0; c < LN_MAXC; ++c)
+                if (c < p.ln_in_chunks) ln_pairs[i][c] = src[(long)c * p.M];
+        }
+    }
+    auto ln_finish = [&]() {
+        if (MODE == 0 && ln_on) {
+            const float nc = (float)(p.K / p.ln_in_chunks);
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                float mean = ln_pairs[i][0][0], M2 = ln_pairs[i][0][1];
+#pragma unroll
+                for (int c = 1; c < LN_MAXC; ++c) {
+                    if (c < p.ln_in_chunks) {
+                        const float delta = ln_pairs[i][c][0] - mean;
+                        const float w = 1.f / (float)(c + 1);
+                        mean += delta * w;
+                        M2 += ln_pairs[i][c][1] + delta * delta * nc * (float)c * w;
+                    }
+                }
+                ln_mean[i] = mean;
+                ln_rstd[i] = 1.0f / sqrtf(M2 / (float)p.K + p.ln_eps);
+            }
+        }
+    };
+
     auto compute = [&](int buf) {
         const char* cX = sX + buf * (BM * 128);
         const char* cW = sW + buf * (BN * 128);
@@ -255,6 +299,7 @@ __global__ __launch_bounds__(128 * WM, gemm_waves_per_simd(MI, NI, STAGES, LORA,
 
     if constexpr (STAGES == 2) {
         if (!(p.probe & 8)) stage(0, kt_begin);
+        ln_finish();
         for (int kt = 0; kt < nk; ++kt) {
             lds_dma_syncthreads();  // drains this wave's glds (explicit vmcnt(0)) and orders all waves
             if (kt + 1 < nk && !(p.probe & 1)) stage((kt + 1) & 1, kt_begin + kt + 1);
@@ -412,6 +457,7 @@ __global__ __launch_bounds__(128 * WM, gemm_waves_per_simd(MI, NI, STAGES, LORA,
         for (int t = 0; t < S - 1; ++t) {
             if (t < nk) issue_all(t);
         }
+        ln_finish();
         if (nk >= S - 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((S - 2) * L) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
@@ -513,6 +559,15 @@ __global__ __launch_bounds__(128 * WM, gemm_waves_per_simd(MI, NI, STAGES, LORA,
                     float a[4], g[4];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) { a[e] = acc[i][0][q * 4 + e]; g[e] = acc[i][NI - 1][q * 4 + e]; }
+                    if (MODE == 0 && ln_on) {
+                        const f32x4 sa = *(const f32x4*)(p.ln_s + n), sg = *(const f32x4*)(p.ln_s + n + 32);
+                        const f32x4 ba = *(const f32x4*)(p.ln_b + n), bg = *(const f32x4*)(p.ln_b + n + 32);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            a[e] = ln_rstd[i] * (a[e] - ln_mean[i] * sa[e]) + ba[e];
+                            g[e] = ln_rstd[i] * (g[e] - ln_mean[i] * sg[e]) + bg[e];
+                        }
+                    }
                     if (p.bias) {
                         const bf16x4 ba = *(const bf16x4*)(p.bias + n);
                         const bf16x4 bg = *(const bf16x4*)(p.bias + n + 32);
@@ -596,6 +651,7 @@ __global__ __launch_bounds__(128 * WM, gemm_waves_per_simd(MI, NI, STAGES, LORA,
         const int mbase = m0 + wm * (32 * MI) + i * 32;
         const int m = mbase + lrow;
         const bool mok = m < p.M;
+        float ln_k = 0.f, ln_sum = 0.f, ln_sq = 0.f;
         f32x4 tv[3];
 #pragma unroll
         for (int g = 0; g < 3; ++g) tv[g] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -631,6 +687,11 @@ __global__ __launch_bounds__(128 * WM, gemm_waves_per_simd(MI, NI, STAGES, LORA,
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = acc[i][j][q * 4 + e];
                 if (mok && n < p.N) {
+                    if (MODE == 0 && ln_on) {
+                        const f32x4 s4 = *(const f32x4*)(p.ln_s + n), b4 = *(const f32x4*)(p.ln_b + n);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = ln_rstd[i] * (v[e] - ln_mean[i] * s4[e]) + b4[e];
+                    }
                     if (p.bias) {
                         const bf16x4 b4 = *(const bf16x4*)(p.bias + n);
 #pragma unroll
@@ -676,6 +737,11 @@ __global__ __launch_bounds__(128 * WM, gemm_waves_per_simd(MI, NI, STAGES, LORA,
                 bf16x4 o;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) o[e] = (__bf16)v[e];
+                if (p.ln_out) {                 // statistics of the stored (rounded) values, shifted by the lane's first one
+                    if (j == 0 && q == 0) { ln_k = (float)o[0]; ln_sum = 0.f; ln_sq = 0.f; }
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { const float dlt = (float)o[e] - ln_k; ln_sum += dlt; ln_sq += dlt * dlt; }
+                }
                 if (to_vt) {
                     // transposed patch sT[n_local][m_local] (32*NI rows of 32 bf16): column n of the tile becomes a
                     // 64-byte run along m
@@ -689,6 +755,18 @@ __global__ __launch_bounds__(128 * WM, gemm_waves_per_simd(MI, NI, STAGES, LORA,
                 const int slot = (j * 4 + q) ^ (lrow & (S - 1));
                 *(bf16x4*)(sE + lrow * (S * 16) + slot * 16 + ((lhi ^ hb) << 3)) = o;
             }
+        }
+        if (NI == 2 && p.ln_out) {
+            // LayerNorm statistics of this row's 64 columns (producer side of the folded LayerNorm): the lane holds 32 of
+            // them, its partner lane^32 the other 32; (mean, M2) from sums shifted by a sample of the row (no cancellation), merged (Chan)
+            const float dm = ln_sum * (1.f / (16 * NI));
+            const float mu = ln_k + dm;
+            const float m2 = fmaxf(ln_sq - ln_sum * dm, 0.f);
+            const float mu_o = __shfl_xor(mu, 32, 64), m2_o = __shfl_xor(m2, 32, 64);
+            const float delta = mu_o - mu;
+            if (lhi == 0 && mok && ncol0 < p.N)
+                *(f32x2*)(p.ln_out + ((long)(ncol0 >> 6) * p.M + m) * 2) =
+                    f32x2{mu + 0.5f * delta, m2 + m2_o + delta * delta * (8.f * NI)};
         }
         __builtin_amdgcn_wave_barrier();       // same-wave LDS ops retire in order; only the compiler must not reorder
         if (to_vt) {
@@ -967,6 +1045,22 @@ extern "C" int slh_gemm(const slh_gemm_desc* d, slh_stream_t stream) {
                       (d->N - d->vt_col0) == d->vt_heads * d->vt_D && d->vt_tokens % 8 == 0 && d->M % d->vt_tokens == 0 &&
                       d->vt_ld % 8 == 0 && d->vt_ld >= d->vt_tokens && !d->geglu && ((uintptr_t)d->vt_out & 15) == 0,
                   "slh_gemm: vt_out constraints");
+    }
+    a.ln_out = d->ln_out; a.ln_in = d->ln_in; a.ln_s = d->ln_s; a.ln_b = d->ln_b;
+    a.ln_in_chunks = d->ln_in_chunks; a.ln_eps = d->ln_eps;
+    if (d->ln_out) {
+        SLH_CHECK(NI == 2 && d->N % 64 == 0 && !d->geglu && !d->vt_out && ((d->tile >> 16) & 15) <= 1,
+                  "slh_gemm: ln_out needs a 128-column tile (NI = 2), N %% 64 == 0, no GEGLU / vt_out / split-K");
+        SLH_CHECK(((uintptr_t)d->ln_out & 7) == 0, "slh_gemm: ln_out alignment");
+    }
+    if (d->ln_in) {
+        SLH_CHECK(d->mode == 0 && !d->a1 && d->ln_s && d->ln_b && !d->bias && !d->lora_down && !d->lora_t &&
+                      ((d->tile >> 16) & 15) <= 1,
+                  "slh_gemm: ln_in needs a dense single-source product, ln_s / ln_b, no bias (folded into ln_b), no adapter, no split-K");
+        SLH_CHECK(d->ln_in_chunks >= 1 && d->ln_in_chunks <= 20 && d->K == 64 * d->ln_in_chunks,
+                  "slh_gemm: ln_in_chunks must be K / 64 (<= 20)");
+        SLH_CHECK(((uintptr_t)d->ln_in & 7) == 0 && ((uintptr_t)d->ln_s & 15) == 0 && ((uintptr_t)d->ln_b & 15) == 0,
+                  "slh_gemm: ln_in / ln_s / ln_b alignment");
     }
     a.probe = d->reserved_;
     a.splitk = (d->tile >> 16) & 15;

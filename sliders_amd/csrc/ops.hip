@@ -208,10 +208,12 @@ __global__ __launch_bounds__(256) void cfg_ddim_kernel(const slh_cfg_ddim_desc d
 }
 
 // ---- guidance loss (prompt_util.py:108-148) --------------------------------------------------------------
-__global__ __launch_bounds__(256) void loss_kernel(const slh_loss_desc d) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+// One workgroup, fixed summation order: the loss value is bit-reproducible (a grid of workgroups adding their partial
+// sums with an fp32 atomic gave a different last digit from run to run).  n is 65536 per sample: a few microseconds, once
+// per training iteration.
+__global__ __launch_bounds__(1024) void loss_kernel(const slh_loss_desc d) {
     float sq = 0.f;
-    if (i < d.n) {
+    for (int i = threadIdx.x; i < d.n; i += 1024) {
         const float tg = (float)((const __bf16*)d.target)[i];
         const float po = (float)((const __bf16*)d.positive)[i];
         const float ne = (float)((const __bf16*)d.neutral)[i];
@@ -220,7 +222,7 @@ __global__ __launch_bounds__(256) void loss_kernel(const slh_loss_desc d) {
         const float d2 = round_bf16(d.guidance * d1);
         const float y = round_bf16(d.erase ? ne - d2 : ne + d2);
         const float diff = tg - y;
-        sq = diff * diff;
+        sq += diff * diff;
         const __bf16 gq = (__bf16)((2.0f / (float)d.n) * diff);
         if (d.dtarget) ((__bf16*)d.dtarget)[i] = gq;
         if (d.dtarget_pix) {
@@ -231,10 +233,15 @@ __global__ __launch_bounds__(256) void loss_kernel(const slh_loss_desc d) {
         }
     }
     sq = wave_sum(sq);
-    __shared__ float part[4];
+    __shared__ float part[16];
     if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = sq;
     __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(d.loss, (part[0] + part[1] + part[2] + part[3]) / (float)d.n);
+    if (threadIdx.x == 0) {
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) t += part[w];
+        *d.loss += t / (float)d.n;
+    }
 }
 
 // ---- AdamW over the flat LoRA buffer: torch.optim.AdamW single-tensor op order, bf16 state ------------
@@ -327,7 +334,7 @@ extern "C" int slh_cfg_ddim(const slh_cfg_ddim_desc* d, slh_stream_t stream) {
 
 extern "C" int slh_guidance_loss(const slh_loss_desc* d, slh_stream_t stream) {
     SLH_CHECK(d && d->target && d->positive && d->neutral && d->uncond && d->loss, "slh_guidance_loss: null pointer");
-    hipLaunchKernelGGL(loss_kernel, dim3((d->n + 255) / 256), dim3(256), 0, (hipStream_t)stream, *d);
+    hipLaunchKernelGGL(loss_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, *d);
     SLH_LAUNCH_CHECK("slh_guidance_loss");
     return 0;
 }

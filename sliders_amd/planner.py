@@ -39,6 +39,7 @@ class Act:
     ld: int
     buf: Optional[Buf] = None
     name: str = ""
+    ln: Optional[tuple] = None     # (Buf of per-row 64-column chunk statistics written by the producing GEMM, chunks): folded LayerNorm
 
     @property
     def HW(self) -> int:
@@ -219,11 +220,16 @@ class UNetPlan:
     def gemm(self, x: Src, wname: str, N: int, name: str, bias: bool = True, conv: Optional[dict] = None,
              rowbias: Optional[Tuple[int, int]] = None, residual: Optional[Act] = None,
              lora_paths: Optional[List[str]] = None, geglu: bool = False, out: Optional[Act] = None,
-             w_ptr: Optional[int] = None, bias_ptr: Optional[int] = None, vt_heads: Optional[int] = None) -> Act:
+             w_ptr: Optional[int] = None, bias_ptr: Optional[int] = None, vt_heads: Optional[int] = None,
+             ln_stats: bool = False, ln_fold: Optional[Act] = None) -> Optional[Act]:
         """y = x . W^T (+bias)(+rowbias per sample)(+LoRA)(+residual).  conv: {'stride','xform'} for 3x3.
         vt_heads: the product is a fused q|k|v projection of that many heads; where the kernel supports it (no-grad
         passes, head_dim % 64 == 0) its V third is written head-transposed for slh_attn_fwd straight from the epilogue
-        and self.last_vt = (pointer, 0) names it - one launch and one HBM round trip of V less per self-attention."""
+        and self.last_vt = (pointer, 0) names it - one launch and one HBM round trip of V less per self-attention.
+        ln_stats: also leave per-row statistics of the result for a LayerNorm folded into the NEXT product (out.ln, set only
+        when the tile that will run supports it).  ln_fold = the un-normalised activation x whose producer left such
+        statistics: this product computes Linear(LayerNorm(x)) from x itself with the gamma-scaled copy of the weights
+        (weights.py _put_ln_folded); returns None - nothing emitted - when the tile that would run cannot (split-K)."""
         x0, x1 = _src_parts(x)
         cin = x0.C + (x1.C if x1 else 0)
         B = x0.B
@@ -270,7 +276,19 @@ class UNetPlan:
         d.tile = tuned_tile(d)
         if not d.tile and M <= 192 and N >= 4096:
             d.tile = 0x12        # few rows, very wide: 64-row tiles waste the least of the short M
-        provision_splitk(self, d, name)
+        if ln_fold is not None:
+            if ((d.tile >> 16) & 15) > 1 or (not d.tile and splitk_wanted(d)):
+                return None
+            d.w, d.bias = self.w.ptr(wname + ".lnw"), 0
+            d.ln_in, d.ln_in_chunks, d.ln_eps = ln_fold.ln[0].ptr, ln_fold.ln[1], 1e-5
+            d.ln_s, d.ln_b = self.w.ptr(wname + ".lns"), self.w.ptr(wname + ".lnb")
+        else:
+            provision_splitk(self, d, name)
+        if ln_stats and not self.train and not geglu and N % 64 == 0 and not d.splitk_c32 and \
+                (lib.gemm_variant(d) >> 4) & 15 == 2:
+            st = self.f32((N // 64, M, 2), name + ".ln_chunks")
+            d.ln_out = st.ptr
+            out.ln = (st, N // 64)
         self.last_vt = None
         if vt_heads and not self.train and not geglu and conv is None and os.environ.get("SLIDERS_NO_FUSED_VT") is None:
             Cq = N // 3
@@ -315,6 +333,19 @@ class UNetPlan:
         if self.train:
             self.tape.append(dict(op="ln", x=x, out=y, wname=wname, mr=mr, name=name))
         return y
+
+    def ln_gemm(self, h: Act, norm: str, wname: str, N: int, bias: bool = True, lora_paths: Optional[List[str]] = None,
+                geglu: bool = False, vt_heads: Optional[int] = None) -> Act:
+        """Linear(LayerNorm(h)): folded into one product when h's producer left row statistics, the consumer carries no adapter
+        and the pass keeps no tape; the LayerNorm launch + the plain product otherwise."""
+        grp = self._lora_group(lora_paths) if lora_paths else None
+        if not self.train and grp is None and h.ln is not None and getattr(self.w, "ln_fold", False) and \
+                self.w.has(wname + ".lnw") and h.C % 64 == 0 and h.C <= 1280 and h.ld == h.C:
+            y = self.gemm(h, wname, N, wname, bias=False, geglu=geglu, vt_heads=vt_heads, ln_fold=h)
+            if y is not None:
+                return y
+        n = self.layernorm(h, norm, norm)
+        return self.gemm(n, wname, N, wname, bias=bias, lora_paths=lora_paths, geglu=geglu, vt_heads=vt_heads)
 
     def attention(self, q: Act, k: Act, v: Act, Tk: int, heads: int, name: str, vt_pre=None) -> Act:
         """q [B*Tq][C] view, k/v [B*Tk][C] views (any ld); returns [B*Tq][C].  vt_pre = (pointer to this layer's first
@@ -427,14 +458,14 @@ class UNetPlan:
     def _tblock(self, h: Act, path: str, heads: int, ctx: Act) -> Act:
         C = h.C
         a1, a2 = path + ".attn1", path + ".attn2"
-        n1 = self.layernorm(h, path + ".norm1", path + ".norm1")
-        qkv = self.gemm(n1, a1 + ".qkv", 3 * C, a1 + ".qkv", bias=False,
-                        lora_paths=[a1 + ".to_q", a1 + ".to_k", a1 + ".to_v"], vt_heads=heads)
+        # BasicTransformerBlock.norm1/2/3: in the no-grad passes a LayerNorm whose consumer carries no adapter is folded
+        # into that product (ln_gemm); its producer leaves the row statistics (ln_stats)
+        qkv = self.ln_gemm(h, path + ".norm1", a1 + ".qkv", 3 * C, bias=False,
+                           lora_paths=[a1 + ".to_q", a1 + ".to_k", a1 + ".to_v"], vt_heads=heads)
         T = h.HW
         o1 = self.attention(qkv.cols(0, C), qkv.cols(C, C), qkv.cols(2 * C, C), T, heads, a1 + ".sdpa", vt_pre=self.last_vt)
-        h1 = self.gemm(o1, a1 + ".out", C, a1 + ".out", residual=h, lora_paths=[a1 + ".to_out.0"])
-        n2 = self.layernorm(h1, path + ".norm2", path + ".norm2")
-        q2 = self.gemm(n2, a2 + ".q", C, a2 + ".q", bias=False, lora_paths=[a2 + ".to_q"])
+        h1 = self.gemm(o1, a1 + ".out", C, a1 + ".out", residual=h, lora_paths=[a1 + ".to_out.0"], ln_stats=True)
+        q2 = self.ln_gemm(h1, path + ".norm2", a2 + ".q", C, bias=False, lora_paths=[a2 + ".to_q"])
         vt_pre = None
         if self.kv_all is not None:
             k_off, v_off = self.w.kv_all_offset[a2]
@@ -449,9 +480,9 @@ class UNetPlan:
         if self._lora_group([a2 + ".to_k", a2 + ".to_v"]) is None:
             self.nograd_kv.add(kv.buf.ptr)      # text K/V carry no gradient unless they are adapted
         o2 = self.attention(q2, k2, v2, self.ctx_len, heads, a2 + ".sdpa", vt_pre=vt_pre)
-        h2 = self.gemm(o2, a2 + ".out", C, a2 + ".out", residual=h1, lora_paths=[a2 + ".to_out.0"])
-        n3 = self.layernorm(h2, path + ".norm3", path + ".norm3")
+        h2 = self.gemm(o2, a2 + ".out", C, a2 + ".out", residual=h1, lora_paths=[a2 + ".to_out.0"], ln_stats=True)
         if self.train:
+            n3 = self.layernorm(h2, path + ".norm3", path + ".norm3")
             pre = self.gemm(n3, path + ".ff1", 8 * C, path + ".ff1", lora_paths=[path + ".ff.net.0.proj"])
             ff = self.act(h.B, h.H, h.W, 4 * C, path + ".geglu")
             self.prog.add(lib.OP_ELEMENTWISE, lib.EwDesc(a=pre.ptr, out=ff.ptr, M=pre.M, C=4 * C, lda=pre.ld, ldo=ff.ld,
@@ -461,12 +492,12 @@ class UNetPlan:
             grp = self._lora_group([path + ".ff.net.0.proj"])
             if grp is not None:
                 raise NotImplementedError("LoRA on GEGLU.proj is not a reference target")
-            ff = self.gemm(n3, path + ".ff1", 8 * C, path + ".ff1", geglu=True)
-        return self.gemm(ff, path + ".ff2", C, path + ".ff2", residual=h2, lora_paths=[path + ".ff.net.2"])
+            ff = self.ln_gemm(h2, path + ".norm3", path + ".ff1", 8 * C, geglu=True)
+        return self.gemm(ff, path + ".ff2", C, path + ".ff2", residual=h2, lora_paths=[path + ".ff.net.2"], ln_stats=True)
 
     def _transformer(self, x: Act, path: str, layers: int, heads: int) -> Act:
         g = self.groupnorm(x, path + ".norm", 1e-6, 0, path + ".norm")
-        h = self.gemm(g, path + ".proj_in", x.C, path + ".proj_in", lora_paths=[path + ".proj_in"])
+        h = self.gemm(g, path + ".proj_in", x.C, path + ".proj_in", lora_paths=[path + ".proj_in"], ln_stats=True)
         for k in range(layers):
             h = self._tblock(h, f"{path}.transformer_blocks.{k}", heads, self.ctx)
         return self.gemm(h, path + ".proj_out", x.C, path + ".proj_out", residual=x, lora_paths=[path + ".proj_out"])

@@ -259,6 +259,7 @@ class _VirtualWeights:
         self.kv_all_offset = w.kv_all_offset
         self.kv_all_vbase = w.kv_all_vbase
         self.gemm_shape = w.gemm_shape
+        self.ln_fold = w.ln_fold
 
     def ptr(self, name):
         return 0x1000

@@ -65,6 +65,21 @@ def unpack_gemm_w(flat: torch.Tensor, n: int, k: int) -> torch.Tensor:
     return t.permute(0, 2, 1, 3, 4).reshape(npad, k)[:n].contiguous()
 
 
+def fold_layernorm(w: torch.Tensor, bias, gamma: torch.Tensor, beta: torch.Tensor, dtype=torch.bfloat16, device=None):
+    """(W' = dtype(W * gamma), s = row sums of W' in fp32, b' = bias + W . beta in fp32) for slh_gemm_desc.ln_in:
+    Linear(LayerNorm(x)) = rstd * (x . W'^T - mean * s) + b'.  s is taken from the ROUNDED W' the kernel multiplies with."""
+    device = device if device is not None else w.device
+    w32 = w.to(device=device, dtype=dtype).float()                      # the weights the unfused path multiplies with
+    g32 = gamma.to(device=device, dtype=dtype).float()
+    b32 = beta.to(device=device, dtype=dtype).float()
+    wf = (w32 * g32[None, :]).to(dtype)
+    s = wf.float().sum(1)
+    bp = w32 @ b32
+    if bias is not None:
+        bp = bp + bias.to(device=device, dtype=dtype).float()
+    return wf, s.contiguous(), bp.contiguous()
+
+
 class WeightStore:
     def __init__(self, cfg: UNetConfig, state_dict: Dict[str, torch.Tensor], device, dtype=torch.bfloat16):
         self.cfg = cfg
@@ -75,6 +90,9 @@ class WeightStore:
         # A/B switch for measurements only: SLIDERS_W_ROWMAJOR=1 keeps the GEMM matrices [N][K] (w_layout 0)
         self.packed = os.environ.get("SLIDERS_W_ROWMAJOR") is None
         self._sd = state_dict
+        # LayerNorm folded into its consumer GEMMs in the no-grad passes (one more copy of the q|k|v, attn2.to_q and GEGLU
+        # projection matrices, pre-scaled by the LayerNorm weight); SLIDERS_NO_LN_FOLD=1 keeps the LayerNorm launches
+        self.ln_fold = os.environ.get("SLIDERS_NO_LN_FOLD") is None
         self.temb_offsets: Dict[str, int] = {}
         self.resnet_paths: List[str] = []
         self._pack()
@@ -89,6 +107,19 @@ class WeightStore:
         t = t.to(device=self.device, dtype=self.dtype)
         self.gemm_shape[name] = tuple(t.shape)
         self.t[name] = pack_gemm_w(t) if self.packed else t.contiguous()
+
+    def _put_ln_folded(self, wname: str, w: torch.Tensor, bias, gamma: torch.Tensor, beta: torch.Tensor, perm=None):
+        """LayerNorm folded into the Linear that consumes it (slh_gemm_desc.ln_in; no-grad passes):
+            Linear(LN(x)) = rstd * (x . W'^T - mean * s) + b',   W' = bf16(W * gamma),  s = row sums of W' (fp32, of the ROUNDED
+            matrix the kernel multiplies with),  b' = bias + W . beta (fp32).
+        Stored as <wname>.lnw (tile-packed like .w), .lns, .lnb; perm: the GEGLU row permutation of the fused epilogue."""
+        wf, s, bp = fold_layernorm(w, bias, gamma, beta, self.dtype, self.device)
+        if perm is not None:
+            wf, s, bp = perm(wf), perm(s), perm(bp)
+        self.gemm_shape[wname + ".lnw"] = tuple(wf.shape)
+        self.t[wname + ".lnw"] = pack_gemm_w(wf) if self.packed else wf.contiguous()
+        self.t[wname + ".lns"] = s.contiguous()
+        self.t[wname + ".lnb"] = bp.contiguous()
 
     def gemm_matrix(self, name: str) -> torch.Tensor:
         """Row-major [N][K] view of a tile-packed matrix (copy)."""
@@ -163,6 +194,13 @@ class WeightStore:
                 self._put(f"{name}.ff1.b", _geglu_perm(sd[f"{name}.ff.net.0.proj.bias"]))
                 self._put_gemm(f"{name}.ff2.w", sd[f"{name}.ff.net.2.weight"])
                 self._put(f"{name}.ff2.b", sd[f"{name}.ff.net.2.bias"])
+                if self.ln_fold:
+                    n1, n2, n3 = (( sd[f"{name}.{nm}.weight"], sd[f"{name}.{nm}.bias"]) for nm in ("norm1", "norm2", "norm3"))
+                    self._put_ln_folded(f"{a1}.qkv", torch.cat([sd[f"{a1}.to_q.weight"], sd[f"{a1}.to_k.weight"],
+                                                                sd[f"{a1}.to_v.weight"]], 0), None, *n1)
+                    self._put_ln_folded(f"{a2}.q", sd[f"{a2}.to_q.weight"], None, *n2)
+                    self._put_ln_folded(f"{name}.ff1", sd[f"{name}.ff.net.0.proj.weight"], sd[f"{name}.ff.net.0.proj.bias"], *n3,
+                                        perm=_geglu_perm)
         # all cross-attention K/V projections read the SAME text embeddings: one [sum(C) K rows | sum(C) V rows][Dctx]
         # matrix lets a UNet pass compute them in one full-chip launch instead of one 120-workgroup launch per
         # transformer block, and transposes every V with one more (tile-packed blocks are row-block major, so packed

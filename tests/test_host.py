@@ -75,6 +75,7 @@ class _FakeWeights:
         self.kv_all_offset = {}
         self.kv_all_vbase = 0
         self.gemm_shape = {}
+        self.ln_fold = True
 
     def ptr(self, name):
         return 0x1000

@@ -188,6 +188,78 @@ def test_gemm_geglu(dev):
     report("geglu_bwd", dpre, _perm_cols(pr.grad), 1.5e-2)
 
 
+@pytest.mark.parametrize("C,offset", [(640, 0.0), (1280, 0.0), (320, 0.0), (1280, 8.0)])
+def test_gemm_layernorm_folded(dev, C, offset):
+    """BasicTransformerBlock.norm2 / norm3 folded into the products around them (slh_gemm_desc.ln_out / ln_in): the
+    producer (attention out-projection + residual) leaves (mean, M2) of every 64-column chunk of its bf16 rows; the
+    consumer multiplies the RAW rows with the gamma-scaled weights and normalises in the epilogue.  Against the reference's
+    op sequence (LayerNorm in fp32 -> bf16 -> Linear -> bf16; GEGLU for ff1), plain and GEGLU consumers, several tiles;
+    offset: rows whose mean is many standard deviations from zero (the chunk statistics are two-pass, merged with Chan's
+    update - nothing cancels)."""
+    from sliders_amd.weights import _geglu_perm, fold_layernorm
+    torch.manual_seed(C)
+    M = 300
+    o = bf(torch.randn(M, C, device=dev))
+    wo = bf(torch.randn(C, C, device=dev) / math.sqrt(C))
+    bo = bf(torch.randn(C, device=dev) + offset)
+    res = bf(torch.randn(M, C, device=dev) * 2)
+    gamma, beta = bf(torch.randn(C, device=dev) * 0.5 + 1.0), bf(torch.randn(C, device=dev) * 0.3)
+    h_ref = bf(o.float() @ wo.float().t() + bo.float() + res.float())
+    for ptile in (0x4412, 0x422, 0x12, 0x4022):
+        h = torch.zeros(M, C, device=dev, dtype=torch.bfloat16)
+        chunks = torch.full((C // 64, M, 2), float("nan"), device=dev)      # chunk-major
+        d = lib.GemmDesc(a0=p(o), w=p(wo), bias=p(bo), residual=p(res), c=p(h), lda0=C, ca0=C, mode=0, stride=1, ldw=C, M=M, N=C,
+                         K=C, ld_res=C, ldc=C, rows_per_sample=M, tile=ptile, ln_out=p(chunks))
+        lib.call(lib.OP_GEMM, d, stream())
+        torch.cuda.synchronize()
+        report(f"ln producer tile{ptile:x} C{C}", h, h_ref.float(), TOL)
+        hc = h.float().view(M, C // 64, 64).double()
+        mref = hc.mean(-1)
+        m2ref = ((hc - mref[..., None]) ** 2).sum(-1)
+        got = chunks.permute(1, 0, 2).double()
+        assert float((got[..., 0] - mref).abs().max()) < 1e-5 * max(1.0, float(mref.abs().max()))
+        assert float(((got[..., 1] - m2ref) / m2ref).abs().max()) < 1e-4
+        # the reference's sequence on the tensor the producer actually stored
+        ln = bf(F.layer_norm(h.float(), (C,), gamma.float(), beta.float(), 1e-5))
+        # (a) plain consumer without bias (attn2.to_q / the fused q|k|v)
+        N = 2 * C
+        w = bf(torch.randn(N, C, device=dev) / math.sqrt(C))
+        wf, sv, bp = fold_layernorm(w, None, gamma, beta)
+        ref = ln.float() @ w.float().t()
+        for tile in (0x4412, 0x22, 0x11, 0x4322):
+            c = torch.zeros(M, N, device=dev, dtype=torch.bfloat16)
+            d = lib.GemmDesc(a0=p(h), w=p(wf), c=p(c), lda0=C, ca0=C, mode=0, stride=1, ldw=C, M=M, N=N, K=C, ldc=N,
+                             rows_per_sample=M, tile=tile, ln_in=p(chunks), ln_in_chunks=C // 64, ln_s=p(sv), ln_b=p(bp), ln_eps=1e-5)
+            lib.call(lib.OP_GEMM, d, stream())
+            torch.cuda.synchronize()
+            report(f"ln consumer plain tile{tile:x} C{C} off{offset}", c, ref, TOL)
+        # (b) GEGLU consumer with bias (ff.net.0.proj)
+        n_out = 256
+        wg = bf(torch.randn(2 * n_out, C, device=dev) / math.sqrt(C))
+        bg = bf(torch.randn(2 * n_out, device=dev))
+        wf, sv, bp = fold_layernorm(wg, bg, gamma, beta)
+        wf, sv, bp = _geglu_perm(wf), _geglu_perm(sv).contiguous(), _geglu_perm(bp).contiguous()
+        proj = bf(ln.float() @ wg.float().t() + bg.float()).float()
+        refg = proj[:, :n_out] * bf(F.gelu(proj[:, n_out:])).float()
+        for tile in (0x4412, 0x12, 0x4012):
+            c = torch.zeros(M, n_out, device=dev, dtype=torch.bfloat16)
+            d = lib.GemmDesc(a0=p(h), w=p(wf), c=p(c), lda0=C, ca0=C, mode=0, stride=1, ldw=C, M=M, N=2 * n_out, K=C, ldc=n_out,
+                             geglu=1, rows_per_sample=M, tile=tile, ln_in=p(chunks), ln_in_chunks=C // 64, ln_s=p(sv), ln_b=p(bp),
+                             ln_eps=1e-5)
+            lib.call(lib.OP_GEMM, d, stream())
+            torch.cuda.synchronize()
+            report(f"ln consumer geglu tile{tile:x} C{C} off{offset}", c, refg, TOL)
+    # descriptors the kernel cannot honour are rejected before any launch
+    bad = lib.GemmDesc(a0=p(o), w=p(wo), c=p(h), lda0=C, ca0=C, mode=0, stride=1, ldw=C, M=M, N=C, K=C, ldc=C, rows_per_sample=M,
+                       tile=0x11, ln_out=p(chunks))
+    with pytest.raises(lib.SlidersHipError, match="ln_out"):
+        lib.call(lib.OP_GEMM, bad, stream())
+    bad = lib.GemmDesc(a0=p(h), w=p(wf), bias=p(bo), c=p(h), lda0=C, ca0=C, mode=0, stride=1, ldw=C, M=M, N=C, K=C, ldc=C,
+                       rows_per_sample=M, ln_in=p(chunks), ln_in_chunks=C // 64, ln_s=p(sv), ln_b=p(bp), ln_eps=1e-5)
+    with pytest.raises(lib.SlidersHipError, match="ln_in"):
+        lib.call(lib.OP_GEMM, bad, stream())
+
+
 def _perm_cols(g):
     from sliders_amd.weights import _geglu_perm
     return _geglu_perm(g.t().contiguous()).t().contiguous()
