@@ -226,7 +226,7 @@ __global__ __launch_bounds__(128 * WM, gemm_waves_per_simd(MI, NI, STAGES, LORA,
 
     // LayerNorm of the A operand, folded (consumer side).  The producer of A left per-row (mean, M2) pairs of 64-column
     // chunks (ln_in, laid out [chunk][row], written by its epilogue below); they are requested here, ahead of the first operand tiles, merged
-    // in chunk order (Chan's update: cancellation-free) into the row's mean and 1/sigma, and applied in the epilogue:
+    // in a fixed order (Chan's merge for equal counts: cancellation-free) into the row's mean and 1/sigma, and applied in the epilogue:
     //   LN(x) . W^T = rstd * (x . W'^T - mean * s) + b',   W' = W * gamma, s = row sums of W', b' = bias + W . beta
     constexpr int LN_MAXC = 20;
     float ln_mean[MI], ln_rstd[MI];
@@ -245,20 +245,27 @@ __global__ __launch_bounds__(128 * WM, gemm_waves_per_simd(MI, NI, STAGES, LORA,
     }
     auto ln_finish = [&]() {
         if (MODE == 0 && ln_on) {
+            // equal-sized chunks, one pass over the pairs with the chunk means shifted by the first one (d_c = mean_c - mean_0):
+            //   mean = mean_0 + S/k,  M2 = sum M2_c + n_chunk * (sum d_c^2 - S^2/k),  S = sum d_c
+            // = Chan's merge for equal counts; two interleaved accumulator sets keep the dependent chains short; fixed order
             const float nc = (float)(p.K / p.ln_in_chunks);
+            const float inv_chunks = 1.f / (float)p.ln_in_chunks;
 #pragma unroll
             for (int i = 0; i < MI; ++i) {
-                float mean = ln_pairs[i][0][0], M2 = ln_pairs[i][0][1];
+                const float m0v = ln_pairs[i][0][0];
+                float sa = 0.f, sb = 0.f, pa = 0.f, pb = 0.f, qa = ln_pairs[i][0][1], qb = 0.f;
 #pragma unroll
-                for (int c = 1; c < LN_MAXC; ++c) {
-                    if (c < p.ln_in_chunks) {
-                        const float delta = ln_pairs[i][c][0] - mean;
-                        const float w = 1.f / (float)(c + 1);
-                        mean += delta * w;
-                        M2 += ln_pairs[i][c][1] + delta * delta * nc * (float)c * w;
+                for (int c = 1; c < LN_MAXC; c += 2) {
+                    if (c < p.ln_in_chunks) { const float dl = ln_pairs[i][c][0] - m0v; sa += dl; pa += dl * dl; qa += ln_pairs[i][c][1]; }
+                    if (c + 1 < p.ln_in_chunks && c + 1 < LN_MAXC) {
+                        const float dl = ln_pairs[i][c + 1 < LN_MAXC ? c + 1 : c][0] - m0v;
+                        sb += dl; pb += dl * dl; qb += ln_pairs[i][c + 1 < LN_MAXC ? c + 1 : c][1];
                     }
                 }
-                ln_mean[i] = mean;
+                const float S = sa + sb;
+                const float dm = S * inv_chunks;
+                ln_mean[i] = m0v + dm;
+                const float M2 = (qa + qb) + nc * fmaxf((pa + pb) - S * dm, 0.f);
                 ln_rstd[i] = 1.0f / sqrtf(M2 / (float)p.K + p.ln_eps);
             }
         }

@@ -66,7 +66,7 @@ class Act:
 Src = Union[Act, Tuple[Act, Act]]
 
 SPLITK_MAX_MN = 6 << 20          # output elements up to which split-K is considered (one 24 MB fp32 slab per slice at most)
-SPLITK_MIN_K = 2048
+SPLITK_MIN_K = int(os.environ.get("SLIDERS_SPLITK_MIN_K", "2048"))
 
 
 def splitk_candidate(d) -> bool:
