@@ -353,6 +353,27 @@ typedef struct slh_wgrad_desc {
 } slh_wgrad_desc;
 int slh_lora_wgrad(const slh_wgrad_desc* d, slh_stream_t stream);
 
+/* Batched launches: n independent problems of one kind in ONE launch (the backward of a UNet pass has ~380 rank-4
+ * weight-gradient reductions and ~210 head transposes of forward activations, each far too small to fill the chip).
+ * table is a DEVICE array of n descriptors of the kind's own type, prefix a DEVICE int32[n + 1] running sum of the
+ * workgroups each problem needs (slh_*_blocks(descriptor), which also validates the descriptor: -1 + slh_last_error()),
+ * total = prefix[n].  A workgroup finds its problem by bisection of prefix. */
+typedef struct slh_batch_desc {
+    const void* table; const int32_t* prefix;
+    int32_t n, total;
+    int32_t arg;             /* slh_lora_wgrad_batch: R (4 or 12), the same for every problem of the batch */
+    int32_t pad_;
+} slh_batch_desc;
+int slh_lora_wgrad_blocks(const slh_wgrad_desc* d);
+int slh_lora_wgrad_batch(const slh_batch_desc* d, slh_stream_t stream);
+int slh_transpose_heads_blocks(const slh_transpose_desc* d);
+int slh_transpose_heads_batch(const slh_batch_desc* d, slh_stream_t stream);
+
+/* out[i] = idx[i] < 0 ? 0 : src[idx[i]] on 16-bit elements (the k-major copies of the adapters' up matrices that the fused
+ * backward-data products stream as their third operand: rebuilt from the live parameters at the head of every backward). */
+typedef struct slh_gather16_desc { const void* src; const int32_t* idx; void* out; int64_t n; } slh_gather16_desc;
+int slh_gather16(const slh_gather16_desc* d, slh_stream_t stream);
+
 /* Backward-data term of a 3x3 LoRA down conv (lora.py:82-87): gx[i][c] (+)= scale * sum_{tap,r} U[o][r] *
  * A[r][tap][c] for the output pixels o with o*stride + tap - 1 = i.  U fp32 [batch*ho*wo][ldu], A = lora_down
  * as stored [4][9*cin], gx bf16 pixel-major image of hl x wl. */
@@ -479,7 +500,8 @@ enum {
     SLH_OP_WGRAD = 14, SLH_OP_ADAMW = 15, SLH_OP_GN_BWD_STATS = 16, SLH_OP_GN_BWD_APPLY = 17,
     SLH_OP_LAYERNORM_BWD = 18, SLH_OP_ATTN_BWD = 19, SLH_OP_MEMSET = 20, SLH_OP_LORA_CONV_DGRAD = 21,
     SLH_OP_TEMB_LORA_BWD = 22, SLH_OP_SGEMM = 23, SLH_OP_GN32_STATS = 24, SLH_OP_GN32_APPLY = 25, SLH_OP_SOFTMAX32 = 26,
-    SLH_OP_VAE_CONV_IN = 27, SLH_OP_VAE_MOMENTS = 28, SLH_OP_VAE_SAMPLE = 29, SLH_OP_VAE_POST_QUANT = 30, SLH_OP_LION = 31
+    SLH_OP_VAE_CONV_IN = 27, SLH_OP_VAE_MOMENTS = 28, SLH_OP_VAE_SAMPLE = 29, SLH_OP_VAE_POST_QUANT = 30, SLH_OP_LION = 31,
+    SLH_OP_WGRAD_BATCH = 32, SLH_OP_TRANSPOSE_BATCH = 33, SLH_OP_GATHER16 = 34
 };
 typedef struct slh_memset_desc { void* ptr; int64_t nbytes; int32_t value; int32_t pad; } slh_memset_desc;
 int slh_run_program(const void* program, int64_t nbytes, slh_stream_t stream);

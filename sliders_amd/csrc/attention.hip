@@ -179,10 +179,10 @@ __global__ __launch_bounds__(64 * NW, DT == 1 ? (NW == 4 ? 4 : 3) : ((DT == 2 &&
 
 // src [B][T][ld], head h = columns [h*D, (h+1)*D) -> dst [B][H][Dp][ldt], Dp = 64*ceil(D/64); rows d >= D and
 // tokens >= T are written as zeros.  grid = (ldt/64, H * Dp/64, B)
-__global__ __launch_bounds__(256) void transpose_heads_kernel(const slh_transpose_desc p, int D, int DT) {
+__device__ __forceinline__ void transpose_heads_body(const slh_transpose_desc& p, int D, int DT, int bx, int by, int bz) {
     __shared__ __bf16 tile[64][72];
     const int tid = threadIdx.x;
-    const int t0 = blockIdx.x * 64, h = blockIdx.y / DT, dt = blockIdx.y - h * DT, b = blockIdx.z;
+    const int t0 = bx * 64, h = by / DT, dt = by - h * DT, b = bz;
     const __bf16* src = (const __bf16*)p.src;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -205,6 +205,28 @@ __global__ __launch_bounds__(256) void transpose_heads_kernel(const slh_transpos
     for (int e = 0; e < 8; ++e) { o0[e] = tile[tc + e][d]; o1[e] = tile[tc + 8 + e][d]; }
     *(bf16x8*)dst = o0;
     *(bf16x8*)(dst + 8) = o1;
+}
+
+__global__ __launch_bounds__(256) void transpose_heads_kernel(const slh_transpose_desc p, int D, int DT) {
+    transpose_heads_body(p, D, DT, blockIdx.x, blockIdx.y, blockIdx.z);
+}
+
+// n problems in one launch (slh_batch_desc): workgroup -> problem by bisection of the prefix sums
+__global__ __launch_bounds__(256) void transpose_heads_batch_kernel(const slh_transpose_desc* table, const int* prefix, int n) {
+    const int bid = blockIdx.x;
+    int lo = 0, hi = n;
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (prefix[mid] <= bid) lo = mid; else hi = mid;
+    }
+    lo = __builtin_amdgcn_readfirstlane(lo);
+    const slh_transpose_desc d = table[lo];
+    const int D = d.D > 0 ? d.D : 64;
+    const int DT = (D + 63) / 64;
+    const int local = bid - prefix[lo];
+    const int gx = d.ldt / 64, gy = d.H * DT;
+    const int bx = local % gx, rest = local / gx;
+    transpose_heads_body(d, D, DT, bx, rest % gy, rest / gy);
 }
 
 template <int DT>
@@ -234,11 +256,32 @@ extern "C" int slh_attn_fwd(const slh_attn_desc* d, slh_stream_t stream) {
     return launch_fwd<3>(d, s);
 }
 
-extern "C" int slh_transpose_heads(const slh_transpose_desc* d, slh_stream_t stream) {
+static int transpose_check(const slh_transpose_desc* d) {
     SLH_CHECK(d && d->src && d->dst, "slh_transpose_heads: null pointer");
     SLH_CHECK(d->ld % 8 == 0 && d->ldt % 64 == 0 && d->ldt >= d->T, "slh_transpose_heads: alignment");
+    SLH_CHECK(d->B > 0 && d->H > 0 && d->T > 0, "slh_transpose_heads: empty problem");
     const int D = d->D > 0 ? d->D : 64;
     SLH_CHECK(D % 8 == 0 && D <= 192, "slh_transpose_heads: head_dim %d unsupported", D);
+    return 0;
+}
+
+extern "C" int slh_transpose_heads_blocks(const slh_transpose_desc* d) {
+    if (transpose_check(d)) return -1;
+    const int D = d->D > 0 ? d->D : 64;
+    return (d->ldt / 64) * d->H * ((D + 63) / 64) * d->B;
+}
+
+extern "C" int slh_transpose_heads_batch(const slh_batch_desc* d, slh_stream_t stream) {
+    SLH_CHECK(d && d->table && d->prefix && d->n > 0 && d->total > 0, "slh_transpose_heads_batch: empty batch / null pointer");
+    hipLaunchKernelGGL(transpose_heads_batch_kernel, dim3(d->total), dim3(256), 0, (hipStream_t)stream,
+                       (const slh_transpose_desc*)d->table, d->prefix, d->n);
+    SLH_LAUNCH_CHECK("slh_transpose_heads_batch");
+    return 0;
+}
+
+extern "C" int slh_transpose_heads(const slh_transpose_desc* d, slh_stream_t stream) {
+    if (transpose_check(d)) return -1;
+    const int D = d->D > 0 ? d->D : 64;
     const int DT = (D + 63) / 64;
     dim3 grid(d->ldt / 64, d->H * DT, d->B);
     hipLaunchKernelGGL(transpose_heads_kernel, grid, dim3(256), 0, (hipStream_t)stream, *d, D, DT);

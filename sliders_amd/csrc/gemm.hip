@@ -1002,11 +1002,18 @@ extern "C" int slh_gemm(const slh_gemm_desc* d, slh_stream_t stream) {
         SLH_CHECK(d->M == d->batch * d->ho * d->wo, "slh_gemm: conv M mismatch");
     }
     if (d->lora_down) {
-        SLH_CHECK(!d->lora_t && d->lora_up && d->lora_scale && !d->lora_up_rmajor && !d->geglu,
-                  "slh_gemm: fused lora_down excludes an external T / r-major up / geglu");
-        SLH_CHECK(d->lora_groups >= 1 && d->lora_groups <= 3 && d->lora_rank == 4 * d->lora_groups &&
-                      d->N % d->lora_groups == 0 && (d->N / d->lora_groups) % 4 == 0,
-                  "slh_gemm: fused lora needs rank = 4 * groups");
+        SLH_CHECK(!d->lora_t && d->lora_up && d->lora_scale && !d->geglu, "slh_gemm: fused lora_down excludes an external T / geglu");
+        if (d->lora_up_rmajor) {
+            // backward-data form: lora_down = the k-major copy of the up matrices ([rank][K], block-diagonal over a fused
+            // q|k|v group), lora_up = the down matrices as stored ([rank][N]); U = dY . B leaves through lora_t_out
+            SLH_CHECK(d->lora_groups == 1 && (d->lora_rank == 4 || d->lora_rank == 8 || d->lora_rank == 12) &&
+                          ((d->tile >> 16) & 15) <= 1,
+                      "slh_gemm: fused r-major lora needs groups = 1, rank in {4, 8, 12}, no split-K");
+        } else {
+            SLH_CHECK(d->lora_groups >= 1 && d->lora_groups <= 3 && d->lora_rank == 4 * d->lora_groups &&
+                          d->N % d->lora_groups == 0 && (d->N / d->lora_groups) % 4 == 0,
+                      "slh_gemm: fused lora needs rank = 4 * groups");
+        }
         if (d->lora_t_out) SLH_CHECK(d->ld_t >= d->lora_rank && d->ld_t % 4 == 0, "slh_gemm: ld_t for lora_t_out");
     }
     if (d->lora_t) {

@@ -183,14 +183,14 @@ struct WgradArgs {
 };
 
 template <int R>
-__global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p) {
+__device__ __forceinline__ void wgrad_body(const WgradArgs& p, const int bx, const int by, const int bz) {
     __shared__ float red[4][32][8 * R + 1];
     const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;
     const int C = p.A.ca0 + p.A.ca1;
-    const int c = (blockIdx.x * 32 + cx) * 8;
+    const int c = (bx * 32 + cx) * 8;
     const bool cvalid = c < C;
-    const int tap = blockIdx.z;
-    const int m_begin = blockIdx.y * p.rows_per_block;
+    const int tap = bz;
+    const int m_begin = by * p.rows_per_block;
     const int m_end = min(p.M, m_begin + p.rows_per_block);
     float acc[8][R];
 #pragma unroll
@@ -245,7 +245,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p) {
         const int ccx = idx / (8 * R);
         const int er = idx - ccx * (8 * R);
         const int e = er / R, r = er - e * R;
-        const int cc = (blockIdx.x * 32 + ccx) * 8 + e;
+        const int cc = (bx * 32 + ccx) * 8 + e;
         if (cc >= C) continue;
         float t = 0.f;
 #pragma unroll
@@ -254,6 +254,64 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p) {
         float* o = p.rmajor ? p.out + (long)r * p.ldo + col : p.out + col * p.ldo + r;
         atomicAdd(o, s * t);
     }
+}
+
+template <int R>
+__global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p) {
+    wgrad_body<R>(p, blockIdx.x, blockIdx.y, blockIdx.z);
+}
+
+// launch geometry of one weight-gradient problem (host and device agree by construction)
+struct WgradGeom { int gx, splits, taps, rows_per_block; };
+__host__ __device__ inline WgradGeom wgrad_geom(int C, int M, int mode) {
+    WgradGeom g;
+    g.gx = (C / 8 + 31) / 32;
+    g.taps = mode == 1 ? 9 : 1;
+    // a rank-4 gradient is a reduction over M with only C/256 (x9 taps) independent column blocks: split M until the
+    // launch has ~768 workgroups (3 per CU), at least 64 rows each; partial sums meet in the fp32 atomics of wgrad_body
+    const int blocks_xz = g.gx * g.taps;
+    int splits = (768 + blocks_xz - 1) / blocks_xz;
+    const int max_splits = (M + 63) / 64, min_splits = (M + 1023) / 1024;
+    if (splits > max_splits) splits = max_splits;
+    if (splits < min_splits) splits = min_splits;
+    if (splits < 1) splits = 1;
+    g.splits = splits;
+    g.rows_per_block = ((M + splits - 1) / splits + 7) / 8 * 8;
+    return g;
+}
+
+__host__ __device__ inline void wgrad_args(WgradArgs& p, const slh_wgrad_desc& d) {
+    p.A.a0 = (const __bf16*)d.z0; p.A.a1 = (const __bf16*)d.z1;
+    p.A.lda0 = d.ldz0; p.A.lda1 = d.ldz1; p.A.ca0 = d.c0; p.A.ca1 = d.c1; p.A.mode = d.mode;
+    p.A.hs = d.hs; p.A.ws = d.ws; p.A.src_xform = d.src_xform; p.A.stride = d.stride; p.A.ho = d.ho; p.A.wo = d.wo;
+    p.v = d.v; p.out = d.out; p.scale = d.scale;
+    p.M = d.M; p.R = d.R; p.ldv = d.ldv; p.ldo = d.ldo;
+    p.rmajor = d.out_rmajor;
+    p.vgroup_cols = d.vgroup_cols;
+    p.rows_per_block = wgrad_geom(d.c0 + d.c1, d.M, d.mode).rows_per_block;
+}
+
+// problem of workgroup `bid`: the last index with prefix[index] <= bid (prefix[0] = 0, prefix[n] = total > bid)
+__device__ __forceinline__ int batch_find(const int* prefix, int n, int bid) {
+    int lo = 0, hi = n;
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (prefix[mid] <= bid) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+template <int R>
+__global__ __launch_bounds__(256) void wgrad_batch_kernel(const slh_wgrad_desc* table, const int* prefix, int n) {
+    const int bid = blockIdx.x;
+    const int pi = __builtin_amdgcn_readfirstlane(batch_find(prefix, n, bid));
+    const slh_wgrad_desc d = table[pi];
+    WgradArgs p;
+    wgrad_args(p, d);
+    const WgradGeom g = wgrad_geom(d.c0 + d.c1, d.M, d.mode);
+    const int local = bid - prefix[pi];
+    const int bx = local % g.gx, rest = local / g.gx;
+    wgrad_body<R>(p, bx, rest % g.splits, rest / g.splits);
 }
 
 }  // namespace
@@ -316,35 +374,44 @@ extern "C" int slh_gemv(const slh_gemv_desc* d, slh_stream_t stream) {
     return 0;
 }
 
-extern "C" int slh_lora_wgrad(const slh_wgrad_desc* d, slh_stream_t stream) {
+static int wgrad_check(const slh_wgrad_desc* d) {
     SLH_CHECK(d && d->z0 && d->v && d->out && d->scale, "slh_lora_wgrad: null pointer");
     SLH_CHECK(d->R == 4 || d->R == 12, "slh_lora_wgrad: R must be 4 or 12");
     SLH_CHECK(d->c0 % 8 == 0 && d->c1 % 8 == 0 && d->ldz0 % 8 == 0 && d->ldz1 % 8 == 0, "slh_lora_wgrad: alignment");
     SLH_CHECK((d->z1 != nullptr) == (d->c1 > 0), "slh_lora_wgrad: z1/c1 mismatch");
-    WgradArgs p;
-    fill_addr(p.A, d->z0, d->z1, d->ldz0, d->ldz1, d->c0, d->c1, d->mode, d->hs, d->ws, d->src_xform, d->stride,
-              d->ho, d->wo);
+    SLH_CHECK(d->M > 0 && d->c0 + d->c1 > 0, "slh_lora_wgrad: empty problem");
     if (d->mode == 1) SLH_CHECK(d->M == d->batch * d->ho * d->wo, "slh_lora_wgrad: conv M mismatch");
-    p.v = d->v; p.out = d->out; p.scale = d->scale;
-    p.M = d->M; p.R = d->R; p.ldv = d->ldv; p.ldo = d->ldo;
-    p.rmajor = d->out_rmajor;
-    p.vgroup_cols = d->vgroup_cols;
-    const int C = d->c0 + d->c1;
-    const int gx = (C / 8 + 31) / 32;
-    // a rank-4 gradient is a reduction over M with only C/256 (x9 taps) independent column blocks: split M until the
-    // launch has ~768 workgroups (3 per CU), at least 64 rows each; partial sums meet in the fp32 atomics below
-    const int blocks_xz = gx * (d->mode == 1 ? 9 : 1);
-    int splits = (768 + blocks_xz - 1) / blocks_xz;
-    const int max_splits = (d->M + 63) / 64, min_splits = (d->M + 1023) / 1024;
-    if (splits > max_splits) splits = max_splits;
-    if (splits < min_splits) splits = min_splits;
-    if (splits < 1) splits = 1;
-    p.rows_per_block = ((d->M + splits - 1) / splits + 7) / 8 * 8;
-    dim3 grid(gx, splits, d->mode == 1 ? 9 : 1);
+    return 0;
+}
+
+extern "C" int slh_lora_wgrad(const slh_wgrad_desc* d, slh_stream_t stream) {
+    if (wgrad_check(d)) return -1;
+    WgradArgs p;
+    wgrad_args(p, *d);
+    const WgradGeom g = wgrad_geom(d->c0 + d->c1, d->M, d->mode);
+    dim3 grid(g.gx, g.splits, g.taps);
     hipStream_t s = (hipStream_t)stream;
     if (d->R == 4) hipLaunchKernelGGL(wgrad_kernel<4>, grid, dim3(256), 0, s, p);
     else hipLaunchKernelGGL(wgrad_kernel<12>, grid, dim3(256), 0, s, p);
     SLH_LAUNCH_CHECK("slh_lora_wgrad");
+    return 0;
+}
+
+extern "C" int slh_lora_wgrad_blocks(const slh_wgrad_desc* d) {
+    if (wgrad_check(d)) return -1;
+    const WgradGeom g = wgrad_geom(d->c0 + d->c1, d->M, d->mode);
+    return g.gx * g.splits * g.taps;
+}
+
+extern "C" int slh_lora_wgrad_batch(const slh_batch_desc* d, slh_stream_t stream) {
+    SLH_CHECK(d && d->table && d->prefix && d->n > 0 && d->total > 0, "slh_lora_wgrad_batch: empty batch / null pointer");
+    SLH_CHECK(d->arg == 4 || d->arg == 12, "slh_lora_wgrad_batch: arg must be the common R (4 or 12)");
+    hipStream_t s = (hipStream_t)stream;
+    if (d->arg == 4)
+        hipLaunchKernelGGL(wgrad_batch_kernel<4>, dim3(d->total), dim3(256), 0, s, (const slh_wgrad_desc*)d->table, d->prefix, d->n);
+    else
+        hipLaunchKernelGGL(wgrad_batch_kernel<12>, dim3(d->total), dim3(256), 0, s, (const slh_wgrad_desc*)d->table, d->prefix, d->n);
+    SLH_LAUNCH_CHECK("slh_lora_wgrad_batch");
     return 0;
 }
 

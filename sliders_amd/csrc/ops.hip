@@ -324,6 +324,23 @@ extern "C" int slh_elementwise(const slh_ew_desc* d, slh_stream_t stream) {
     return 0;
 }
 
+namespace {
+__global__ __launch_bounds__(256) void gather16_kernel(const unsigned short* src, const int* idx, unsigned short* out, long n) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int j = idx[i];
+    out[i] = j < 0 ? (unsigned short)0 : src[j];
+}
+}  // namespace
+
+extern "C" int slh_gather16(const slh_gather16_desc* d, slh_stream_t stream) {
+    SLH_CHECK(d && d->src && d->idx && d->out && d->n > 0, "slh_gather16: null pointer / empty");
+    hipLaunchKernelGGL(gather16_kernel, dim3((unsigned)((d->n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const unsigned short*)d->src, d->idx, (unsigned short*)d->out, (long)d->n);
+    SLH_LAUNCH_CHECK("slh_gather16");
+    return 0;
+}
+
 extern "C" int slh_cfg_ddim(const slh_cfg_ddim_desc* d, slh_stream_t stream) {
     SLH_CHECK(d && d->eps && d->out && (d->x || !d->do_step), "slh_cfg_ddim: null pointer");
     const long n = (long)d->nb * d->chw;

@@ -73,6 +73,9 @@ extern "C" int slh_run_program(const void* program, int64_t nbytes, slh_stream_t
             case SLH_OP_VAE_MOMENTS: rc = run_desc<slh_vae_conv_desc>(p, sz, slh_vae_moments, stream, "vae_moments"); break;
             case SLH_OP_VAE_POST_QUANT: rc = run_desc<slh_vae_conv_desc>(p, sz, slh_vae_post_quant, stream, "vae_post_quant"); break;
             case SLH_OP_VAE_SAMPLE: rc = run_desc<slh_vae_sample_desc>(p, sz, slh_vae_sample, stream, "vae_sample"); break;
+            case SLH_OP_WGRAD_BATCH: rc = run_desc<slh_batch_desc>(p, sz, slh_lora_wgrad_batch, stream, "wgrad_batch"); break;
+            case SLH_OP_TRANSPOSE_BATCH: rc = run_desc<slh_batch_desc>(p, sz, slh_transpose_heads_batch, stream, "transpose_batch"); break;
+            case SLH_OP_GATHER16: rc = run_desc<slh_gather16_desc>(p, sz, slh_gather16, stream, "gather16"); break;
             case SLH_OP_MEMSET: {
                 if (sz != (int32_t)sizeof(slh_memset_desc)) { slh_set_error("slh_run_program: memset desc size"); return -3; }
                 slh_memset_desc d;
@@ -160,7 +163,8 @@ extern "C" int slh_desc_sizes(int32_t* out, int32_t cap) {
         (int32_t)sizeof(slh_wgrad_desc),    (int32_t)sizeof(slh_adamw_desc),    (int32_t)sizeof(slh_memset_desc),
         (int32_t)sizeof(slh_lora_cdgrad_desc), (int32_t)sizeof(slh_temb_lora_bwd_desc),
         (int32_t)sizeof(slh_sgemm_desc),    (int32_t)sizeof(slh_gn32_desc),     (int32_t)sizeof(slh_softmax32_desc),
-        (int32_t)sizeof(slh_vae_conv_desc), (int32_t)sizeof(slh_vae_sample_desc), (int32_t)sizeof(slh_lion_desc)};
+        (int32_t)sizeof(slh_vae_conv_desc), (int32_t)sizeof(slh_vae_sample_desc), (int32_t)sizeof(slh_lion_desc),
+        (int32_t)sizeof(slh_batch_desc),    (int32_t)sizeof(slh_gather16_desc)};
     const int n = (int)(sizeof(sizes) / sizeof(sizes[0]));
     for (int i = 0; i < n && i < cap; ++i) out[i] = sizes[i];
     return n;

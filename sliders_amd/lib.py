@@ -90,6 +90,8 @@ Gn32Desc = _struct("Gn32Desc", _ptrs("x", "gamma", "beta", "stats", "y") + _ints
 Softmax32Desc = _struct("Softmax32Desc", _ptrs("x") + [("ld", c_i64)] + _ints("rows", "cols"))
 VaeConvDesc = _struct("VaeConvDesc", _ptrs("x", "w", "bias", "qw", "qb", "y") + _ints("batch", "h", "wd", "cin", "cout")
                       + [("inv_scaling", c_f32)])
+BatchDesc = _struct("BatchDesc", _ptrs("table", "prefix") + _ints("n", "total", "arg", "pad_"))
+Gather16Desc = _struct("Gather16Desc", _ptrs("src", "idx", "out") + [("n", c_i64)])
 VaeSampleDesc = _struct("VaeSampleDesc", _ptrs("moments", "post_noise", "noise", "latent_f32", "noisy_f32", "noisy_bf16")
                         + _ints("batch", "hw") + [("scaling", c_f32), ("sqrt_alpha", c_f32), ("sqrt_one_minus_alpha", c_f32)]
                         + _ints("pad_"))
@@ -97,7 +99,8 @@ VaeSampleDesc = _struct("VaeSampleDesc", _ptrs("moments", "post_noise", "noise",
 # order of slh_desc_sizes()
 _SIZE_ORDER = [GemmDesc, SkinnyDesc, GemvDesc, GnDesc, GnBwdDesc, LnDesc, LnBwdDesc, AttnDesc, TransposeDesc,
                AttnBwdDesc, TembedDesc, ConvInDesc, EwDesc, CfgDdimDesc, LossDesc, WgradDesc, AdamwDesc, MemsetDesc,
-               LoraCdgradDesc, TembLoraBwdDesc, SgemmDesc, Gn32Desc, Softmax32Desc, VaeConvDesc, VaeSampleDesc, LionDesc]
+               LoraCdgradDesc, TembLoraBwdDesc, SgemmDesc, Gn32Desc, Softmax32Desc, VaeConvDesc, VaeSampleDesc, LionDesc,
+               BatchDesc, Gather16Desc]
 
 # opcodes (enum in sliders_hip.h)
 OP_GEMM, OP_SKINNY, OP_GEMV, OP_GN_STATS, OP_GN_APPLY, OP_LAYERNORM, OP_ATTN_FWD, OP_TRANSPOSE_HEADS = range(1, 9)
@@ -106,6 +109,7 @@ OP_GN_BWD_STATS, OP_GN_BWD_APPLY, OP_LAYERNORM_BWD, OP_ATTN_BWD, OP_MEMSET = ran
 OP_LORA_CONV_DGRAD, OP_TEMB_LORA_BWD = 21, 22
 OP_SGEMM, OP_GN32_STATS, OP_GN32_APPLY, OP_SOFTMAX32, OP_VAE_CONV_IN, OP_VAE_MOMENTS, OP_VAE_SAMPLE, OP_VAE_POST_QUANT = range(23, 31)
 OP_LION = 31
+OP_WGRAD_BATCH, OP_TRANSPOSE_BATCH, OP_GATHER16 = 32, 33, 34
 
 EW_COPY, EW_ADD, EW_GEGLU_FWD, EW_GEGLU_BWD, EW_UPSAMPLE_BWD, EW_COLSUM = range(6)
 
@@ -125,10 +129,13 @@ _ENTRY = {
     OP_SOFTMAX32: ("slh_softmax32", Softmax32Desc), OP_VAE_CONV_IN: ("slh_vae_conv_in", VaeConvDesc),
     OP_VAE_MOMENTS: ("slh_vae_moments", VaeConvDesc), OP_VAE_SAMPLE: ("slh_vae_sample", VaeSampleDesc),
     OP_VAE_POST_QUANT: ("slh_vae_post_quant", VaeConvDesc), OP_LION: ("slh_lion", LionDesc),
+    OP_WGRAD_BATCH: ("slh_lora_wgrad_batch", BatchDesc), OP_TRANSPOSE_BATCH: ("slh_transpose_heads_batch", BatchDesc),
+    OP_GATHER16: ("slh_gather16", Gather16Desc),
 }
 
 EXPORTS = ["slh_version", "slh_last_error", "slh_run_program", "slh_desc_sizes", "slh_graph_capture", "slh_graph_launch",
-           "slh_graph_destroy", "slh_gemm_variant", "slh_gn_row_blocks", "slh_gn_clusters", "slh_gn32_row_blocks"] + [v[0] for v in _ENTRY.values()]
+           "slh_graph_destroy", "slh_gemm_variant", "slh_gn_row_blocks", "slh_gn_clusters", "slh_gn32_row_blocks",
+           "slh_lora_wgrad_blocks", "slh_transpose_heads_blocks"] + [v[0] for v in _ENTRY.values()]
 
 
 class SlidersHipError(RuntimeError):
@@ -166,8 +173,8 @@ def load() -> C.CDLL:
         fn = getattr(lib, name)
         fn.argtypes = [C.POINTER(desc), c_vp]
         fn.restype = c_i32
-    sizes = (c_i32 * 32)()
-    n = lib.slh_desc_sizes(sizes, 32)
+    sizes = (c_i32 * 64)()
+    n = lib.slh_desc_sizes(sizes, 64)
     if n != len(_SIZE_ORDER):
         raise SlidersHipError(f"binding/library mismatch: library reports {n} descriptors, binding has {len(_SIZE_ORDER)}")
     for i, d in enumerate(_SIZE_ORDER):
@@ -202,6 +209,34 @@ def gn32_workspace(hw: int):
     r = l.slh_gn32_row_blocks(hw)
     c = l.slh_gn_clusters(r)
     return r + c, 1 + c
+
+
+_BATCH_KINDS = {OP_WGRAD_BATCH: ("slh_lora_wgrad_blocks", WgradDesc), OP_TRANSPOSE_BATCH: ("slh_transpose_heads_blocks", TransposeDesc)}
+
+
+def batch_table(opcode: int, descs, device, arg: int = 0):
+    """n problems of one kind -> (BatchDesc, tensors to keep alive): the descriptors packed into a device byte table and the
+    int32 prefix sums of the workgroups each needs (include/sliders_hip.h, slh_batch_desc).  Every descriptor is validated by
+    the library here, at plan time (slh_*_blocks); device = None builds a pointer-less descriptor for dry-run planning."""
+    import torch
+    fn_name, dtype = _BATCH_KINDS[opcode]
+    l = load()
+    fn = getattr(l, fn_name)
+    fn.argtypes = [C.POINTER(dtype)]
+    fn.restype = c_i32
+    prefix = [0]
+    for d in descs:
+        assert isinstance(d, dtype)
+        nb = fn(C.byref(d)) if device is not None else 1
+        if nb <= 0:
+            raise SlidersHipError(f"{fn_name}: {last_error()}")
+        prefix.append(prefix[-1] + nb)
+    if device is None:
+        return BatchDesc(table=0x1000, prefix=0x1000, n=len(descs), total=prefix[-1], arg=arg), ()
+    raw = b"".join(bytes(d) for d in descs)
+    table = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(device)
+    pre = torch.tensor(prefix, dtype=torch.int32, device=device)
+    return BatchDesc(table=table.data_ptr(), prefix=pre.data_ptr(), n=len(descs), total=prefix[-1], arg=arg), (table, pre)
 
 
 def gemm_variant(desc) -> int:

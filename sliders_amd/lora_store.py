@@ -79,6 +79,7 @@ class LoraStore:
         self.exp_avg = torch.zeros(n, dtype=torch.bfloat16, device=device)
         self.exp_avg_sq = torch.zeros(n, dtype=torch.bfloat16, device=device)
         self.opt_step = 0
+        self._build_up_t()
         if init == "reference":
             self.init_reference(kaiming_a)
 
@@ -86,6 +87,8 @@ class LoraStore:
     def _layout(self):
         off = 0
         placed = set()
+        self._up_t_slots: Dict[tuple, tuple] = {}
+        self._up_t_numel = 0
         self.temb_entries: List[LoraEntry] = [e for e in self.entries if e.target.module_path.endswith("time_emb_proj")]
         by_path = self.by_path
 
@@ -99,6 +102,10 @@ class LoraStore:
                 off += e.up_numel
             for e in group:
                 placed.add(e.name)
+            if all(e.target.kind in ("linear", "conv1") for e in group):
+                ntot = sum(e.target.out_dim for e in group)
+                self._up_t_slots[tuple(e.name for e in group)] = (self._up_t_numel, group, ntot)
+                self._up_t_numel += (4 * len(group) * ntot + 7) // 8 * 8
 
         for e in self.entries:
             if e.name in placed or e in self.temb_entries:
@@ -130,6 +137,30 @@ class LoraStore:
         for e in self.entries:
             assert e.down_off % 8 == 0 and e.up_off % 4 == 0, e.name
         self.numel = off
+
+    # ---- k-major copies of the up matrices (backward-data products with the adapter fused in) ---------
+    def up_t_offset(self, grp: List[LoraEntry]) -> Optional[int]:
+        """Element offset, inside self.up_t, of the [4 * len(grp)][sum out_dim] matrix whose row 4g + r holds column r of
+        member g's up matrix over that member's own output columns and zeros elsewhere (block-diagonal for a fused q|k|v
+        group): U = dY . B, a down-projection of the output gradient, rides in the backward-data GEMM as its third operand
+        (planner.BackwardPlan._b_gemm).  One slot per dense group of the layout; None for convolutions / unknown groups."""
+        slot = self._up_t_slots.get(tuple(e.name for e in grp))
+        return None if slot is None else slot[0]
+
+    def _build_up_t(self):
+        """up_t (bf16, refreshed from the live parameters by one slh_gather16 at the head of every backward) and its int32
+        gather index into self.params (-1 = structural zero)."""
+        idx = torch.full((max(self._up_t_numel, 1),), -1, dtype=torch.int32)
+        for off, grp, ntot in self._up_t_slots.values():
+            col = 0
+            for g, e in enumerate(grp):
+                n = e.target.out_dim
+                src = e.up_off + torch.arange(n, dtype=torch.int32)[None, :] * 4 + torch.arange(4, dtype=torch.int32)[:, None]
+                rows = off + (4 * g + torch.arange(4)[:, None]) * ntot + col + torch.arange(n)[None, :]
+                idx[rows.reshape(-1).long()] = src.reshape(-1)
+                col += n
+        self.up_t_index = idx.to(self.device)
+        self.up_t = torch.zeros(max(self._up_t_numel, 1), dtype=torch.bfloat16, device=self.device)
 
     def fused_group(self, paths: List[str]) -> Optional[List[LoraEntry]]:
         """Entries for `paths` if they are all adapted AND stored adjacently (downs then ups), else None."""

@@ -604,12 +604,39 @@ class BackwardPlan:
         zmark = self.zarena.mark()
         H, W = fwd.H, fwd.W
         self.deps_pix = self.arena.alloc((nb * H * W, 4), torch.float32, "bwd.deps_pix")
+        # launches that do not sit on the dependency chain are collected and issued as ONE batched launch each
+        # (slh_batch_desc): the head transposes of FORWARD activations (K^T, Q^T of every attention layer) at the head of the
+        # program, and the adapters' weight gradients at its tail - except the up-gradient (dB) of a module whose output
+        # gradient buffer doubles as its residual input's (alias_grad): later accumulations would change dY under it
+        self._tr_batch: List = []
+        self._wg_batch: Dict[int, List] = {4: [], 12: []}
+        self._keep: List = []            # device tables of the batched launches
+        self.batched = os.environ.get("SLIDERS_BWD_UNBATCHED") is None
+        self.fuse_u = os.environ.get("SLIDERS_BWD_UNFUSED_U") is None
+        self._uses_up_t = False
         self._walk()
+        dev = None if self.arena.virtual else fwd.lora.params.device
+        for R, descs in self._wg_batch.items():
+            if descs:
+                bd, keep = lib.batch_table(lib.OP_WGRAD_BATCH, descs, dev, arg=R)
+                self._keep.append(keep)
+                self.prog.add(lib.OP_WGRAD_BATCH, bd, f"bwd.wgrad_batch_R{R}")
         zend = self.zarena.mark()
         head = lib.Program()
         if zend > zmark:
             p, n = self.zarena.region(zmark, zend)
             head.memset(p, n, 0, "zero_bwd_stats")
+        if self._uses_up_t:
+            if self.arena.virtual:
+                gd = lib.Gather16Desc(src=0x1000, idx=0x1000, out=0x1000, n=1)
+            else:
+                gd = lib.Gather16Desc(src=fwd.lora.params.data_ptr(), idx=fwd.lora.up_t_index.data_ptr(),
+                                      out=fwd.lora.up_t.data_ptr(), n=fwd.lora.up_t.numel())
+            head.add(lib.OP_GATHER16, gd, "bwd.up_t")
+        if self._tr_batch:
+            bd, keep = lib.batch_table(lib.OP_TRANSPOSE_BATCH, self._tr_batch, dev)
+            self._keep.append(keep)
+            head.add(lib.OP_TRANSPOSE_BATCH, bd, "bwd.kt_qt_batch")
         head.extend(self.prog)
         self.prog = head
 
@@ -719,12 +746,17 @@ class BackwardPlan:
         ps = self._sl(pre)
         self._ew(lib.EW_GEGLU_BWD, ps, gp, go, "bwd." + rec["name"], C=out.C)
 
-    def _transpose(self, src: Act, heads: int, T: int, name: str):
+    def _transpose(self, src: Act, heads: int, T: int, name: str, forward_data: bool = False):
+        """forward_data: src is an activation of the forward pass (final before the backward starts): the transpose joins
+        the one batched launch at the head of the program instead of sitting in the chain."""
         D = src.C // heads
         ldt = (T + 63) // 64 * 64
         t = self.arena.alloc((self.nb, heads, (D + 63) // 64 * 64, ldt), torch.bfloat16, name)
-        self.prog.add(lib.OP_TRANSPOSE_HEADS, lib.TransposeDesc(src=src.ptr, dst=t.ptr, B=self.nb, H=heads, T=T,
-                                                                ld=src.ld, ldt=ldt, D=D), name)
+        d = lib.TransposeDesc(src=src.ptr, dst=t.ptr, B=self.nb, H=heads, T=T, ld=src.ld, ldt=ldt, D=D)
+        if forward_data and self.batched:
+            self._tr_batch.append(d)
+        else:
+            self.prog.add(lib.OP_TRANSPOSE_HEADS, d, name)
         return t, ldt
 
     def _b_attn(self, rec):
@@ -735,7 +767,7 @@ class BackwardPlan:
         go, _ = self.grad(o, write=False)
         need_dkv = 1 if (k.buf.ptr not in self.f.nograd_kv) else 0
         qs, ks, vs, os_ = self._sl(q), self._sl(k), self._sl(v), self._sl(o)
-        kt, ldkt = self._transpose(ks, heads, Tk, "bwd." + rec["name"] + ".kt")
+        kt, ldkt = self._transpose(ks, heads, Tk, "bwd." + rec["name"] + ".kt", forward_data=True)
         gq, aq = self.grad(q)
         assert not aq
         delta = self.arena.alloc((self.nb * heads * Tq + 64,), torch.float32, "bwd." + rec["name"] + ".delta")
@@ -744,7 +776,7 @@ class BackwardPlan:
                             B=self.nb, H=heads, Tq=Tq, Tk=Tk, ldq=qs.ld, ldk=ks.ld, ldv=vs.ld, ldo=os_.ld, lddo=go.ld,
                             ldkt=ldkt, lddq=gq.ld, scale=(q.C // heads) ** -0.5, need_dkv=need_dkv, D=q.C // heads)
         if need_dkv:
-            qt, ldqt = self._transpose(qs, heads, Tq, "bwd." + rec["name"] + ".qt")
+            qt, ldqt = self._transpose(qs, heads, Tq, "bwd." + rec["name"] + ".qt", forward_data=True)
             dot, _ = self._transpose(go, heads, Tq, "bwd." + rec["name"] + ".dot")
             gk, ak = self.grad(k)
             gv, av = self.grad(v)
@@ -755,6 +787,12 @@ class BackwardPlan:
     def _splitk(self, d, name):
         d.tile = tuned_tile(d)
         provision_splitk(self, d, name)
+
+    def _wgrad(self, d, name: str, defer: bool):
+        if defer and self.batched:
+            self._wg_batch[d.R].append(d)
+        else:
+            self.prog.add(lib.OP_WGRAD, d, name)
 
     def _b_gemm(self, rec):
         y = rec["out"]
@@ -791,20 +829,36 @@ class BackwardPlan:
                 self.prog.add(lib.OP_TEMB_LORA_BWD, d, name + ".temb_lora")
         # LoRA: U = dY . B_up per fused member; dB = s dY^T T ; dA = s U^T X
         U = None
+        fused_u = False
+        dA_after = []
+        need0 = x0.buf.ptr not in f.nograd
+        need1 = x1 is not None and x1.buf.ptr not in f.nograd
         if grp is not None:
             ng = len(grp)
             Ng = N // ng
             U = self.arena.alloc((Ms, 4 * ng), torch.float32, name + ".U")
             T = rec["T"]
             Ts = T.ptr + 4 * self.b0 * (Ho * Wo) * 4 * ng
-            for g_i, e in enumerate(grp):
-                d = lib.SkinnyDesc(a0=gy.ptr + 2 * g_i * Ng, w=self.lora.up_ptr(e), out=U.ptr + 4 * 4 * g_i, lda0=gy.ld,
-                                   ca0=Ng, mode=0, stride=1, M=Ms, R=4, K=Ng, ldo=4 * ng, w_kmajor=1)
-                self.prog.add(lib.OP_SKINNY, d, name + f".U{g_i}")
+            # U = dY . B (the up matrices as a rank-4 down-projection of the output gradient): inside the backward-data GEMM
+            # of a dense module - third operand tile = the k-major copy of B (LoraStore.up_t), written out through lora_t_out
+            # for the down-gradient - unless that product runs split-K or does not exist (no gradient needed upstream)
+            up_t_off = self.lora.up_t_offset(grp) if (self.fuse_u and conv is None and x1 is None and (need0 or need1)) else None
+            if up_t_off is not None:
+                probe = lib.GemmDesc(M=Ms, N=x0.C, K=N, mode=0, stride=1)
+                probe.lora_down = 1
+                tile = tuned_tile(probe)
+                fused_u = not (((tile >> 16) & 15) > 1 or (not tile and splitk_wanted(probe)))
+            if not fused_u:
+                for g_i, e in enumerate(grp):
+                    d = lib.SkinnyDesc(a0=gy.ptr + 2 * g_i * Ng, w=self.lora.up_ptr(e), out=U.ptr + 4 * 4 * g_i, lda0=gy.ld,
+                                       ca0=Ng, mode=0, stride=1, M=Ms, R=4, K=Ng, ldo=4 * ng, w_kmajor=1)
+                    self.prog.add(lib.OP_SKINNY, d, name + f".U{g_i}")
             d = lib.WgradDesc(z0=gy.ptr, v=Ts, out=self.lora.gup_ptr(grp[0]), scale=self.scale_ptr, ldz0=gy.ld, c0=N,
                               mode=0, stride=1, M=Ms, R=4, ldv=4 * ng, ldo=4, out_rmajor=0,
                               vgroup_cols=Ng if ng > 1 else 0)
-            self.prog.add(lib.OP_WGRAD, d, name + ".dB")
+            # dY of a module with a residual input may be the residual's gradient buffer too (alias_grad above): it keeps
+            # accumulating after this point, so its up-gradient cannot wait for the batched launch at the tail
+            self._wgrad(d, name + ".dB", defer=r is None or r.buf.ptr in f.nograd)
             x0s = self._sl(x0)
             x1s = self._sl(x1) if x1 is not None else None
             # the down matrices of a fused q|k|v group are adjacent ([12][K]) and so are their U columns: one R = 12 launch
@@ -818,10 +872,11 @@ class BackwardPlan:
                 if conv is not None:
                     d.mode, d.batch, d.hs, d.ws = 1, self.nb, x0.H, x0.W
                     d.src_xform, d.stride, d.ho, d.wo = conv.get("xform", 0), conv.get("stride", 1), Ho, Wo
-                self.prog.add(lib.OP_WGRAD, d, name + f".dA{g_i}")
+                if fused_u:
+                    dA_after.append((d, name + f".dA{g_i}"))            # U is written by the dgrad launch below
+                else:
+                    self._wgrad(d, name + f".dA{g_i}", defer=True)      # forward activations and U: final
         # backward data
-        need0 = x0.buf.ptr not in f.nograd
-        need1 = x1 is not None and x1.buf.ptr not in f.nograd
         if not (need0 or need1):
             return
         cin = x0.C + (x1.C if x1 is not None else 0)
@@ -838,10 +893,20 @@ class BackwardPlan:
                              stride=1, ldw=N, M=Ms, N=cin, K=N, ld_res=tgt.ld, ldc=tgt.ld, rows_per_sample=Ho * Wo,
                              w_layout=1 if self.w.packed else 0)
             if grp is not None:
-                d.lora_t, d.ld_t, d.lora_up, d.lora_scale = U.ptr, 4 * len(grp), self.lora.down_ptr(grp[0]), self.scale_ptr
+                d.ld_t, d.lora_up, d.lora_scale = 4 * len(grp), self.lora.down_ptr(grp[0]), self.scale_ptr
                 d.lora_groups, d.lora_rank, d.lora_up_rmajor = 1, 4 * len(grp), 1
+                if fused_u:
+                    self._uses_up_t = True
+                    base = 0x2000 if self.arena.virtual else self.lora.up_t.data_ptr()
+                    d.lora_down, d.lora_t_out = base + 2 * up_t_off, U.ptr
+                else:
+                    d.lora_t = U.ptr
             self._splitk(d, name)
+            if fused_u:
+                assert ((d.tile >> 16) & 15) <= 1 and not d.splitk_c32, name
             self.prog.add(lib.OP_GEMM, d, name + ".dgrad")
+            for dA, nm in dA_after:
+                self._wgrad(dA, nm, defer=True)
             if x1 is not None:
                 if need0:
                     self.add_into(x0, tgt.cols(0, x0.C), name + ".gx0")

@@ -37,6 +37,9 @@ def tuned_tile(d) -> int:
         return 0
     tb = table()
     t = tb.get(gemm_key(d, True), tb.get(gemm_key(d), 0))
+    if not t and d.lora_down:      # adapter fused in but only the plain product was measured (backward-data GEMMs): same tile
+        k = gemm_key(d, True)
+        t = tb.get(k[:-1] + "0", 0)
     force = os.environ.get("SLIDERS_FORCE_STAGES")     # experiment knob: 2 or 3 for every non-128x128 tile
     if force and t and (t & 0xFF) != 0x22:
         t = (t & 0xFF) | (int(force) << 8 if force == "3" else 0)

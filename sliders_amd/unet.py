@@ -280,6 +280,9 @@ class _VirtualLora:
     def fused_group(self, paths):
         return self._s.fused_group(paths)
 
+    def up_t_offset(self, grp):
+        return self._s.up_t_offset(grp)
+
     def down_ptr(self, e):
         return 0x2000
 

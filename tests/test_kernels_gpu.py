@@ -689,6 +689,106 @@ def test_lora_wgrad(dev):
     report("wgrad_conv", out, 0.25 * wd.grad.permute(0, 2, 3, 1).reshape(4, -1), 1e-4)
 
 
+def test_batched_wgrad_transposes_and_gather(dev):
+    """slh_batch_desc: n weight-gradient reductions / head transposes of different shapes in ONE launch give what the n
+    single launches give (the table and the prefix sums of workgroups live in device memory; a workgroup finds its problem
+    by bisection), and slh_gather16 builds the k-major, block-diagonal copy of the up matrices."""
+    torch.manual_seed(15)
+    scale = torch.tensor([0.5], device=dev)
+    probs, keep = [], []
+    for M, C, R, rmajor in ((1500, 320, 4, 0), (700, 1280, 4, 1), (64, 64, 4, 0), (2048, 640, 4, 1), (300, 2560, 4, 0)):
+        z = bf(torch.randn(M, C, device=dev))
+        v = torch.randn(M, 8, device=dev)
+        out_b = torch.randn(R, C, device=dev) if rmajor else torch.randn(C, R, device=dev)      # += semantics: start non-zero
+        out_s = out_b.clone()
+        mk = lambda o: lib.WgradDesc(z0=p(z), v=p(v), out=p(o), scale=p(scale), ldz0=C, c0=C, mode=0, stride=1, M=M, R=R, ldv=8,
+                                     ldo=C if rmajor else R, out_rmajor=rmajor, vgroup_cols=0)
+        probs.append((mk(out_b), mk(out_s), out_b, out_s))
+        keep += [z, v]
+    # one conv-mode problem in the same batch
+    B, H, W, Ci = 2, 10, 12, 64
+    img = bf(torch.randn(B * H * W, Ci, device=dev))
+    U = torch.randn(B * H * W, 4, device=dev)
+    ob, os_ = torch.zeros(4, 9 * Ci, device=dev), torch.zeros(4, 9 * Ci, device=dev)
+    mk = lambda o: lib.WgradDesc(z0=p(img), v=p(U), out=p(o), scale=p(scale), ldz0=Ci, c0=Ci, mode=1, batch=B, hs=H, ws=W, stride=1,
+                                 ho=H, wo=W, M=B * H * W, R=4, ldv=4, ldo=9 * Ci, out_rmajor=1, vgroup_cols=0)
+    probs.append((mk(ob), mk(os_), ob, os_))
+    bd, tabs = lib.batch_table(lib.OP_WGRAD_BATCH, [q[0] for q in probs], dev, arg=4)
+    lib.call(lib.OP_WGRAD_BATCH, bd, stream())
+    for _, ds, _, _ in probs:
+        lib.call(lib.OP_WGRAD, ds, stream())
+    torch.cuda.synchronize()
+    for i, (_, _, o_b, o_s) in enumerate(probs):
+        report(f"wgrad batch problem {i}", o_b, o_s, 1e-5)
+    # R = 12 batch
+    z = bf(torch.randn(900, 640, device=dev)); v = torch.randn(900, 12, device=dev)
+    o1, o2 = torch.zeros(12, 640, device=dev), torch.zeros(12, 640, device=dev)
+    mk = lambda o: lib.WgradDesc(z0=p(z), v=p(v), out=p(o), scale=p(scale), ldz0=640, c0=640, mode=0, stride=1, M=900, R=12, ldv=12,
+                                 ldo=640, out_rmajor=1, vgroup_cols=0)
+    bd, tabs2 = lib.batch_table(lib.OP_WGRAD_BATCH, [mk(o1)], dev, arg=12)
+    lib.call(lib.OP_WGRAD_BATCH, bd, stream())
+    lib.call(lib.OP_WGRAD, mk(o2), stream())
+    torch.cuda.synchronize()
+    report("wgrad batch R12", o1, o2, 1e-5)
+    report("wgrad batch R12 vs torch", o1, 0.5 * v.t() @ z.float(), 1e-4)
+    # transposes: different head dims / token counts in one launch, bit-equal to the single launches
+    tp = []
+    for Bb, Hh, T, D in ((2, 10, 4096, 64), (1, 8, 77, 40), (2, 5, 1024, 160), (1, 20, 300, 64)):
+        src = bf(torch.randn(Bb * T, Hh * D, device=dev))
+        Dp, ldt = (D + 63) // 64 * 64, (T + 63) // 64 * 64
+        d1 = torch.full((Bb, Hh, Dp, ldt), 7.0, device=dev, dtype=torch.bfloat16)
+        d2 = torch.full((Bb, Hh, Dp, ldt), 7.0, device=dev, dtype=torch.bfloat16)
+        mk = lambda dst: lib.TransposeDesc(src=p(src), dst=p(dst), B=Bb, H=Hh, T=T, ld=Hh * D, ldt=ldt, D=D)
+        tp.append((mk(d1), mk(d2), d1, d2, src))
+    bd, tabs3 = lib.batch_table(lib.OP_TRANSPOSE_BATCH, [q[0] for q in tp], dev)
+    lib.call(lib.OP_TRANSPOSE_BATCH, bd, stream())
+    for _, ds, _, _, _ in tp:
+        lib.call(lib.OP_TRANSPOSE_HEADS, ds, stream())
+    torch.cuda.synchronize()
+    for i, (_, _, d1, d2, _) in enumerate(tp):
+        assert torch.equal(d1, d2), f"transpose batch problem {i}"
+    # a bad descriptor is refused when the table is built
+    with pytest.raises(lib.SlidersHipError):
+        lib.batch_table(lib.OP_TRANSPOSE_BATCH, [lib.TransposeDesc(src=p(src), dst=p(d1), B=1, H=1, T=100, ld=64, ldt=60, D=64)], dev)
+    # gather16
+    src = bf(torch.randn(1000, device=dev))
+    idx = torch.randint(-1, 1000, (4096,), device=dev, dtype=torch.int32)
+    out = torch.zeros(4096, device=dev, dtype=torch.bfloat16)
+    lib.call(lib.OP_GATHER16, lib.Gather16Desc(src=p(src), idx=p(idx), out=p(out), n=4096), stream())
+    torch.cuda.synchronize()
+    ref = torch.where(idx >= 0, src[idx.clamp_min(0).long()], torch.zeros((), device=dev, dtype=torch.bfloat16))
+    assert torch.equal(out, ref)
+
+
+@pytest.mark.parametrize("tile", [0x4412, 0x422, 0x22, 0x11, 0x4322])
+def test_gemm_fused_lora_backward_data_form(dev, tile):
+    """Backward-data product of an adapted Linear with the adapter fused in (slh_gemm_desc.lora_down + lora_up_rmajor):
+    dX = dY . W + s * (dY . B) . A, the rank-4..12 intermediate U = dY . B computed from the k-major copy of the up matrices
+    (block-diagonal for a fused q|k|v group) as the third operand tile and written out for the down-gradient."""
+    torch.manual_seed(32)
+    for groups, M, Nf, Kf in ((1, 300, 320, 640), (3, 512, 3 * 128, 1280)):       # forward: y[M][Nf] = x[M][Kf] W^T
+        dy = bf(torch.randn(M, Nf, device=dev))
+        wT = bf(torch.randn(Kf, Nf, device=dev) / math.sqrt(Nf))                  # dgrad weights: [Kf][Nf]
+        ups = [bf(torch.randn(Nf // groups, 4, device=dev)) for _ in range(groups)]
+        A = bf(torch.randn(4 * groups, Kf, device=dev) / math.sqrt(Kf))           # down matrices as stored [rank][Kf]
+        scale = torch.tensor([0.25], device=dev)
+        up_t = torch.zeros(4 * groups, Nf, device=dev, dtype=torch.bfloat16)
+        Ng = Nf // groups
+        for g in range(groups):
+            up_t[4 * g:4 * g + 4, g * Ng:(g + 1) * Ng] = ups[g].t()
+        U_ref = torch.cat([dy.float()[:, g * Ng:(g + 1) * Ng] @ ups[g].float() for g in range(groups)], 1)
+        ref = dy.float() @ wT.float().t() + 0.25 * U_ref @ A.float()
+        dx = torch.zeros(M, Kf, device=dev, dtype=torch.bfloat16)
+        U = torch.full((M, 4 * groups), float("nan"), device=dev)
+        d = lib.GemmDesc(a0=p(dy), w=p(wT), c=p(dx), lora_down=p(up_t), lora_up=p(A), lora_scale=p(scale), lora_t_out=p(U),
+                         lda0=Nf, ca0=Nf, mode=0, stride=1, ldw=Nf, M=M, N=Kf, K=Nf, ldc=Kf, rows_per_sample=M, ld_t=4 * groups,
+                         lora_groups=1, lora_rank=4 * groups, lora_up_rmajor=1, tile=tile)
+        lib.call(lib.OP_GEMM, d, stream())
+        torch.cuda.synchronize()
+        report(f"fused dgrad+lora groups{groups} tile{tile:x}", dx, ref, TOL)
+        report(f"fused dgrad U groups{groups} tile{tile:x}", U, U_ref, 1e-5)
+
+
 @pytest.mark.parametrize("tile", [0x22, 0x21, 0x12, 0x11, 0x311, 0x4022, 0x4322, 0x4012, 0x4011, 0x422, 0x421, 0x4412, 0x4411])
 def test_gemm_fused_lora_down(dev, tile):
     """LoRAModule.forward fused into one launch: y = x W^T + b + s (x A^T) B^T, T = x A^T written for backward."""
