@@ -63,13 +63,15 @@ def launch(op, d):
 def valid(d, tile):
     mi, ni, wm = (tile >> 4) & 15, tile & 15, (tile >> 12) & 15
     if (tile >> 16) & 15:                       # split-K candidates only where the planner provisioned a workspace
-        if not d.splitk_c32 or (d.K // 64) < 4 * ((tile >> 16) & 15):
+        if not d.splitk_c32 or (d.K // 64) < 4 * ((tile >> 16) & 15) or ((tile >> 16) & 15) > d.splitk_slabs:
             return False
     if d.geglu and ni != 2:
         return False
     if d.ln_out and (ni != 2 or (tile >> 16) & 15):        # folded LayerNorm: the producer writes 64-column chunk statistics
         return False
     if d.ln_in and (tile >> 16) & 15:
+        return False
+    if d.lora_down and d.lora_up_rmajor and (tile >> 16) & 15:     # backward-data product with the adapter fused in
         return False
     if wm == 4 and d.M * d.N < 256 * 128 * 32:
         return False
@@ -106,6 +108,7 @@ for pname, prog in programs:
     gemms = [(i, d) for i, (op, d) in enumerate(prog.ops) if op == lib.OP_GEMM]
     orig = {i: d.tile for i, d in gemms}
     times = defaultdict(lambda: defaultdict(float))      # key -> tile -> total us over the program
+    partial = defaultdict(set)
     counts = defaultdict(int)
     for i, d in gemms:
         counts[gemm_key(d, True)] += 1
@@ -129,12 +132,14 @@ for pname, prog in programs:
             for d, e0, e1 in recs:
                 if tile is None or valid(d, tile):
                     times[gemm_key(d, True)][tile if tile is not None else -1] += e0.elapsed_time(e1) * 1e3 / args.reps
+                elif tile is not None:
+                    partial[gemm_key(d, True)].add(tile)        # not applicable to every launch of the key: not comparable
     for i, d in gemms:
         d.tile = orig[i]
     tot_h = tot_b = 0.0
     print(f"== {pname}: {len(gemms)} GEMM launches, {len(counts)} shapes")
     for key, tt in sorted(times.items(), key=lambda kv: -kv[1][-1]):
-        cand = {t: v for t, v in tt.items() if t != -1}
+        cand = {t: v for t, v in tt.items() if t != -1 and t not in partial[key]}
         if not cand:
             continue
         bt = min(cand, key=cand.get)

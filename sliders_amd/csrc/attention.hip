@@ -21,8 +21,18 @@ __device__ __forceinline__ int lds_off(int row, int slot) {
 }
 
 // NW waves per workgroup: 4 (128 queries) or 2 (64 queries, used when the grid would not fill the chip)
-template <int NW, int DT>
-__global__ __launch_bounds__(64 * NW, DT == 1 ? (NW == 4 ? 4 : 3) : ((DT == 2 && NW == 4) ? 2 : 1)) void attn_fwd_kernel(const slh_attn_desc p) {
+// TAIL: Tk is not a multiple of 64 (cross-attention, Tk = 77): the key columns past Tk of the last tile are masked.  A
+// template flag because hipcc if-converts the mask into ~50 selects per tile that every tile of every launch would execute.
+// SLH_ATTN_GROUPED (A/B build, scripts/probe_attn.py): all fragment reads of a phase issued ahead of its MFMAs - needs ~140
+// VGPRs (3 waves per SIMD instead of 4) and measured the same (412 vs 406 us over the pass shapes: co-resident waves already
+// hide the LDS latency hipcc leaves exposed in front of every MFMA)
+#ifdef SLH_ATTN_GROUPED
+constexpr int ATTN_OCC41 = 3;
+#else
+constexpr int ATTN_OCC41 = 4;
+#endif
+template <int NW, int DT, bool TAIL>
+__global__ __launch_bounds__(64 * NW, DT == 1 ? (NW == 4 ? ATTN_OCC41 : 3) : ((DT == 2 && NW == 4) ? 2 : 1)) void attn_fwd_kernel(const slh_attn_desc p) {
     __shared__ __attribute__((aligned(16))) char smem[4 * DT * 8192];
     char* sK = smem;                    // [2][DT][64 kv][128 B]
     char* sV = smem + 2 * DT * 8192;    // [2][DT][64 d ][128 B]
@@ -92,20 +102,37 @@ __global__ __launch_bounds__(64 * NW, DT == 1 ? (NW == 4 ? 4 : 3) : ((DT == 2 &&
         const char* cK = sK + (t & 1) * DT * 8192;
         const char* cV = sV + (t & 1) * DT * 8192;
         f32x16 s[2];
-#pragma unroll
-        for (int kt = 0; kt < 2; ++kt) {
+        // all K fragments of a 32-key half are requested before its first MFMA (hipcc otherwise emits read -> wait -> MFMA
+        // eight times per tile: ~100 cycles of LDS latency exposed in front of every 32-cycle MFMA); with D <= 64 both
+        // halves' reads go out before any MFMA
+        bf16x8 kf[2][DT * 4];
+        auto read_k = [&](const int kt) {
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
-                for (int ks = 0; ks < 4; ++ks) {
-                    const bf16x8 kf = *(const bf16x8*)(cK + dt * 8192 + lds_off(kt * 32 + prow, ks * 2 + lhi));
-                    // first product of the tile takes a literal-zero C operand instead of 16 zeroed registers
-                    if (dt == 0 && ks == 0) s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[0], kZero16, 0, 0, 0);
-                    else s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[dt * 4 + ks], s[kt], 0, 0, 0);
-                }
-        }
+                for (int ks = 0; ks < 4; ++ks)
+                    kf[kt][dt * 4 + ks] = *(const bf16x8*)(cK + dt * 8192 + lds_off(kt * 32 + prow, ks * 2 + lhi));
+        };
+        auto mma_k = [&](const int kt) {
+#pragma unroll
+            for (int i = 0; i < DT * 4; ++i) {
+                // first product of the tile takes a literal-zero C operand instead of 16 zeroed registers
+                if (i == 0) s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[kt][0], qf[0], kZero16, 0, 0, 0);
+                else s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[kt][i], qf[i], s[kt], 0, 0, 0);
+            }
+        };
+#ifndef SLH_ATTN_GROUPED
+        read_k(0); mma_k(0); read_k(1); mma_k(1);
+#else
+        read_k(0);
+        if (DT == 1) read_k(1);
+        __builtin_amdgcn_sched_barrier(0);
+        mma_k(0);
+        if (DT != 1) { read_k(1); __builtin_amdgcn_sched_barrier(0); }
+        mma_k(1);
+#endif
         // s[kt][r] = S[q = lrow][kv = t*64 + kt*32 + 16*(r>>3) + 8*lhi + (r&7)]
-        if (t == nt - 1 && (p.Tk & 63)) {
+        if (TAIL && t == nt - 1) {
 #pragma unroll
             for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
@@ -149,13 +176,24 @@ __global__ __launch_bounds__(64 * NW, DT == 1 ? (NW == 4 ? 4 : 3) : ((DT == 2 &&
 #pragma unroll
                 for (int r = 0; r < 16; ++r) o[dd][r] *= alpha;
         }
+        // same for V: the four fragments of a 32-wide d block are requested together, the next block's before this block's MFMAs
+        bf16x8 vf[2][4];
+        auto read_v = [&](const int set, const int dd) {
 #pragma unroll
-        for (int dd = 0; dd < 2 * DT; ++dd)
+            for (int kstep = 0; kstep < 4; ++kstep)
+                vf[set][kstep] = *(const bf16x8*)(cV + (dd >> 1) * 8192 + lds_off((dd & 1) * 32 + lrow, kstep * 2 + lhi));
+        };
+        read_v(0, 0);
 #pragma unroll
-            for (int kstep = 0; kstep < 4; ++kstep) {
-                const bf16x8 vf = *(const bf16x8*)(cV + (dd >> 1) * 8192 + lds_off((dd & 1) * 32 + lrow, kstep * 2 + lhi));
-                o[dd] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pb[kstep >> 1][kstep & 1], o[dd], 0, 0, 0);
-            }
+        for (int dd = 0; dd < 2 * DT; ++dd) {
+            if (dd + 1 < 2 * DT) read_v((dd + 1) & 1, dd + 1);
+#ifdef SLH_ATTN_GROUPED
+            __builtin_amdgcn_sched_barrier(0);
+#endif
+#pragma unroll
+            for (int kstep = 0; kstep < 4; ++kstep)
+                o[dd] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[dd & 1][kstep], pb[kstep >> 1][kstep & 1], o[dd], 0, 0, 0);
+        }
     }
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
     const float inv = 1.f / l_tot;
@@ -232,10 +270,14 @@ __global__ __launch_bounds__(256) void transpose_heads_batch_kernel(const slh_tr
 template <int DT>
 int launch_fwd(const slh_attn_desc* d, hipStream_t s) {
     const long blocks4 = (long)((d->Tq + 127) / 128) * d->H * d->B;
-    if (blocks4 >= 256)
-        hipLaunchKernelGGL((attn_fwd_kernel<4, DT>), dim3((d->Tq + 127) / 128, d->H, d->B), dim3(256), 0, s, *d);
-    else
-        hipLaunchKernelGGL((attn_fwd_kernel<2, DT>), dim3((d->Tq + 63) / 64, d->H, d->B), dim3(128), 0, s, *d);
+    const bool tail = (d->Tk & 63) != 0;
+    if (blocks4 >= 256) {
+        if (tail) hipLaunchKernelGGL((attn_fwd_kernel<4, DT, true>), dim3((d->Tq + 127) / 128, d->H, d->B), dim3(256), 0, s, *d);
+        else hipLaunchKernelGGL((attn_fwd_kernel<4, DT, false>), dim3((d->Tq + 127) / 128, d->H, d->B), dim3(256), 0, s, *d);
+    } else {
+        if (tail) hipLaunchKernelGGL((attn_fwd_kernel<2, DT, true>), dim3((d->Tq + 63) / 64, d->H, d->B), dim3(128), 0, s, *d);
+        else hipLaunchKernelGGL((attn_fwd_kernel<2, DT, false>), dim3((d->Tq + 63) / 64, d->H, d->B), dim3(128), 0, s, *d);
+    }
     SLH_LAUNCH_CHECK("slh_attn_fwd");
     return 0;
 }

@@ -135,7 +135,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const slh_attn_bwd_des
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int kv = t * 64 + kt * 32 + 16 * (r >> 3) + 8 * lhi + (r & 7);
-                float pv = exp2f(s[r] * c - lse2);
+                float pv = __builtin_amdgcn_exp2f(s[r] * c - lse2);   // raw v_exp_f32 (argument <= 0), like the forward
                 if (kv >= p.Tk) pv = 0.f;
                 ds[kt][r >> 3][r & 7] = (__bf16)(pv * (dp[r] - delta));
             }
@@ -262,7 +262,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const slh_attn_bwd_de
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     const int r = hf * 8 + e;
-                    float pv = exp2f(s[r] * c - lv[e]);
+                    float pv = __builtin_amdgcn_exp2f(s[r] * c - lv[e]);
                     if (t * 64 + qb + e >= p.Tq) pv = 0.f;
                     pb[qt][hf][e] = (__bf16)pv;
                     dsb[qt][hf][e] = (__bf16)(pv * (dp[r] - dl[e]));

@@ -903,7 +903,7 @@ class BackwardPlan:
                     d.lora_t = U.ptr
             self._splitk(d, name)
             if fused_u:
-                assert ((d.tile >> 16) & 15) <= 1 and not d.splitk_c32, name
+                assert ((d.tile >> 16) & 15) <= 1, name
             self.prog.add(lib.OP_GEMM, d, name + ".dgrad")
             for dA, nm in dA_after:
                 self._wgrad(dA, nm, defer=True)
