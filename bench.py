@@ -148,10 +148,13 @@ def measure_roofline(eng, plan):
     if cands:                                   # PMC counters cannot be read from inside the timed process: the
         tpath = cands[-1]                       # per-launch HBM-side bytes come from the newest committed --pmc passes
         with open(tpath) as f:
-            pm = json.load(f)["kernels"].get(kname.replace(", ", "; "))
+            pmj = json.load(f)
+            pm = pmj["kernels"].get(kname.replace(", ", "; "))
+            thead = pmj.get("tree_head")
         if pm:
             traffic = pm["fetch_bytes_per_launch"] + pm["write_bytes_per_launch"]
-            tsrc = f"profiles/{os.path.basename(tpath)} (FETCH_SIZE x2 + WRITE_SIZE per launch, LoRA-on forward pass)"
+            tsrc = (f"profiles/{os.path.basename(tpath)} (FETCH_SIZE x2 + WRITE_SIZE per launch, LoRA-on forward pass; counter passes "
+                    f"taken on tree {thead or 'unrecorded'})")
     # MFMA utilisation from the newest committed counter pass: SQ_VALU_MFMA_BUSY_CYCLES (32 per 32x32x16 MFMA, summed over
     # the SIMDs) / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs)
     def mfma_util(kernel_prefix):

@@ -14,6 +14,7 @@ def rows(path):
 
 
 fetch, write, out = sys.argv[1:4]
+tree_head = sys.argv[4] if len(sys.argv) > 4 else None      # git HEAD of the tree the passes were taken on
 kern = {}
 for r in rows(fetch):
     n = max(int(r["dispatches"]), 1)
@@ -24,7 +25,7 @@ for r in rows(write):
     k["write_bytes_per_launch"] = int(1024 * float(r["WRITE_SIZE"]) / n)
     hit, miss = float(r["TCC_HIT_sum"]), float(r["TCC_MISS_sum"])
     k["l2_hit_rate"] = round(hit / (hit + miss), 3) if hit + miss > 0 else None
-res = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum (separate passes, --kernel-trace only) over "
+res = {"tree_head": tree_head, "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum (separate passes, --kernel-trace only) over "
                  "LoRA-on SDXL 1024x1024 B=2 UNet passes (scripts/bench_forward.py --lora --warm 0 --iters 1: the first call "
                  "plus one replay); FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports 64 B per 128-B request); "
                  "WRITE_SIZE uncalibrated; KB -> bytes",

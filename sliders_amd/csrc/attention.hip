@@ -40,8 +40,21 @@ __global__ __launch_bounds__(64 * NW, DT == 1 ? (NW == 4 ? ATTN_OCC41 : 3) : ((D
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lrow = lane & 31, lhi = lane >> 5;
     const int frow = lane >> 3, fslot = lane & 7;
-    const int h = blockIdx.y, b = blockIdx.z;
-    const int q0 = blockIdx.x * (32 * NW) + wave * 32;
+    // XCD-aware block order (block i runs on XCD i % 8, each with its own 4 MB L2): every XCD gets a contiguous run of the
+    // (sample, head, query block) sequence with the query block fastest, so the query blocks that share one head's K / V
+    // meet in ONE L2 instead of all eight (counter pass of the round-3 tree: 103 MB fetched per T = 4096 launch for 31 MB of
+    // Q, K, V; L2 hit 52 %)
+    int vb = blockIdx.x;
+    {
+        const int nblk = gridDim.x;
+        const int qd = nblk >> 3, rm = nblk & 7;
+        const int xcd = vb & 7, idx = vb >> 3;
+        vb = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + idx;
+    }
+    const int nqb = (p.Tq + 32 * NW - 1) / (32 * NW);
+    const int qb = vb % nqb, hb = vb / nqb;
+    const int h = hb % p.H, b = hb / p.H;
+    const int q0 = qb * (32 * NW) + wave * 32;
     const int D = p.D > 0 ? p.D : 64;
     const int vt_heads = p.vt_batch_heads > 0 ? p.vt_batch_heads : p.H;
 
@@ -272,11 +285,13 @@ int launch_fwd(const slh_attn_desc* d, hipStream_t s) {
     const long blocks4 = (long)((d->Tq + 127) / 128) * d->H * d->B;
     const bool tail = (d->Tk & 63) != 0;
     if (blocks4 >= 256) {
-        if (tail) hipLaunchKernelGGL((attn_fwd_kernel<4, DT, true>), dim3((d->Tq + 127) / 128, d->H, d->B), dim3(256), 0, s, *d);
-        else hipLaunchKernelGGL((attn_fwd_kernel<4, DT, false>), dim3((d->Tq + 127) / 128, d->H, d->B), dim3(256), 0, s, *d);
+        const dim3 grid((unsigned)blocks4);
+        if (tail) hipLaunchKernelGGL((attn_fwd_kernel<4, DT, true>), grid, dim3(256), 0, s, *d);
+        else hipLaunchKernelGGL((attn_fwd_kernel<4, DT, false>), grid, dim3(256), 0, s, *d);
     } else {
-        if (tail) hipLaunchKernelGGL((attn_fwd_kernel<2, DT, true>), dim3((d->Tq + 63) / 64, d->H, d->B), dim3(128), 0, s, *d);
-        else hipLaunchKernelGGL((attn_fwd_kernel<2, DT, false>), dim3((d->Tq + 63) / 64, d->H, d->B), dim3(128), 0, s, *d);
+        const dim3 grid((unsigned)((long)((d->Tq + 63) / 64) * d->H * d->B));
+        if (tail) hipLaunchKernelGGL((attn_fwd_kernel<2, DT, true>), grid, dim3(128), 0, s, *d);
+        else hipLaunchKernelGGL((attn_fwd_kernel<2, DT, false>), grid, dim3(128), 0, s, *d);
     }
     SLH_LAUNCH_CHECK("slh_attn_fwd");
     return 0;

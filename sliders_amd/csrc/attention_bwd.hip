@@ -51,6 +51,15 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const slh_attn_bwd_desc
     p.delta[((long)b * p.H + h) * p.Tq + q] = s;
 }
 
+// XCD-aware block order shared by the backward kernels (see attn_fwd_kernel): virtual block id whose consecutive values
+// (same head, next 128-row block) land on the same XCD's L2
+__device__ __forceinline__ int xcd_virtual_block() {
+    const int vb = blockIdx.x, nblk = gridDim.x;
+    const int qd = nblk >> 3, rm = nblk & 7;
+    const int xcd = vb & 7, idx = vb >> 3;
+    return (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + idx;
+}
+
 // ---- dQ ------------------------------------------------------------------------------------------------
 template <int DT>
 __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const slh_attn_bwd_desc p) {
@@ -62,8 +71,10 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const slh_attn_bwd_des
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lrow = lane & 31, lhi = lane >> 5;
     const int frow = lane >> 3, fslot = lane & 7;
-    const int h = blockIdx.y, b = blockIdx.z;
-    const int q0 = blockIdx.x * 128 + wave * 32;
+    const int vb = xcd_virtual_block();
+    const int nqb = (p.Tq + 127) / 128;
+    const int h = (vb / nqb) % p.H, b = vb / (nqb * p.H);
+    const int q0 = (vb % nqb) * 128 + wave * 32;
     const int D = p.D > 0 ? p.D : 64;
     const __bf16* K = (const __bf16*)p.k;
     const __bf16* V = (const __bf16*)p.v;
@@ -178,8 +189,10 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const slh_attn_bwd_de
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lrow = lane & 31, lhi = lane >> 5;
     const int frow = lane >> 3, fslot = lane & 7;
-    const int h = blockIdx.y, b = blockIdx.z;
-    const int k0 = blockIdx.x * 128 + wave * 32;
+    const int vb = xcd_virtual_block();
+    const int nkb = (p.Tk + 127) / 128;
+    const int h = (vb / nkb) % p.H, b = vb / (nkb * p.H);
+    const int k0 = (vb % nkb) * 128 + wave * 32;
     const int D = p.D > 0 ? p.D : 64;
     const __bf16* Q = (const __bf16*)p.q;
     const __bf16* G = (const __bf16*)p.d_o;
@@ -317,7 +330,7 @@ extern "C" int slh_attn_bwd(const slh_attn_bwd_desc* d, slh_stream_t stream) {
     const int DT = (D + 63) / 64;
     const long total = (long)d->B * d->Tq * d->H;
     hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, *d, D);
-    const dim3 gq((d->Tq + 127) / 128, d->H, d->B);
+    const dim3 gq((unsigned)((long)((d->Tq + 127) / 128) * d->H * d->B));
     if (DT == 1) hipLaunchKernelGGL(attn_bwd_dq_kernel<1>, gq, dim3(256), 0, s, *d);
     else if (DT == 2) hipLaunchKernelGGL(attn_bwd_dq_kernel<2>, gq, dim3(256), 0, s, *d);
     else hipLaunchKernelGGL(attn_bwd_dq_kernel<3>, gq, dim3(256), 0, s, *d);
@@ -325,7 +338,7 @@ extern "C" int slh_attn_bwd(const slh_attn_bwd_desc* d, slh_stream_t stream) {
         SLH_CHECK(d->qt && d->dot && d->dk && d->dv, "slh_attn_bwd: dK/dV need qt, dot, dk, dv");
         SLH_CHECK(d->ldqt % 64 == 0 && d->ldqt >= ((d->Tq + 63) / 64) * 64 && d->lddk % 4 == 0 && d->lddv % 4 == 0,
                   "slh_attn_bwd: QT/dOT padding");
-        const dim3 gk((d->Tk + 127) / 128, d->H, d->B);
+        const dim3 gk((unsigned)((long)((d->Tk + 127) / 128) * d->H * d->B));
         if (DT == 1) hipLaunchKernelGGL((attn_bwd_dkv_kernel<1, 2>), gk, dim3(256), 0, s, *d);
         else if (DT == 2) hipLaunchKernelGGL((attn_bwd_dkv_kernel<2, 2>), gk, dim3(256), 0, s, *d);
         else hipLaunchKernelGGL((attn_bwd_dkv_kernel<3, 1>), gk, dim3(256), 0, s, *d);

@@ -23,6 +23,7 @@ from sliders_amd import prompt_util, train_util
 from sliders_amd.config import CONFIGS
 from sliders_amd.lora_store import LoraStore
 from sliders_amd.trainer import PairEmbeds, SliderTrainer
+from tests.util import rel_err
 from sliders_amd.unet import UNetEngine
 from tests.util import rel_err
 
@@ -132,15 +133,40 @@ def test_reference_shaped_loop_equals_fused_iteration(dev, tmp_path, name, actio
     print(f"[seam] {name}: denoised rel_l2 {r_den:.3e}, target eps rel_l2 {r_tgt:.3e}, loss {loss.item():.5e} vs fused "
           f"{loss_b.item():.5e}, grad cosine {cos:.6f}, |g| {grad_a.norm():.3e} vs {grad_b.norm():.3e}, "
           f"update sign agreement {agree:.4f}, max |dparam| {dpa.abs().max():.2e} / {dpb.abs().max():.2e}")
-    # both paths run the same kernels per UNet pass; they differ in where the bf16 roundings of the glue sit (torch ops
-    # vs fused kernels), in the de-duplicated frozen pass and in the fp32 atomics order of GroupNorm statistics.  The
-    # run-to-run floor of ONE path is already rel_l2 ~7e-3 on the denoised latents / cosine ~0.993 on the gradient
-    # (tests/test_rccl_gpu.py prints it), so the bounds are 1.5 x that floor
-    assert r_den < 1.2e-2 and r_tgt < 2.0e-2
-    # two runs of the SAME iteration differ by up to ~5 % in the loss (a difference of four predictions that each carry the
-    # engine's run-to-run floor - GroupNorm statistics are fp32 atomics); measured spread of this comparison: 0.3 - 4.6 %
-    assert abs(loss.item() - loss_b.item()) < 0.08 * abs(loss_b.item())
-    assert cos > 0.97          # measured 0.9945 (tiny_sdxl), 0.979 (tiny_sd1) against a run-to-run floor of 0.993
+    # both paths replay the same command buffers on the same inputs and the engine is bit-reproducible (round 3: fixed-order
+    # reductions), so the denoised latents and the target prediction are EQUAL; what differs is the glue around them - the
+    # loss and its gradient computed by torch bf16 ops here vs the fused fp32 kernel, three frozen CFG pairs vs the
+    # de-duplicated B=3 pass (measured: loss 0.16 - 0.31 % apart, gradient cosine 1.0000)
+    assert r_den == 0.0 and r_tgt == 0.0
+    assert abs(loss.item() - loss_b.item()) < 0.01 * abs(loss_b.item())
+    assert cos > 0.9995
     assert agree > 0.85
-    assert abs(grad_a.norm().item() / grad_b.norm().item() - 1.0) < 0.08
+    assert abs(grad_a.norm().item() / grad_b.norm().item() - 1.0) < 0.01
     assert 0 < dpa.abs().max() < 5e-4
+
+
+def test_integration_md_c_abi_stub_runs_as_written(dev):
+    """the ctypes stub a maintainer of the reference would write, executed VERBATIM from the
+    document (so the documented struct cannot drift from include/sliders_hip.h): one fused LoRAModule.forward launch."""
+    import ctypes as C
+    import math
+    import os
+    import re
+    from sliders_amd import lib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, "INTEGRATION.md")).read()
+    block = next(b for b in re.findall(r"```python\n(.*?)```", text, re.S) if "class GemmDesc(C.Structure)" in b)
+    block = block.replace('C.CDLL("sliders_amd/libsliders_hip.so")', f'C.CDLL("{lib.LIB_PATH}")')
+    torch.manual_seed(0)
+    M, N, K = 200, 192, 256
+    bf = lambda t: t.to(device=dev, dtype=torch.bfloat16).contiguous()
+    ns = dict(x=bf(torch.randn(M, K)), W=bf(torch.randn(N, K) / math.sqrt(K)), b=bf(torch.randn(N)),
+              y=torch.zeros(M, N, device=dev, dtype=torch.bfloat16), A=bf(torch.randn(4, K) / math.sqrt(K)),
+              B=bf(torch.randn(N, 4)), s=torch.tensor([0.25], device=dev), M=M, N=N, K=K)
+    lib.load()
+    exec(block, ns)
+    torch.cuda.synchronize()
+    assert C.sizeof(ns["GemmDesc"]) == C.sizeof(lib.GemmDesc)
+    x, W, b, A, B = (ns[k].float() for k in ("x", "W", "b", "A", "B"))
+    ref = x @ W.t() + b + 0.25 * (x @ A.t()).to(torch.bfloat16).float() @ B.t()
+    assert rel_err(ns["y"].float().cpu(), ref.cpu()) < 6e-3

@@ -94,14 +94,13 @@ def test_iteration_matches_reference_loop_on_oracle(dev, name, action, pred):
     cos = F.cosine_similarity(store.grads.cpu(), flat, dim=0).item()
     print(f"[parity] iteration: denoised rel_l2={r_den:.3e} target-eps rel_l2={r_tgt:.3e} loss {loss.item():.5e} vs "
           f"{ref_loss.item():.5e} grad cosine {cos:.5f} |g| {store.grads.norm().item():.3e} vs {flat.norm().item():.3e}")
-    # 1.3 x the worst values measured on MI355X over the cases and several runs (denoised 6.5e-3, target 1.31e-2,
-    # loss within 4.8 %, gradient cosine 0.9857-0.9959; the run-to-run floor of the engine itself is cosine 0.993 and the
-    # loss, a difference of four predictions, moves by 1-3 % between two runs of the same inputs)
+    # engine (bf16 chain, k denoise steps) vs the reference loop on the fp32 oracle.  The engine is bit-reproducible since
+    # round 3, so these are fixed numbers, not samples: denoised 6.2e-3 - 7.6e-3, target eps 1.0e-2 - 1.5e-2 (the
+    # torch-bf16 arm of a SINGLE pass already sits at 1.0e-2 - 1.5e-2 on these nets, tests/test_unet_gpu.py), loss within
+    # 0.6 % / 4.0 % / 6.3 % (a difference of four such predictions), gradient cosine 0.9966 / 0.9844 / 0.9849
     assert r_den < 1.0e-2 and r_tgt < 2.0e-2
-    # (the SD-2.x-like net measured 6.2 %: its predictions sit at rel-L2 1.2-1.5e-2 like its torch-bf16 arm, and the loss is a
-    # difference of four of them)
     assert abs(loss.item() - ref_loss.item()) < 0.08 * ref_loss.item()
-    assert cos > 0.97          # measured 0.983 - 0.996 over cases and runs
+    assert cos > 0.975
     # AdamW moved every trainable parameter by about lr (first step: |update| ~ lr)
     delta = (store.params.float() - params0.float()).abs()
     assert delta.max().item() < 5e-4 and delta.max().item() > 0

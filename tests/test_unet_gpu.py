@@ -7,7 +7,8 @@ resolution of the output itself (ulp(0.5) = 2e-3) and below the error of the ref
 the oracle run in torch bf16 (the reference's precision) differs from the fp32 oracle by rel-L2 ~1e-2 on these
 nets.  The test therefore measures BOTH arms against the fp32 oracle and requires
     rel_l2(engine, fp32) <= rel_l2(torch_bf16, fp32) + 3e-4          (3e-4 = run-to-run noise of either arm)
-    max|engine - fp32|   <= 2.8e-2                                    (1.3 x the largest value measured on MI355X)
+    max|engine - fp32|   <= max(1.5 x the bf16 arm's max error, 6 sigma of its rel-L2)   (a tail statistic: bounded
+                            relative to the same statistic of the reference-precision arm, not to one earlier sample)
 i.e. the HIP path is at least as close to exact arithmetic as the reference's own bf16 path (it is closer in
 every measured case: fused epilogues round once where the reference rounds per op).
 """
@@ -55,7 +56,9 @@ def check(name, got, e32, ebf):
           f" | torch-bf16 arm rel_l2={r_ref:.3e} max_abs={(ebf - e32).abs().max():.3e} | eps rms={e32.pow(2).mean().sqrt():.3f}")
     assert torch.isfinite(got).all()
     assert r_eng <= r_ref + 3e-4, f"{name}: engine error {r_eng:.3e} vs reference-precision arm {r_ref:.3e}"
-    assert (got - e32).abs().max().item() <= 2.8e-2, f"{name}: max abs error {(got - e32).abs().max().item():.3e}"
+    rms = e32.pow(2).mean().sqrt().item()
+    m_eng, m_ref = (got - e32).abs().max().item(), (ebf - e32).abs().max().item()
+    assert m_eng <= max(1.5 * m_ref, 6.0 * r_ref * rms), f"{name}: max abs error {m_eng:.3e} vs the bf16 arm's {m_ref:.3e}"
 
 
 @pytest.mark.parametrize("name,hw", [("tiny_sdxl", 16), ("tiny_sd1", 16), ("tiny_sdxl", 24), ("tiny_sd2", 16)])

@@ -209,8 +209,8 @@ def test_image_slider_iteration_matches_reference_loop_on_oracle(dev):
     cos = F.cosine_similarity(store.grads.cpu(), flat, dim=0).item()
     print(f"[parity] image-slider iteration: loss high {lh.item():.5e} vs {losses[0]:.5e}, low {ll.item():.5e} vs {losses[1]:.5e}, "
           f"grad cosine {cos:.5f} |g| {store.grads.norm().item():.3e} vs {flat.norm().item():.3e}")
-    assert abs(lh.item() - losses[0]) < 0.04 * losses[0] and abs(ll.item() - losses[1]) < 0.04 * losses[1]
-    assert cos > 0.99           # measured 0.9976; the run-to-run floor of the engine is ~0.993-0.999
+    assert abs(lh.item() - losses[0]) < 0.01 * losses[0] and abs(ll.item() - losses[1]) < 0.01 * losses[1]   # measured 0.02 %
+    assert cos > 0.995          # measured 0.9976 (a fixed number: the engine is bit-reproducible since round 3)
     delta = (store.params.float() - params0.float()).abs()
     assert 0 < delta.max().item() < 5e-4
 
