@@ -44,7 +44,7 @@ def build_parser() -> argparse.ArgumentParser:
     p.add_argument("--folders", type=str, required=False, default="verylow, low, high, veryhigh",
                    help="folders with different attribute-scaled images")
     p.add_argument("--scales", type=str, required=False, default="-2, -1, 1, 2", help="scales for different attribute-scaled images")
-    p.add_argument("--synthetic", action="store_true", help="random-init weights, embeddings and images (no files)")
+    p.add_argument("--synthetic", action="store_true", help="random-init weights and embeddings (no model files); random images too unless the folders exist")
     p.add_argument("--seed", type=int, default=0)
     return p
 
@@ -119,11 +119,13 @@ def train(config, prompts, device: int, xl: bool, folder_main: str, folders, sca
     pyrng = random.Random(seed * 7919 + rank)              # image / scale choice is rank-local (different data per rank)
     save_path = Path(config.save.path)
     dtype = config_util.parse_precision(config.train.precision)
+    # --synthetic replaces the model files; image folders are still read when they exist (random images otherwise)
+    have_image_files = all(os.path.isdir(f"{folder_main}/{f}") and list_images(f"{folder_main}/{f}/") for f in folders)
     for i in range(config.train.iterations):
         k, pi = samp.next()
         s, pair = pairs[pi]
         scale_to_look = abs(pyrng.choice(list(scales)))
-        if synthetic:
+        if synthetic and not have_image_files:
             g = torch.Generator().manual_seed(pyrng.randrange(1 << 30))
             img_low = VaeEncoder.preprocess(torch.randint(0, 256, (size, size, 3), generator=g, dtype=torch.uint8))
             img_high = VaeEncoder.preprocess(torch.randint(0, 256, (size, size, 3), generator=g, dtype=torch.uint8))

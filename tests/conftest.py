@@ -39,7 +39,7 @@ def _cpu_threads():
 # The driver runs `pytest -m gpu -x`: one failure hides every test collected after it.  Cheap, row-specific tests therefore
 # run first and the tests that build multi-GB fp32 oracles last (round 2: a flaky bound in the first heavy file kept the
 # whole VAE / image-slider / sampler file from running).
-_GPU_ORDER = ["test_kernels_gpu", "test_graph_gpu", "test_vae_gpu", "test_schedulers_gpu", "test_loader_gpu", "test_trainer_gpu",
+_GPU_ORDER = ["test_kernels_gpu", "test_graph_gpu", "test_vae_gpu", "test_schedulers_gpu", "test_loader_gpu", "test_trainer_gpu", "test_cli_gpu",
               "test_seam_gpu", "test_rccl_gpu", "test_backward_gpu", "test_unet_gpu", "test_bench_config_gpu"]
 
 

@@ -1,0 +1,116 @@
+"""GPU: the reference's entry points end to end on synthetic weights (`--synthetic`: seeded random-init UNet / VAE with the
+real shapes and seeded text embeddings - there are no checkpoints offline): YAML -> prompt pairs -> training loop ->
+checkpoint file with the reference's key layout.  trainscripts/textsliders/train_lora.py:155-309,
+trainscripts/imagesliders/train_lora-scale.py."""
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+CONFIG = """prompts_file: "{prompts}"
+pretrained_model:
+  name_or_path: "CompVis/stable-diffusion-v1-4"
+  v2: false
+  v_pred: false
+network:
+  type: "c3lier"
+  rank: 4
+  alpha: 1.0
+  training_method: "noxattn"
+train:
+  precision: "bfloat16"
+  noise_scheduler: "{sched}"
+  iterations: {iters}
+  lr: 0.0002
+  optimizer: "{opt}"
+  lr_scheduler: "{lrs}"
+  max_denoising_steps: 50
+save:
+  name: "{name}"
+  path: "{out}"
+  per_steps: 500
+  precision: "bfloat16"
+logging:
+  use_wandb: false
+  verbose: false
+other:
+  use_xformers: true
+"""
+PROMPTS = """- target: "person"
+  positive: "person, smiling"
+  unconditional: "person, frowning"
+  neutral: "person"
+  action: "enhance"
+  guidance_scale: 4
+  resolution: 256
+  dynamic_resolution: {dyn}
+  batch_size: 1
+- target: "dog"
+  positive: "dog, fluffy"
+  unconditional: "dog, shaved"
+  neutral: "dog"
+  action: "erase"
+  guidance_scale: 2
+  resolution: 256
+  dynamic_resolution: false
+  batch_size: 1
+"""
+
+
+def _run(script, args, tmp_path, timeout=500):
+    r = subprocess.run([sys.executable, os.path.join(ROOT, script)] + args, cwd=ROOT, capture_output=True, text=True, timeout=timeout,
+                       env=dict(os.environ, PYTHONPATH=ROOT))
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    return r
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("sched,opt,lrs,dyn", [("ddim", "AdamW", "constant", "true"), ("euler_a", "lion", "cosine", "false")])
+def test_text_slider_cli_end_to_end(dev, tmp_path, sched, opt, lrs, dyn):
+    """train_lora.py on the SD-1.x architecture: two prompt pairs (enhance / erase), dynamic_resolution on one of them (a new
+    (H, W) bucket almost every iteration: the plan cache and the zero-init arena are exercised the way a real run does),
+    a non-default scheduler / optimizer / LR schedule in the second case; the saved file has the reference's keys."""
+    prompts = tmp_path / "prompts.yaml"
+    prompts.write_text(PROMPTS.format(dyn=dyn))
+    cfg = tmp_path / "config.yaml"
+    cfg.write_text(CONFIG.format(prompts=prompts, sched=sched, iters=6, opt=opt, lrs=lrs, name="cli", out=tmp_path / "models"))
+    _run("trainscripts/textsliders/train_lora.py", ["--config_file", str(cfg), "--synthetic", "--name", "clitest"], tmp_path)
+    files = [os.path.join(dp, f) for dp, _, fs in os.walk(tmp_path / "models") for f in fs if f.endswith(".pt")]
+    assert files, "no checkpoint written"
+    sd = torch.load(files[0], map_location="cpu")
+    from sliders_amd.config import CONFIGS
+    from sliders_amd.lora_store import LoraStore
+    ref = LoraStore(CONFIGS["sd1"](), rank=4, alpha=1.0, train_method="noxattn", init="none").state_dict()
+    assert list(sd.keys()) == list(ref.keys())
+    assert all(sd[k].shape == ref[k].shape for k in ref)
+    ups = [v.float() for k, v in sd.items() if k.endswith("lora_up.weight")]
+    assert all(torch.isfinite(u).all() for u in ups) and any(float(u.abs().max()) > 0 for u in ups), "the adapters did not train"
+
+
+@pytest.mark.timeout(600)
+def test_image_slider_cli_end_to_end(dev, tmp_path):
+    """train_lora-scale.py (SD-1.x image sliders, 256x256 pairs): folders of before / after images, VAE encode on the GPU,
+    +scale / -scale predictions, two backward passes per step."""
+    from PIL import Image
+    import numpy as np
+    rng = np.random.default_rng(0)
+    for folder in ("low", "high"):
+        os.makedirs(tmp_path / "imgs" / folder)
+        for i in range(2):
+            Image.fromarray(rng.integers(0, 256, (300, 280, 3), dtype=np.uint8)).save(tmp_path / "imgs" / folder / f"im{i}.png")
+    prompts = tmp_path / "prompts.yaml"
+    prompts.write_text(PROMPTS.format(dyn="false"))
+    cfg = tmp_path / "config.yaml"
+    cfg.write_text(CONFIG.format(prompts=prompts, sched="ddim", iters=4, opt="AdamW", lrs="constant", name="img", out=tmp_path / "models"))
+    _run("trainscripts/imagesliders/train_lora-scale.py",
+         ["--config_file", str(cfg), "--synthetic", "--alpha", "1.0", "--name", "imgtest", "--folder_main", str(tmp_path / "imgs"),
+          "--folders", "low, high", "--scales", "-1, 1"], tmp_path)
+    files = [os.path.join(dp, f) for dp, _, fs in os.walk(tmp_path / "models") for f in fs if f.endswith(".pt")]
+    assert files, "no checkpoint written"
+    sd = torch.load(files[0], map_location="cpu")
+    assert any(k.endswith("lora_up.weight") and float(v.float().abs().max()) > 0 for k, v in sd.items())
