@@ -129,8 +129,8 @@ def measure_roofline(eng, plan):
                 acc["conv3x3"]["ms"] += ms; acc["conv3x3"]["work"] += nbytes; acc["conv3x3"]["n"] += 1
         elif opcode == lib.OP_ATTN_FWD:
             acc["attention"]["ms"] += ms; acc["attention"]["work"] += 4.0 * d.B * d.H * d.Tq * d.Tk * (d.D or 64); acc["attention"]["n"] += 1
-        elif opcode in (lib.OP_GN_STATS, lib.OP_GN_APPLY):
-            if opcode == lib.OP_GN_APPLY:          # one read + one write of the tensor for the stats/apply pair
+        elif opcode in (lib.OP_GN_STATS, lib.OP_GN_APPLY, lib.OP_GN_FUSED):
+            if opcode != lib.OP_GN_STATS:          # one read + one write of the tensor for the stats/apply pair (or the fused launch)
                 acc["groupnorm"]["work"] += 2.0 * 2.0 * d.batch * d.hw * (d.c0 + d.c1); acc["groupnorm"]["n"] += 1
             acc["groupnorm"]["ms"] += ms
         elif opcode == lib.OP_LAYERNORM:

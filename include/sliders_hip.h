@@ -182,6 +182,11 @@ int slh_gn_apply(const slh_gn_desc* d, slh_stream_t stream);
 /* workgroups per sample of slh_gn_stats / slh_gn_bwd_stats, and the clusters they form; -1 for an unsupported shape */
 int slh_gn_row_blocks(int channels, int hw, int groups);
 int slh_gn_clusters(int row_blocks);
+/* Tiny tensors (8x8 latents: a sample's group slab is a few KB): statistics AND normalisation in one launch, one read
+ * of x; also writes stats for the backward.  partial / ticket unused.  (Measured: loses at 32x32, ties at 16x16.)
+ * slh_gn_fused_ok(channels, hw, groups) = 1 where it applies. */
+int slh_gn_fused_ok(int channels, int hw, int groups);
+int slh_gn_fused(const slh_gn_desc* d, slh_stream_t stream);
 
 /* GroupNorm backward (dx only: gamma/beta are frozen).  Two launches like the forward:
  * bwd_stats reduces per (b,g) sum(dyhat) and sum(dyhat*xhat) into bstats (fixed order, see slh_gn_desc),
@@ -501,7 +506,7 @@ enum {
     SLH_OP_LAYERNORM_BWD = 18, SLH_OP_ATTN_BWD = 19, SLH_OP_MEMSET = 20, SLH_OP_LORA_CONV_DGRAD = 21,
     SLH_OP_TEMB_LORA_BWD = 22, SLH_OP_SGEMM = 23, SLH_OP_GN32_STATS = 24, SLH_OP_GN32_APPLY = 25, SLH_OP_SOFTMAX32 = 26,
     SLH_OP_VAE_CONV_IN = 27, SLH_OP_VAE_MOMENTS = 28, SLH_OP_VAE_SAMPLE = 29, SLH_OP_VAE_POST_QUANT = 30, SLH_OP_LION = 31,
-    SLH_OP_WGRAD_BATCH = 32, SLH_OP_TRANSPOSE_BATCH = 33, SLH_OP_GATHER16 = 34
+    SLH_OP_WGRAD_BATCH = 32, SLH_OP_TRANSPOSE_BATCH = 33, SLH_OP_GATHER16 = 34, SLH_OP_GN_FUSED = 35
 };
 typedef struct slh_memset_desc { void* ptr; int64_t nbytes; int32_t value; int32_t pad; } slh_memset_desc;
 int slh_run_program(const void* program, int64_t nbytes, slh_stream_t stream);

@@ -115,6 +115,20 @@ __global__ __launch_bounds__(64 * NW, DT == 1 ? (NW == 4 ? ATTN_OCC41 : 3) : ((D
         const char* cK = sK + (t & 1) * DT * 8192;
         const char* cV = sV + (t & 1) * DT * 8192;
         f32x16 s[2];
+#ifndef SLH_ATTN_GROUPED
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    const bf16x8 kf = *(const bf16x8*)(cK + dt * 8192 + lds_off(kt * 32 + prow, ks * 2 + lhi));
+                    // first product of the tile takes a literal-zero C operand instead of 16 zeroed registers
+                    if (dt == 0 && ks == 0) s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[0], kZero16, 0, 0, 0);
+                    else s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[dt * 4 + ks], s[kt], 0, 0, 0);
+                }
+        }
+#else
         // all K fragments of a 32-key half are requested before its first MFMA (hipcc otherwise emits read -> wait -> MFMA
         // eight times per tile: ~100 cycles of LDS latency exposed in front of every 32-cycle MFMA); with D <= 64 both
         // halves' reads go out before any MFMA
@@ -134,9 +148,6 @@ __global__ __launch_bounds__(64 * NW, DT == 1 ? (NW == 4 ? ATTN_OCC41 : 3) : ((D
                 else s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[kt][i], qf[i], s[kt], 0, 0, 0);
             }
         };
-#ifndef SLH_ATTN_GROUPED
-        read_k(0); mma_k(0); read_k(1); mma_k(1);
-#else
         read_k(0);
         if (DT == 1) read_k(1);
         __builtin_amdgcn_sched_barrier(0);
@@ -189,6 +200,15 @@ __global__ __launch_bounds__(64 * NW, DT == 1 ? (NW == 4 ? ATTN_OCC41 : 3) : ((D
 #pragma unroll
                 for (int r = 0; r < 16; ++r) o[dd][r] *= alpha;
         }
+#ifndef SLH_ATTN_GROUPED
+#pragma unroll
+        for (int dd = 0; dd < 2 * DT; ++dd)
+#pragma unroll
+            for (int kstep = 0; kstep < 4; ++kstep) {
+                const bf16x8 vf = *(const bf16x8*)(cV + (dd >> 1) * 8192 + lds_off((dd & 1) * 32 + lrow, kstep * 2 + lhi));
+                o[dd] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pb[kstep >> 1][kstep & 1], o[dd], 0, 0, 0);
+            }
+#else
         // same for V: the four fragments of a 32-wide d block are requested together, the next block's before this block's MFMAs
         bf16x8 vf[2][4];
         auto read_v = [&](const int set, const int dd) {
@@ -200,13 +220,12 @@ __global__ __launch_bounds__(64 * NW, DT == 1 ? (NW == 4 ? ATTN_OCC41 : 3) : ((D
 #pragma unroll
         for (int dd = 0; dd < 2 * DT; ++dd) {
             if (dd + 1 < 2 * DT) read_v((dd + 1) & 1, dd + 1);
-#ifdef SLH_ATTN_GROUPED
             __builtin_amdgcn_sched_barrier(0);
-#endif
 #pragma unroll
             for (int kstep = 0; kstep < 4; ++kstep)
                 o[dd] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[dd & 1][kstep], pb[kstep >> 1][kstep & 1], o[dd], 0, 0, 0);
         }
+#endif
     }
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
     const float inv = 1.f / l_tot;

@@ -53,7 +53,7 @@ __global__ void gn_stats_kernel(const slh_gn_desc d, int nchunk, int rpi, int ro
         const int ga = c / cg, gb = (c + 7) / cg;
         const float ka = (float)*gn_src(d, (long)b * d.hw, ga * cg), kb = (float)*gn_src(d, (long)b * d.hw, gb * cg);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) ks[e] = (c + e) / cg == ga ? ka : kb;
+        for (int e = 0; e < 8; ++e) ks[e] = (c + e) < (ga + 1) * cg ? ka : kb;
     } else {
 #pragma unroll
         for (int e = 0; e < 8; ++e) ks[e] = (float)*gn_src(d, (long)b * d.hw, ((c + e) / cg) * cg);
@@ -62,19 +62,19 @@ __global__ void gn_stats_kernel(const slh_gn_desc d, int nchunk, int rpi, int ro
     for (int e = 0; e < 8; ++e) { s[e] = 0.f; q[e] = 0.f; }
     {
         // all of the thread's rows are requested before the first one is used (HBM latency paid once, not GN_ITERS times)
+        // (unconditional loads at clamped rows + a select: a load behind `if (r < r1)` makes hipcc branch around it and wait
+        // vmcnt(0) at every join - the loads then complete one by one, cdna_hip_programming.md section 5 trap 4c)
         bf16x8 v[GN_ITERS];
 #pragma unroll
         for (int it = 0; it < GN_ITERS; ++it) {
-            const int r = r0 + rl + it * rpi;
-            if (r < r1) v[it] = *(const bf16x8*)gn_src(d, (long)b * d.hw + r, c);
+            const int r = min(r0 + rl + it * rpi, d.hw - 1);
+            v[it] = *(const bf16x8*)gn_src(d, (long)b * d.hw + r, c);
         }
 #pragma unroll
         for (int it = 0; it < GN_ITERS; ++it) {
-            const int r = r0 + rl + it * rpi;
-            if (r < r1) {
+            const float w = (r0 + rl + it * rpi) < r1 ? 1.f : 0.f;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) { const float f = (float)v[it][e] - ks[e]; s[e] += f; q[e] += f * f; }
-            }
+            for (int e = 0; e < 8; ++e) { const float f = ((float)v[it][e] - ks[e]) * w; s[e] += f; q[e] += f * f; }
         }
     }
     float S, Q;
@@ -115,8 +115,8 @@ __global__ void gn_apply_kernel(const slh_gn_desc d, int nchunk, int rpi, int ro
     bf16x8 v[GN_ITERS];
 #pragma unroll
     for (int it = 0; it < GN_ITERS; ++it) {
-        const int r = r0 + rl + it * rpi;
-        if (r < r1) v[it] = *(const bf16x8*)gn_src(d, (long)b * d.hw + r, c);
+        const int r = min(r0 + rl + it * rpi, d.hw - 1);       // unconditional (see gn_stats_kernel)
+        v[it] = *(const bf16x8*)gn_src(d, (long)b * d.hw + r, c);
     }
 #pragma unroll
     for (int it = 0; it < GN_ITERS; ++it) {
@@ -131,6 +131,125 @@ __global__ void gn_apply_kernel(const slh_gn_desc d, int nchunk, int rpi, int ro
             o[e] = (__bf16)y;
         }
         *(bf16x8*)((__bf16*)d.y + row * d.ldy + c) = o;
+    }
+}
+
+// ---- tiny tensors: statistics + normalisation in ONE launch -----------------------------------------------------
+// At 8x8 a (sample, group) slab is a few KB: one workgroup owns `gq` adjacent groups of one sample (gq * cg a
+// multiple of 8 channels, so its rows are whole 16-byte chunks), keeps its slab in registers, reduces the statistics in a
+// fixed order (shifted sums -> wave tree -> LDS) and writes the normalised rows - one read of x, no partials, no tickets,
+// no second launch (the two-launch form costs ~9 + 6 us + a boundary on these shapes, all of it latency).
+constexpr int GNF_ITEMS = 3;           // 16-byte chunks per thread.  Measured (scripts/probe_gn.py): the one-launch form wins only
+                                       // while a thread holds <= 3 chunks (8x8 latents: 8-10 us against 6.5 + 6.3 + a boundary);
+                                       // at 16x16 it ties and at 32x32 it LOSES 2.5x (41 us vs 8 + 7): 16-64 workgroups then carry
+                                       // all of the SiLU / select arithmetic that the two-launch form spreads over the chip
+constexpr int GNF_MAXG = 4;            // groups per workgroup
+
+struct GnFusedGeom { int gq, nch, items; bool ok; };
+__host__ __device__ inline GnFusedGeom gn_fused_geom(int C, int hw, int groups) {
+    GnFusedGeom g;
+    const int cg = C / groups;
+    g.gq = 1;
+    while (g.gq <= GNF_MAXG && (g.gq * cg) % 8) g.gq *= 2;
+    g.nch = g.gq * cg / 8;
+    g.items = (hw * g.nch + 255) / 256;
+    g.ok = g.gq <= GNF_MAXG && groups % g.gq == 0 && g.items <= GNF_ITEMS && hw * g.nch >= 64;
+    return g;
+}
+
+// r = idx / nch as (idx * magic) >> 32 with magic = ceil(2^32 / nch) (64-bit: it is 2^32 for nch = 1): exact for idx * nch < 2^32;
+// group of channel x inside the workgroup's <= 4 groups by comparison - both replace ~30-instruction integer divisions
+// that made this kernel 5x slower than its memory traffic (8 + 8 + 1 of them per 16-byte chunk)
+__device__ __forceinline__ int gnf_div(int idx, unsigned long long magic) { return (int)(((unsigned long long)(unsigned)idx * magic) >> 32); }
+__device__ __forceinline__ int gnf_group(int x, int cg) { return (x >= cg) + (x >= 2 * cg) + (x >= 3 * cg); }
+
+__global__ __launch_bounds__(256) void gn_fused_kernel(const slh_gn_desc d, int cg, int gq, int nch, unsigned long long magic) {
+    __shared__ float red[4][2 * GNF_MAXG];
+    __shared__ float fin[2 * GNF_MAXG];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.y;
+    const int c_base = blockIdx.x * gq * cg;                 // first channel of this workgroup (a multiple of 8)
+    const int total = d.hw * nch;
+    // shifts: the first element of each local group (row 0 of the sample)
+    float ks[GNF_MAXG];
+#pragma unroll
+    for (int g = 0; g < GNF_MAXG; ++g) ks[g] = g < gq ? (float)*gn_src(d, (long)b * d.hw, c_base + g * cg) : 0.f;
+    bf16x8 v[GNF_ITEMS];
+#pragma unroll
+    for (int it = 0; it < GNF_ITEMS; ++it) {
+        if (it * 256 < total) {                                 // uniform over the workgroup: no per-lane branch around the load
+            const int idx = min(tid + it * 256, total - 1);
+            const int r = gnf_div(idx, magic), ch = idx - r * nch;
+            v[it] = *(const bf16x8*)gn_src(d, (long)b * d.hw + r, c_base + ch * 8);
+        }
+    }
+    float s[GNF_MAXG], q[GNF_MAXG];
+#pragma unroll
+    for (int g = 0; g < GNF_MAXG; ++g) { s[g] = 0.f; q[g] = 0.f; }
+#pragma unroll
+    for (int it = 0; it < GNF_ITEMS; ++it) {
+        const int idx = tid + it * 256;
+        if (it * 256 < total) {
+            const int ic = min(idx, total - 1);
+            const int ch = ic - gnf_div(ic, magic) * nch;
+            const float w = idx < total ? 1.f : 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int g = gnf_group(ch * 8 + e, cg);
+#pragma unroll
+                for (int gg = 0; gg < GNF_MAXG; ++gg) {
+                    const float f = gg == g ? ((float)v[it][e] - ks[gg]) * w : 0.f;
+                    s[gg] += f; q[gg] += f * f;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int g = 0; g < GNF_MAXG; ++g) { s[g] = wave_sum(s[g]); q[g] = wave_sum(q[g]); }
+    if (lane == 0) {
+#pragma unroll
+        for (int g = 0; g < GNF_MAXG; ++g) { red[wave][2 * g] = s[g]; red[wave][2 * g + 1] = q[g]; }
+    }
+    __syncthreads();
+    if (tid < gq) {
+        const double S = ((double)red[0][2 * tid] + (double)red[1][2 * tid]) + ((double)red[2][2 * tid] + (double)red[3][2 * tid]);
+        const double Q = ((double)red[0][2 * tid + 1] + (double)red[1][2 * tid + 1]) + ((double)red[2][2 * tid + 1] + (double)red[3][2 * tid + 1]);
+        const double n = (double)d.hw * (double)cg;
+        const double m = S / n;
+        const double var = fmax(Q / n - m * m, 0.0);
+        const float mean = (float)((double)(float)*gn_src(d, (long)b * d.hw, c_base + tid * cg) + m);     // this group's shift + mean of the shifted data
+        const float rstd = (float)(1.0 / sqrt(var + (double)d.eps));
+        fin[2 * tid] = mean; fin[2 * tid + 1] = rstd;
+        const int g_glob = blockIdx.x * gq + tid;
+        d.stats[((long)b * d.groups + g_glob) * 2] = mean;
+        d.stats[((long)b * d.groups + g_glob) * 2 + 1] = rstd;
+    }
+    __syncthreads();
+    float mean[GNF_MAXG], rstd[GNF_MAXG];
+#pragma unroll
+    for (int g = 0; g < GNF_MAXG; ++g) { mean[g] = g < gq ? fin[2 * g] : 0.f; rstd[g] = g < gq ? fin[2 * g + 1] : 0.f; }
+#pragma unroll
+    for (int it = 0; it < GNF_ITEMS; ++it) {
+        const int idx = tid + it * 256;
+        if (idx >= total) continue;
+        const int r = gnf_div(idx, magic), ch = idx - r * nch;
+        const int c = c_base + ch * 8;
+        const bf16x8 gm = *(const bf16x8*)((const __bf16*)d.gamma + c);
+        const bf16x8 bt = *(const bf16x8*)((const __bf16*)d.beta + c);
+        bf16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int g = gnf_group(ch * 8 + e, cg);
+            float mu = 0.f, rs = 0.f;
+#pragma unroll
+            for (int gg = 0; gg < GNF_MAXG; ++gg)
+                if (gg == g) { mu = mean[gg]; rs = rstd[gg]; }
+            const float a = rs * (float)gm[e];
+            float y = (float)v[it][e] * a + ((float)bt[e] - mu * a);
+            if (d.act == 1) y = silu_f(round_bf16(y));  // reference rounds the GroupNorm output to bf16 before SiLU
+            o[e] = (__bf16)y;
+        }
+        *(bf16x8*)((__bf16*)d.y + ((long)b * d.hw + r) * d.ldy + c) = o;
     }
 }
 
@@ -365,6 +484,23 @@ extern "C" int slh_gn_stats(const slh_gn_desc* d, slh_stream_t stream) {
     hipLaunchKernelGGL(gn_stats_kernel, dim3(g.row_blocks, d->batch), dim3(g.threads), g.lds_bytes, (hipStream_t)stream, *d,
                        g.nchunk, g.rpi, g.rows_per_block, g.cg, g.lpg, g.row_blocks);
     SLH_LAUNCH_CHECK("slh_gn_stats");
+    return 0;
+}
+
+extern "C" int slh_gn_fused_ok(int channels, int hw, int groups) {
+    if (channels <= 0 || channels % 8 || hw <= 0 || groups <= 0 || channels % groups) return 0;
+    return gn_fused_geom(channels, hw, groups).ok ? 1 : 0;
+}
+
+extern "C" int slh_gn_fused(const slh_gn_desc* d, slh_stream_t stream) {
+    SLH_CHECK(d && d->x0 && d->stats && d->y && d->gamma && d->beta, "slh_gn_fused: null pointer");
+    if (gn_check("slh_gn_fused", d->c0, d->c1, d->groups, d->ldx0, d->ldx1, d->x1)) return -1;
+    SLH_CHECK(d->ldy % 8 == 0, "slh_gn_fused: ldy");
+    const GnFusedGeom g = gn_fused_geom(d->c0 + d->c1, d->hw, d->groups);
+    SLH_CHECK(g.ok, "slh_gn_fused: shape C=%d hw=%d is not a small-tensor case (slh_gn_fused_ok)", d->c0 + d->c1, d->hw);
+    hipLaunchKernelGGL(gn_fused_kernel, dim3(d->groups / g.gq, d->batch), dim3(256), 0, (hipStream_t)stream, *d,
+                       (d->c0 + d->c1) / d->groups, g.gq, g.nch, (0x100000000ull + g.nch - 1) / g.nch);       // 2^32 itself for nch = 1: 64-bit
+    SLH_LAUNCH_CHECK("slh_gn_fused");
     return 0;
 }
 

@@ -42,6 +42,7 @@ extern "C" int slh_run_program(const void* program, int64_t nbytes, slh_stream_t
             case SLH_OP_GEMV: rc = run_desc<slh_gemv_desc>(p, sz, slh_gemv, stream, "gemv"); break;
             case SLH_OP_GN_STATS: rc = run_desc<slh_gn_desc>(p, sz, slh_gn_stats, stream, "gn_stats"); break;
             case SLH_OP_GN_APPLY: rc = run_desc<slh_gn_desc>(p, sz, slh_gn_apply, stream, "gn_apply"); break;
+            case SLH_OP_GN_FUSED: rc = run_desc<slh_gn_desc>(p, sz, slh_gn_fused, stream, "gn_fused"); break;
             case SLH_OP_LAYERNORM: rc = run_desc<slh_ln_desc>(p, sz, slh_layernorm, stream, "layernorm"); break;
             case SLH_OP_ATTN_FWD: rc = run_desc<slh_attn_desc>(p, sz, slh_attn_fwd, stream, "attn_fwd"); break;
             case SLH_OP_TRANSPOSE_HEADS:

@@ -109,7 +109,7 @@ OP_GN_BWD_STATS, OP_GN_BWD_APPLY, OP_LAYERNORM_BWD, OP_ATTN_BWD, OP_MEMSET = ran
 OP_LORA_CONV_DGRAD, OP_TEMB_LORA_BWD = 21, 22
 OP_SGEMM, OP_GN32_STATS, OP_GN32_APPLY, OP_SOFTMAX32, OP_VAE_CONV_IN, OP_VAE_MOMENTS, OP_VAE_SAMPLE, OP_VAE_POST_QUANT = range(23, 31)
 OP_LION = 31
-OP_WGRAD_BATCH, OP_TRANSPOSE_BATCH, OP_GATHER16 = 32, 33, 34
+OP_WGRAD_BATCH, OP_TRANSPOSE_BATCH, OP_GATHER16, OP_GN_FUSED = 32, 33, 34, 35
 
 EW_COPY, EW_ADD, EW_GEGLU_FWD, EW_GEGLU_BWD, EW_UPSAMPLE_BWD, EW_COLSUM = range(6)
 
@@ -130,12 +130,12 @@ _ENTRY = {
     OP_VAE_MOMENTS: ("slh_vae_moments", VaeConvDesc), OP_VAE_SAMPLE: ("slh_vae_sample", VaeSampleDesc),
     OP_VAE_POST_QUANT: ("slh_vae_post_quant", VaeConvDesc), OP_LION: ("slh_lion", LionDesc),
     OP_WGRAD_BATCH: ("slh_lora_wgrad_batch", BatchDesc), OP_TRANSPOSE_BATCH: ("slh_transpose_heads_batch", BatchDesc),
-    OP_GATHER16: ("slh_gather16", Gather16Desc),
+    OP_GATHER16: ("slh_gather16", Gather16Desc), OP_GN_FUSED: ("slh_gn_fused", GnDesc),
 }
 
 EXPORTS = ["slh_version", "slh_last_error", "slh_run_program", "slh_desc_sizes", "slh_graph_capture", "slh_graph_launch",
            "slh_graph_destroy", "slh_gemm_variant", "slh_gn_row_blocks", "slh_gn_clusters", "slh_gn32_row_blocks",
-           "slh_lora_wgrad_blocks", "slh_transpose_heads_blocks"] + [v[0] for v in _ENTRY.values()]
+           "slh_lora_wgrad_blocks", "slh_transpose_heads_blocks", "slh_gn_fused_ok"] + [v[0] for v in _ENTRY.values()]
 
 
 class SlidersHipError(RuntimeError):
@@ -202,6 +202,11 @@ def gn_workspace(channels: int, hw: int, groups: int):
         raise SlidersHipError(f"slh_gn_row_blocks({channels}, {hw}, {groups}): unsupported shape")
     c = l.slh_gn_clusters(r)
     return r + c, 1 + c
+
+
+def gn_fused_ok(channels: int, hw: int, groups: int) -> bool:
+    """slh_gn_fused (statistics + normalisation in one launch) applies to this shape"""
+    return bool(load().slh_gn_fused_ok(channels, hw, groups))
 
 
 def gn32_workspace(hw: int):

@@ -359,14 +359,16 @@ def _gn_workspace(dev, B, C, HW, G=32):
     return torch.full((B, prow, G, 2), float("nan"), device=dev), torch.zeros(B, ntick, dtype=torch.int32, device=dev)
 
 
-@pytest.mark.parametrize("C0,C1,act,mean,std", [(320, 0, 1, 0.5, 2.0), (64, 0, 0, 0.5, 2.0), (1280, 640, 1, 0.5, 2.0),
-                                                (2560, 0, 1, 0.5, 2.0), (960, 0, 1, 0.5, 2.0),
+@pytest.mark.parametrize("C0,C1,act,mean,std,HW", [(320, 0, 1, 0.5, 2.0, 300), (64, 0, 0, 0.5, 2.0, 300), (1280, 640, 1, 0.5, 2.0, 300),
+                                                (2560, 0, 1, 0.5, 2.0, 300), (960, 0, 1, 0.5, 2.0, 300),
                                                 # DC offset >> spread (real checkpoints' early resnet activations): a one-pass
                                                 # E[x^2] - E[x]^2 in fp32 loses the variance here (bf16 spacing at 50 is 0.25, at 256 is 2)
-                                                (320, 0, 1, 50.0, 1.0), (640, 0, 0, 256.0, 4.0), (1280, 640, 1, -50.0, 1.0)])
-def test_groupnorm(dev, C0, C1, act, mean, std):
+                                                (320, 0, 1, 50.0, 1.0, 300), (640, 0, 0, 256.0, 4.0, 300), (1280, 640, 1, -50.0, 1.0, 300),
+                                                # 8x8 latents: the one-launch form (slh_gn_fused) is what the planner emits
+                                                (1280, 0, 1, 0.5, 2.0, 64), (2560, 0, 1, 30.0, 1.0, 64), (1280, 1280, 0, 0.5, 2.0, 64)])
+def test_groupnorm(dev, C0, C1, act, mean, std, HW):
     torch.manual_seed(7)
-    B, HW = 2, 300
+    B = 2
     C = C0 + C1
     x0 = bf(torch.randn(B * HW, C0, device=dev) * std + mean)
     x1 = bf(torch.randn(B * HW, C1, device=dev) * std + mean) if C1 else None
@@ -401,6 +403,25 @@ def test_groupnorm(dev, C0, C1, act, mean, std):
         lib.call(lib.OP_GN_APPLY, d, stream())
         torch.cuda.synchronize()
         assert torch.equal(stats, s0) and torch.equal(y, y0)
+    # the single-launch form for small tensors (one workgroup per group set): same statistics, same output
+    if lib.gn_fused_ok(C, HW, 32):
+        sf = torch.full((B, 32, 2), float("nan"), device=dev)
+        yf = torch.zeros_like(y)
+        df = lib.GnDesc(x0=p(x0), x1=p(x1), gamma=p(g), beta=p(bta), stats=p(sf), y=p(yf), ldx0=C0, ldx1=C1, c0=C0, c1=C1,
+                        batch=B, hw=HW, groups=32, ldy=C, eps=1e-5, act=act)
+        lib.call(lib.OP_GN_FUSED, df, stream())
+        torch.cuda.synchronize()
+        assert float((sf[..., 0].double() - mref).abs().max() / mref.abs().max().clamp_min(1.0)) < 1e-6
+        assert float(((sf[..., 1].double() - rref) / rref).abs().max()) < 1e-5
+        report(f"groupnorm fused C{C0}+{C1} act{act} mean{mean}", yf, ref, TOL)
+        assert float((yf.float() - y.float()).abs().max()) <= 2.0 ** -7 * float(ref.abs().max()), "one-launch vs two-launch form"
+        y1 = yf.clone()
+        lib.call(lib.OP_GN_FUSED, df, stream())
+        torch.cuda.synchronize()
+        assert torch.equal(yf, y1)
+    else:
+        with pytest.raises(lib.SlidersHipError, match="small-tensor"):
+            lib.call(lib.OP_GN_FUSED, d, stream())
     # backward (dx only)
     dy = bf(torch.randn(B * HW, C, device=dev))
     bst = torch.full((B, 32, 2), float("nan"), device=dev)
