@@ -81,28 +81,30 @@ typedef struct slh_gemm_desc {
                                 in memory, so every LDS-DMA instruction reads 1 KB of consecutive addresses); ldw unused */
     int32_t reserved_;       /* 0.  Non-zero values are profiling ablations (scripts/probe_gemm.py): 1 skip tile refills,
                                 2 skip MFMA work, 4 skip the epilogue, 8 skip the first fill, 16 return at once */
-    float* splitk_c32;       /* split-K workspace or NULL: [splitk_slabs][M][N] fp32, any contents.  With tile bits 16-19 =
-                                S > 1 the K range is cut into S slices; each slice's workgroups write their partial tiles to
-                                slab number <slice> (plain stores - no fp32 atomics, whose arrival-order sums make a pass
-                                differ from run to run) and a second launch adds the slabs IN SLICE ORDER, applies the
-                                epilogue (bias, rowbias, LoRA, residual) and writes c.  For the few-row, long-K products
-                                (1280-channel 3x3 convolutions at 8x8 / 16x16: 10-40 output tiles on 256 CUs, 29 MB of
-                                weights each) this is what fills the chip. */
-    float* splitk_t32;       /* with lora_down and S > 1: [2*splitk_slabs][M][ld_t] fp32 slabs of the adapter's T (two
-                                per slice); the second launch reduces them and, if lora_t_out is set, writes T there */
+    float* splitk_c32;       /* split-K workspace or NULL: splitk_slabs slabs of roundup(M, 256) * roundup(N, 128) floats each (the
+                                partial tiles are kept whole, in accumulator order), any contents.  With tile bits 16-19 =
+                                S > 1 the K range is cut into S slices; each slice's workgroups publish their partial tiles in
+                                slab number <slice> (write-through stores - no fp32 atomics, whose arrival-order sums make a
+                                pass differ from run to run), take a ticket of their tile (splitk_ticket), and the slice that
+                                arrives LAST adds the slabs IN SLICE ORDER and runs the ordinary epilogue - one launch, every
+                                epilogue option available, bit-reproducible.  For the few-tile, long-K products (1280-channel
+                                3x3 convolutions at 8x8 / 16x16: 10-40 output tiles on 256 CUs, 29 MB of weights each) this
+                                is what fills the chip. */
+    float* splitk_t32;       /* with lora_down and S > 1: [ceil(N / (64*NI))][2*S][M][ld_t] fp32 - per column tile, two slabs
+                                per slice of the adapter's T (size it for NI = 1: ceil(N/64) * 2 * splitk_slabs * M * ld_t) */
     void* vt_out;            /* optional: the columns >= vt_col0 of the result (the V third of a fused q|k|v projection,
                                 diffusers Attention.to_v) are written HEAD-TRANSPOSED for slh_attn_fwd instead of into c:
                                 vt_out[((b*vt_heads + h)*Dp + d)*vt_ld + t] = C[b*vt_tokens + t][vt_col0 + h*vt_D + d],
                                 Dp = 64*ceil(vt_D/64) - exactly what slh_transpose_heads would produce from c, without
                                 the extra launch and the round trip of V through HBM.  Needs vt_D % 64 == 0 (no padded
-                                rows), vt_col0 % 128 == 0, vt_tokens % 8 == 0, M % 8 == 0; not with geglu / split-K */
+                                rows), vt_col0 % 128 == 0, vt_tokens % 8 == 0, M % 8 == 0; not with geglu */
     int32_t vt_col0, vt_D, vt_heads, vt_tokens, vt_ld;
     int32_t splitk_slabs;    /* slabs splitk_c32 holds (>= the S of tile) */
     /* LayerNorm folded into the products around it (BasicTransformerBlock.norm1/2/3 of the no-grad passes: no LayerNorm
      * launch, no round trip of the normalised tensor through HBM).
      *   producer (the GEMM that writes the tensor LayerNorm reads): ln_out [N/64][M][2] fp32 (chunk-major: a wave's 32 rows
      *     are contiguous for both sides) receives (mean, M2) of every 64-column chunk of every row of the bf16 result;
-     *     needs a 128-column tile, no GEGLU / vt_out / split-K.
+     *     needs a 128-column tile, no GEGLU / vt_out.
      *   consumer (dense, single source, K = LayerNorm width <= 1280): ln_in = the producer's ln_out, ln_in_chunks = K/64;
      *     w must hold W * gamma, ln_s [N] fp32 its row sums, ln_b [N] fp32 = bias + W . beta (bias must be NULL):
      *     c = rstd_m * (a . w^T - mean_m * ln_s) + ln_b, the row's mean / rstd merged from the chunks in a fixed order. */
@@ -110,6 +112,8 @@ typedef struct slh_gemm_desc {
     const float* ln_in; const float* ln_s; const float* ln_b;
     int32_t ln_in_chunks;
     float ln_eps;
+    void* splitk_ticket;     /* with S > 1: one 64-bit arrival ticket per output tile ([ceil(M/64) * ceil(N/64)] is enough for
+                                every tile shape), zero before the first launch, left zero by every launch */
 } slh_gemm_desc;
 int slh_gemm(const slh_gemm_desc* d, slh_stream_t stream);
 /* (WM<<12)|(MI<<8)|(NI<<4)|mode of the kernel instantiation gemm_kernel<MI,NI,mode,..,WM> slh_gemm would launch for d

@@ -67,9 +67,7 @@ def valid(d, tile):
             return False
     if d.geglu and ni != 2:
         return False
-    if d.ln_out and (ni != 2 or (tile >> 16) & 15):        # folded LayerNorm: the producer writes 64-column chunk statistics
-        return False
-    if d.ln_in and (tile >> 16) & 15:
+    if d.ln_out and ni != 2:                    # folded LayerNorm: the producer writes 64-column chunk statistics
         return False
     if d.lora_down and d.lora_up_rmajor and (tile >> 16) & 15:     # backward-data product with the adapter fused in
         return False

@@ -92,6 +92,12 @@ __device__ __forceinline__ f32x2 load_pair_sc1(const float* p) {
     const unsigned long long bits = __hip_atomic_load((const unsigned long long*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     return f32x2{__builtin_bit_cast(float, (unsigned)bits), __builtin_bit_cast(float, (unsigned)(bits >> 32))};
 }
+// the same pair read with only the L1 bypassed (workgroup scope): served by the L2 of THIS XCD - correct only for data whose
+// write-through stores were issued on this XCD (split-K reduction: the ticket proves it)
+__device__ __forceinline__ f32x2 load_pair_l2(const float* p) {
+    const unsigned long long bits = __hip_atomic_load((const unsigned long long*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    return f32x2{__builtin_bit_cast(float, (unsigned)bits), __builtin_bit_cast(float, (unsigned)(bits >> 32))};
+}
 // true in every thread of the workgroup that arrives last of `expected` at *ticket (zeroed by the caller before the
 // launch; the last arriver re-arms it).  lds_flag: one int of the kernel's LDS.
 __device__ __forceinline__ bool last_arriver(unsigned* ticket, unsigned expected, int* lds_flag) {

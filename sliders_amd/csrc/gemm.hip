@@ -37,6 +37,7 @@ struct GemmArgs {
     int tiles_m, tiles_n, group_m;
     float* c32; float* t32;   // split-K: fp32 partial sums (zeroed by the caller), see slh_gemm_desc.splitk_c32
     int splitk;
+    unsigned long long* ticket;   // split-K arrival tickets, one per output tile (slh_gemm_desc.splitk_ticket)
     __bf16* vt; int vt_col0, vt_D, vt_heads, vt_tokens, vt_ld;   // head-transposed store of the V columns (slh_gemm_desc.vt_out)
     int store16;  // c and ldc allow 16-byte row stores
     // LayerNorm folded into the product (slh_gemm_desc.ln_*): producer side writes per-row chunk statistics of its
@@ -231,7 +232,7 @@ __global__ __launch_bounds__(128 * WM, gemm_waves_per_simd(MI, NI, STAGES, LORA,
     constexpr int LN_MAXC = 20;
     float ln_mean[MI], ln_rstd[MI];
     f32x2 ln_pairs[MI][MODE == 0 ? LN_MAXC : 1];
-    const bool ln_on = MODE == 0 && p.ln_in != nullptr;
+    const bool ln_on = MODE == 0 && !LORA && p.ln_in != nullptr;   // (never with a fused adapter: slh_gemm rejects it)
     if (MODE == 0 && ln_on) {
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
@@ -524,31 +525,118 @@ __global__ __launch_bounds__(128 * WM, gemm_waves_per_simd(MI, NI, STAGES, LORA,
     // ---- epilogue ---------------------------------------------------------------------------------
     // acc[i][j][r] = C[m = m0 + wm*32*MI + i*32 + lrow][n = n0 + wn*32*NI + j*32 + (r&3) + 8*(r>>2) + 4*lhi]
     if (p.splitk > 1) {
-        // split-K: this K slice's partial sums go to ITS OWN fp32 slab of the workspace (plain 16-byte stores, no atomics:
-        // fp32 atomics commit in arrival order and the sum's last bits - hence bf16 roundings downstream - would differ
-        // from run to run); gemm_finalize_kernel adds the slabs in slice order and applies the epilogue
-        float* slab = p.c32 + (long)ks_id * p.M * p.N;
+        // split-K, reduced inside the launch in a FIXED order (no fp32 atomics: they commit in arrival order, the sum's last
+        // bits - hence bf16 roundings downstream - would differ from run to run).  Every K slice publishes its partial tile
+        // in ITS OWN fp32 slab (write-through stores), drains them and takes a ticket of the tile; the slice that draws the
+        // last ticket adds all slabs IN SLICE ORDER (its own included, read back like the others: which slice is last
+        // varies, the arithmetic does not) and runs the ordinary epilogue below.  The other slices are done.
+        // The ticket also counts arrivals per XCD (7-bit fields above the 8-bit count): when every slice ran on the reader's
+        // XCD - the launch order puts the slices of a tile on consecutive block ids of one XCD - the partials are read from
+        // that XCD's L2 (workgroup-scope loads: only the L1 is bypassed); otherwise from memory (agent scope).
+        // Slab layout = the accumulator layout: slab[slice][tile][wave][block i,j][q][lane] holds 4 floats, so every store /
+        // load instruction of a wave moves 1 KB of consecutive addresses and nothing needs a bounds check (rows / columns past
+        // M / N are padding inside the slab).  (8-byte row-major pieces, written through, cost ~50 us per launch.)
+        constexpr int TILE_BYTES = BM * BN * 4;
+        const unsigned slab_bytes = (unsigned)(p.tiles_m * p.tiles_n) * TILE_BYTES;
+        const __amdgpu_buffer_rsrc_t slabs = __builtin_amdgcn_make_buffer_rsrc(p.c32, 0, (int)(p.splitk * slab_bytes), 0x00020000);
+        unsigned lane_off = (unsigned)(tile_m * p.tiles_n + tile_n) * TILE_BYTES + wave * (MI * NI * 4096) + lane * 16;
+        asm volatile("" : "+v"(lane_off));      // not to be formed ahead of the K loop and carried through it
+        int lrow_s = lrow;
+        asm volatile("" : "+v"(lrow_s));
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
-            const int m = m0 + wm * (32 * MI) + i * 32 + lrow;
-            if (m >= p.M) continue;
 #pragma unroll
             for (int j = 0; j < NI; ++j)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const int n = n0 + wn * (32 * NI) + j * 32 + q * 8 + lhi * 4;
-                    if (n >= p.N) continue;
-                    *(f32x4*)(slab + (long)m * p.N + n) =
-                        f32x4{acc[i][j][q * 4], acc[i][j][q * 4 + 1], acc[i][j][q * 4 + 2], acc[i][j][q * 4 + 3]};
+                    const f32x4 v = {acc[i][j][q * 4], acc[i][j][q * 4 + 1], acc[i][j][q * 4 + 2], acc[i][j][q * 4 + 3]};
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), slabs,
+                                                           ks_id * slab_bytes + lane_off + ((i * NI + j) * 4 + q) * 1024, 0, 16 /* sc1 */);
                 }
-            if (LORA && tile_n == 0) {         // both waves of a row pair: each holds the partial of its own k-steps -> 2 slabs per slice
+            const int m = m0 + wm * (32 * MI) + i * 32 + lrow_s;
+            if (m >= p.M) continue;
+            if (LORA) {
+                // T of the tile's rows: each wave of a row pair holds the partial of its own k-steps -> 2 slabs per slice, per
+                // column tile (every column tile reduces its own copy: its last slice cannot wait for another tile's slices)
                 // rank index of accl[i][r]: (r&3) + 8*(r>>2) + 4*lhi  ->  ranks 0-3 / 8-11 in the lhi=0 half, 4-7 in lhi=1
-                float* ts = p.t32 + ((long)(ks_id * 2 + wn) * p.M + m) * p.ld_t;
-                if (4 * lhi < p.lora_rank) *(f32x4*)(ts + 4 * lhi) = f32x4{accl[i][0], accl[i][1], accl[i][2], accl[i][3]};
-                if (lhi == 0 && 8 < p.lora_rank) *(f32x4*)(ts + 8) = f32x4{accl[i][4], accl[i][5], accl[i][6], accl[i][7]};
+                float* ts = p.t32 + (((long)tile_n * 2 * p.splitk + ks_id * 2 + wn) * p.M + m) * p.ld_t;
+                if (4 * lhi < p.lora_rank) {
+                    store_pair_sc1(ts + 4 * lhi, accl[i][0], accl[i][1]);
+                    store_pair_sc1(ts + 4 * lhi + 2, accl[i][2], accl[i][3]);
+                }
+                if (lhi == 0 && 8 < p.lora_rank) {
+                    store_pair_sc1(ts + 8, accl[i][4], accl[i][5]);
+                    store_pair_sc1(ts + 10, accl[i][6], accl[i][7]);
+                }
             }
         }
-        return;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's partials have reached the memory side
+        __syncthreads();                                       // ... and every wave is done with the operand stages
+        unsigned long long& arrival = *(unsigned long long*)smem;
+        const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 7;   // HW_REG_XCC_ID
+        if (tid == 0) {
+            unsigned long long* ticket = p.ticket + (long)tile_m * p.tiles_n + tile_n;
+            const unsigned long long mine = 1ull + (1ull << (8 + 7 * xcc));
+            const unsigned long long seen = __hip_atomic_fetch_add(ticket, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + mine;
+            if ((int)(seen & 255) == p.splitk) __hip_atomic_store(ticket, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            arrival = seen;
+        }
+        __syncthreads();
+        const unsigned long long seen = arrival;
+        if ((int)(seen & 255) != p.splitk) return;
+        const bool local = (int)((seen >> (8 + 7 * xcc)) & 127) == p.splitk;     // uniform over the workgroup
+        // slice 0 is loaded straight into the accumulators (their contents are in the slabs now), every further slice as
+        // batches of independent 16-byte loads (one 32-row block): the serial part is one round trip per slice and block
+        auto reduce = [&](auto kLocal) {
+            constexpr int kAux = decltype(kLocal)::value ? 1 /* sc0: this XCD's L2 */ : 16 /* sc1: memory */;
+            auto ld = [&](const float* q) { return decltype(kLocal)::value ? load_pair_l2(q) : load_pair_sc1(q); };
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+#pragma unroll
+                for (int j = 0; j < NI; ++j)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                            slabs, lane_off + ((i * NI + j) * 4 + q) * 1024, 0, kAux));
+                        acc[i][j][q * 4] = v[0]; acc[i][j][q * 4 + 1] = v[1]; acc[i][j][q * 4 + 2] = v[2]; acc[i][j][q * 4 + 3] = v[3];
+                    }
+                for (int k = 1; k < p.splitk; ++k) {
+                    f32x4 t[NI * 4];
+#pragma unroll
+                    for (int j = 0; j < NI; ++j)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                            t[j * 4 + q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                                slabs, k * slab_bytes + lane_off + ((i * NI + j) * 4 + q) * 1024, 0, kAux));
+#pragma unroll
+                    for (int j = 0; j < NI; ++j)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            acc[i][j][q * 4] += t[j * 4 + q][0]; acc[i][j][q * 4 + 1] += t[j * 4 + q][1];
+                            acc[i][j][q * 4 + 2] += t[j * 4 + q][2]; acc[i][j][q * 4 + 3] += t[j * 4 + q][3];
+                        }
+                }
+                const int m = m0 + wm * (32 * MI) + i * 32 + lrow_s;
+                if (m >= p.M) continue;
+                if (LORA) {
+                    // this wave's own half (wn) of every slice, in slice order; the halves meet in the epilogue's exchange
+                    const long tstride = 2L * p.M * p.ld_t;
+                    const float* ts = p.t32 + (((long)tile_n * 2 * p.splitk + wn) * p.M + m) * p.ld_t;
+                    const bool r0 = 4 * lhi < p.lora_rank, r8 = lhi == 0 && 8 < p.lora_rank;
+                    f32x2 t0 = {0.f, 0.f}, t1 = {0.f, 0.f}, t2 = {0.f, 0.f}, t3 = {0.f, 0.f};
+                    for (int k = 0; k < p.splitk; ++k) {
+                        const float* tk = ts + k * tstride;
+                        const f32x2 a0 = r0 ? ld(tk + 4 * lhi) : f32x2{0.f, 0.f}, a1 = r0 ? ld(tk + 4 * lhi + 2) : f32x2{0.f, 0.f};
+                        const f32x2 a2 = r8 ? ld(tk + 8) : f32x2{0.f, 0.f}, a3 = r8 ? ld(tk + 10) : f32x2{0.f, 0.f};
+                        t0 += a0; t1 += a1; t2 += a2; t3 += a3;
+                    }
+                    accl[i][0] = t0[0]; accl[i][1] = t0[1]; accl[i][2] = t1[0]; accl[i][3] = t1[1];
+                    accl[i][4] = t2[0]; accl[i][5] = t2[1]; accl[i][6] = t3[0]; accl[i][7] = t3[1];
+                }
+            }
+        };
+        if (local) reduce(std::true_type{});
+        else reduce(std::false_type{});
     }
     if (p.geglu) {
         // GEGLU: W rows are stored in 64-row blocks [32 value rows | 32 gate rows]; NI is 2 here, so
@@ -819,83 +907,6 @@ __global__ __launch_bounds__(128 * WM, gemm_waves_per_simd(MI, NI, STAGES, LORA,
     }
 }
 
-// split-K second pass: C = epi(sum of the K slices' slabs, in slice order) with the epilogue of gemm_kernel (bias, per-sample
-// row bias, LoRA up-projection of the reduced T, residual), one thread per 4 consecutive columns of one row.
-__global__ __launch_bounds__(256) void gemm_finalize_kernel(const GemmArgs p) {
-    const int nq = p.N >> 2;
-    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= (long)p.M * nq) return;
-    const int m = (int)(idx / nq);
-    const int n = (int)(idx - (long)m * nq) * 4;
-    const long slab = (long)p.M * p.N;
-    f32x4 c4 = *(const f32x4*)(p.c32 + (long)m * p.N + n);
-    for (int k = 1; k < p.splitk; ++k) c4 += *(const f32x4*)(p.c32 + k * slab + (long)m * p.N + n);
-    float v[4] = {c4[0], c4[1], c4[2], c4[3]};
-    if (p.bias) {
-        const bf16x4 b4 = *(const bf16x4*)(p.bias + n);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] += (float)b4[e];
-    }
-    if (p.rowbias) {
-        const bf16x4 b4 = *(const bf16x4*)(p.rowbias + (long)(m / p.rows_per_sample) * p.ld_rowbias + n);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] += (float)b4[e];
-    }
-    if (p.lora_down) {
-        // fused adapter: T's slabs (two per K slice, see gemm_kernel) reduce in slab order
-        const float lscale = *p.lora_scale;
-        const long tslab = (long)p.M * p.ld_t;
-        const int g = n / p.lora_cols_per_group;
-        const float* tp = p.t32 + (long)m * p.ld_t + g * 4;
-        f32x4 t = *(const f32x4*)tp;
-        for (int k = 1; k < 2 * p.splitk; ++k) t += *(const f32x4*)(tp + k * tslab);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const bf16x4 u = *(const bf16x4*)(p.lora_up + (long)(n + e) * 4);
-            v[e] += lscale * (t[0] * (float)u[0] + t[1] * (float)u[1] + t[2] * (float)u[2] + t[3] * (float)u[3]);
-        }
-        if (p.lora_t_out && n == 0) {          // the backward wants T itself
-            for (int gg = 0; gg * 4 < p.lora_rank; ++gg) {
-                const float* tq = p.t32 + (long)m * p.ld_t + gg * 4;
-                f32x4 tt = *(const f32x4*)tq;
-                for (int k = 1; k < 2 * p.splitk; ++k) tt += *(const f32x4*)(tq + k * tslab);
-                *(f32x4*)(p.lora_t_out + (long)m * p.ld_t + gg * 4) = tt;
-            }
-        }
-    } else if (p.lora_t) {
-        const float* T = p.lora_t;
-        const float lscale = *p.lora_scale;
-        if (!p.lora_up_rmajor) {
-            const int g = n / p.lora_cols_per_group;
-            const f32x4 t = *(const f32x4*)(T + (long)m * p.ld_t + g * 4);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const bf16x4 u = *(const bf16x4*)(p.lora_up + (long)(n + e) * 4);
-                v[e] += lscale * (t[0] * (float)u[0] + t[1] * (float)u[1] + t[2] * (float)u[2] + t[3] * (float)u[3]);
-            }
-        } else {
-            float s4[4] = {0.f, 0.f, 0.f, 0.f};
-            for (int r = 0; r < p.lora_rank; ++r) {
-                const float tr = T[(long)m * p.ld_t + r];
-                const bf16x4 u = *(const bf16x4*)(p.lora_up + (long)r * p.N + n);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) s4[e] += tr * (float)u[e];
-            }
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] += lscale * s4[e];
-        }
-    }
-    if (p.residual) {
-        const bf16x4 r4 = *(const bf16x4*)(p.residual + (long)m * p.ld_res + n);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] += (float)r4[e];
-    }
-    bf16x4 o;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) o[e] = (__bf16)v[e];
-    *(bf16x4*)(p.c + (long)m * p.ldc + n) = o;
-}
-
 template <int MI, int NI, int MODE, bool LORA, int WM>
 int launch_gemm3(const GemmArgs& a, int stages, hipStream_t s) {
     const int grid = a.tiles_m * a.tiles_n * (a.splitk > 1 ? a.splitk : 1);
@@ -911,11 +922,6 @@ int launch_gemm3(const GemmArgs& a, int stages, hipStream_t s) {
     else
         hipLaunchKernelGGL((gemm_kernel<MI, NI, MODE, 2, LORA, WM>), dim3(grid), dim3(128 * WM), 0, s, a);
     SLH_LAUNCH_CHECK("slh_gemm");
-    if (a.splitk > 1) {
-        const long nthr = (long)a.M * (a.N >> 2);
-        hipLaunchKernelGGL(gemm_finalize_kernel, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, s, a);
-        SLH_LAUNCH_CHECK("slh_gemm (split-K finalize)");
-    }
     return 0;
 }
 
@@ -1063,14 +1069,13 @@ extern "C" int slh_gemm(const slh_gemm_desc* d, slh_stream_t stream) {
     a.ln_out = d->ln_out; a.ln_in = d->ln_in; a.ln_s = d->ln_s; a.ln_b = d->ln_b;
     a.ln_in_chunks = d->ln_in_chunks; a.ln_eps = d->ln_eps;
     if (d->ln_out) {
-        SLH_CHECK(NI == 2 && d->N % 64 == 0 && !d->geglu && !d->vt_out && ((d->tile >> 16) & 15) <= 1,
-                  "slh_gemm: ln_out needs a 128-column tile (NI = 2), N %% 64 == 0, no GEGLU / vt_out / split-K");
+        SLH_CHECK(NI == 2 && d->N % 64 == 0 && !d->geglu && !d->vt_out,
+                  "slh_gemm: ln_out needs a 128-column tile (NI = 2), N %% 64 == 0, no GEGLU / vt_out");
         SLH_CHECK(((uintptr_t)d->ln_out & 7) == 0, "slh_gemm: ln_out alignment");
     }
     if (d->ln_in) {
-        SLH_CHECK(d->mode == 0 && !d->a1 && d->ln_s && d->ln_b && !d->bias && !d->lora_down && !d->lora_t &&
-                      ((d->tile >> 16) & 15) <= 1,
-                  "slh_gemm: ln_in needs a dense single-source product, ln_s / ln_b, no bias (folded into ln_b), no adapter, no split-K");
+        SLH_CHECK(d->mode == 0 && !d->a1 && d->ln_s && d->ln_b && !d->bias && !d->lora_down && !d->lora_t,
+                  "slh_gemm: ln_in needs a dense single-source product, ln_s / ln_b, no bias (folded into ln_b), no adapter");
         SLH_CHECK(d->ln_in_chunks >= 1 && d->ln_in_chunks <= 20 && d->K == 64 * d->ln_in_chunks,
                   "slh_gemm: ln_in_chunks must be K / 64 (<= 20)");
         SLH_CHECK(((uintptr_t)d->ln_in & 7) == 0 && ((uintptr_t)d->ln_s & 15) == 0 && ((uintptr_t)d->ln_b & 15) == 0,
@@ -1080,8 +1085,9 @@ extern "C" int slh_gemm(const slh_gemm_desc* d, slh_stream_t stream) {
     a.splitk = (d->tile >> 16) & 15;
     a.c32 = d->splitk_c32;
     a.t32 = d->splitk_t32;
+    a.ticket = (unsigned long long*)d->splitk_ticket;
     if (a.splitk > 1) {
-        // every slice must be non-empty: each writes its whole slab, the finalize pass reads them all
+        // every slice must be non-empty: each publishes its whole partial tile, the last one to arrive reads them all
         const int nk = d->K / 64;
         const int per = (nk + a.splitk - 1) / a.splitk;
         a.splitk = (nk + per - 1) / per;
@@ -1090,8 +1096,10 @@ extern "C" int slh_gemm(const slh_gemm_desc* d, slh_stream_t stream) {
         SLH_CHECK(d->splitk_c32, "slh_gemm: split-K needs the fp32 slab workspace splitk_c32");
         SLH_CHECK(d->splitk_slabs >= a.splitk, "slh_gemm: split-K into %d slices but the workspace holds %d slabs", a.splitk,
                   d->splitk_slabs);
-        SLH_CHECK(!d->geglu, "slh_gemm: split-K excludes the GEGLU epilogue");
-        SLH_CHECK(!d->vt_out, "slh_gemm: split-K excludes the head-transposed V store");
+        SLH_CHECK(d->splitk_ticket, "slh_gemm: split-K needs the arrival tickets splitk_ticket (zeroed once)");
+        SLH_CHECK((long)a.splitk * ((d->M + 255) / 256 * 256L) * ((d->N + 127) / 128 * 128L) * 4 < (1L << 31),
+                  "slh_gemm: split-K slabs beyond 2 GB");
+        SLH_CHECK(((uintptr_t)d->splitk_ticket & 7) == 0 && d->N % 4 == 0, "slh_gemm: split-K needs N %% 4 == 0 and 8-byte aligned tickets");
         SLH_CHECK(!d->lora_down || a.t32, "slh_gemm: split-K with a fused adapter needs the slab workspace splitk_t32");
         SLH_CHECK(((uintptr_t)d->splitk_c32 & 15) == 0 && ((uintptr_t)d->splitk_t32 & 15) == 0, "slh_gemm: slab alignment");
     } else {

@@ -99,9 +99,22 @@ def default_splitk(d) -> int:
 SPLITK_TUNING_SLABS = 8          # slabs provisioned per candidate when the in-situ tuner may try any split factor
 
 
+SPLITK_TICKETS = 4096            # 64-bit arrival tickets per plan (one per output tile of the largest split-K product)
+
+
+def _plan_tickets(plan, n: int) -> int:
+    """The arrival tickets of a plan's split-K products: ONE array per plan - every launch leaves its tickets zero and the
+    launches of a plan are ordered on one stream.  Lives in the zero-init arena (zeroed at the head of the program)."""
+    assert n <= SPLITK_TICKETS, f"split-K product with {n} output tiles"
+    if getattr(plan, "_splitk_tickets", None) is None:
+        plan._splitk_tickets = plan.zarena.alloc((2 * SPLITK_TICKETS,), torch.float32, "splitk.tickets")
+    return plan._splitk_tickets.ptr
+
+
 def provision_splitk(plan, d, name: str):
-    """Give a product that will (or, in tuning mode, may) run split-K its slab workspace: one fp32 [M][N] slab per K slice
-    (each slice writes its own, the finalize launch adds them in slice order - bit-reproducible, nothing to zero) and, with a
+    """Give a product that will (or, in tuning mode, may) run split-K its slab workspace: one fp32 slab (M, N rounded up to whole
+    tiles) per K slice
+    (each slice writes its own, the last slice of a tile to arrive adds them in slice order inside the launch - bit-reproducible) and, with a
     fused adapter, two [M][ld_t] slabs per slice for T.  Fixes d.tile for untuned shapes."""
     if not splitk_wanted(d):
         return
@@ -112,9 +125,14 @@ def provision_splitk(plan, d, name: str):
     if slabs < 2:
         return
     d.splitk_slabs = slabs
-    d.splitk_c32 = plan.arena.alloc((slabs, d.M, d.N), torch.float32, name + ".splitk").ptr
+    d.splitk_c32 = plan.arena.alloc((slabs, (d.M + 255) // 256 * 256, (d.N + 127) // 128 * 128), torch.float32, name + ".splitk").ptr
+    d.splitk_ticket = _plan_tickets(plan, ((d.M + 63) // 64) * ((d.N + 63) // 64))
     if d.lora_down:
-        d.splitk_t32 = plan.arena.alloc((2 * slabs, d.M, d.ld_t), torch.float32, name + ".splitk_T").ptr
+        # one pair of T slabs per slice and per COLUMN TILE (each column tile's last slice reduces its own copy); sized for
+        # the narrowest tile (64 columns) unless the tile is fixed
+        ni = (d.tile & 15) if (d.tile and not tuning) else 1
+        tiles_n = (d.N + 64 * ni - 1) // (64 * ni)
+        d.splitk_t32 = plan.arena.alloc((tiles_n * 2 * slabs, d.M, d.ld_t), torch.float32, name + ".splitk_T").ptr
 
 
 def _src_parts(x: Src):

@@ -148,6 +148,19 @@ def test_gemm_head_transposed_v_store(dev, tile):
     assert (c[:, 2 * C:].float() == 7.0).all(), "the V columns must not be written to c"
     vref = ref[:, 2 * C:].reshape(B, T, heads, D).permute(0, 2, 3, 1)
     report(f"gemm_vt tile{tile:x} v^T", vt, vref, TOL)
+    if tile in (0x4412, 0x22):
+        # the same with K cut into slices: the last slice to arrive runs this epilogue on the slice-ordered sums
+        c.fill_(7.0)
+        vt.fill_(7.0)
+        d.tile = tile | (3 << 16)
+        slabs = torch.full((3, (M + 255) // 256 * 256, (N + 127) // 128 * 128), float("nan"), device=dev)
+        tickets = torch.zeros((M // 64) * (N // 64), device=dev, dtype=torch.int64)
+        d.splitk_c32, d.splitk_slabs, d.splitk_ticket = p(slabs), 3, p(tickets)
+        lib.call(lib.OP_GEMM, d, stream())
+        torch.cuda.synchronize()
+        report(f"gemm_vt splitk tile{tile:x} q|k", c[:, :2 * C], ref[:, :2 * C], TOL)
+        report(f"gemm_vt splitk tile{tile:x} v^T", vt, vref, TOL)
+        assert int(tickets.abs().sum()) == 0
 
 
 def test_gemm_geglu(dev):
@@ -169,6 +182,19 @@ def test_gemm_geglu(dev):
         proj = bf(x.float() @ w.float().t() + b.float()).float()
         ref = proj[:, :n_out] * bf(F.gelu(proj[:, n_out:])).float()
         report(f"gemm_geglu tile{tile:x}", c, ref, TOL)
+    # split-K with the GEGLU epilogue (the last slice of a tile to arrive runs the ordinary epilogue on the slice-ordered sums)
+    for tile in (0x24412, 0x44012):
+        S = tile >> 16
+        c = torch.zeros(M, n_out, device=dev, dtype=torch.bfloat16)
+        ws = torch.full((S, (M + 255) // 256 * 256, (N + 127) // 128 * 128), float("nan"), device=dev)
+        tickets = torch.zeros((M // 64) * (N // 64), device=dev, dtype=torch.int64)
+        d = lib.GemmDesc(a0=p(x), w=p(wp), bias=p(bp), c=p(c), lda0=K, ca0=K, mode=0, stride=1, ldw=K, M=M, N=N, K=K,
+                         ldc=n_out, geglu=1, rows_per_sample=M, tile=tile, splitk_c32=p(ws), splitk_slabs=S,
+                         splitk_ticket=p(tickets))
+        lib.call(lib.OP_GEMM, d, stream())
+        torch.cuda.synchronize()
+        report(f"gemm_geglu splitk tile{tile:x}", c, ref, TOL)
+        assert int(tickets.abs().sum()) == 0
     # unfused training path: blocked pre-activation + elementwise GEGLU fwd / bwd
     pre = torch.zeros(M, N, device=dev, dtype=torch.bfloat16)
     d = lib.GemmDesc(a0=p(x), w=p(wp), bias=p(bp), c=p(pre), lda0=K, ca0=K, mode=0, stride=1, ldw=K, M=M, N=N, K=K,
@@ -249,6 +275,30 @@ def test_gemm_layernorm_folded(dev, C, offset):
             lib.call(lib.OP_GEMM, d, stream())
             torch.cuda.synchronize()
             report(f"ln consumer geglu tile{tile:x} C{C} off{offset}", c, refg, TOL)
+    # both sides combined with split-K: the slice that arrives last runs the same epilogue on the slice-ordered sums
+    tickets = torch.zeros(((M + 63) // 64) * ((2 * C + 63) // 64), device=dev, dtype=torch.int64)
+    slabs = torch.full((3, 512, 2 * C), float("nan"), device=dev)
+    h2 = torch.zeros(M, C, device=dev, dtype=torch.bfloat16)
+    chunks2 = torch.full((C // 64, M, 2), float("nan"), device=dev)
+    d = lib.GemmDesc(a0=p(o), w=p(wo), bias=p(bo), residual=p(res), c=p(h2), lda0=C, ca0=C, mode=0, stride=1, ldw=C, M=M, N=C,
+                     K=C, ld_res=C, ldc=C, rows_per_sample=M, tile=0x24412, ln_out=p(chunks2), splitk_c32=p(slabs), splitk_slabs=3,
+                     splitk_ticket=p(tickets))
+    lib.call(lib.OP_GEMM, d, stream())
+    torch.cuda.synchronize()
+    report(f"ln producer splitk C{C}", h2, h_ref.float(), TOL)
+    hc = h2.float().view(M, C // 64, 64).double()
+    assert float((chunks2.permute(1, 0, 2).double()[..., 0] - hc.mean(-1)).abs().max()) < 1e-5 * max(1.0, float(hc.mean(-1).abs().max()))
+    ln2 = bf(F.layer_norm(h2.float(), (C,), gamma.float(), beta.float(), 1e-5))
+    wf2, sv2, bp2 = fold_layernorm(w, None, gamma, beta)
+    for tile in (0x24412, 0x30022):
+        c = torch.zeros(M, N, device=dev, dtype=torch.bfloat16)
+        d = lib.GemmDesc(a0=p(h2), w=p(wf2), c=p(c), lda0=C, ca0=C, mode=0, stride=1, ldw=C, M=M, N=N, K=C, ldc=N,
+                         rows_per_sample=M, tile=tile, ln_in=p(chunks2), ln_in_chunks=C // 64, ln_s=p(sv2), ln_b=p(bp2), ln_eps=1e-5,
+                         splitk_c32=p(slabs), splitk_slabs=3, splitk_ticket=p(tickets))
+        lib.call(lib.OP_GEMM, d, stream())
+        torch.cuda.synchronize()
+        report(f"ln consumer splitk tile{tile:x} C{C} off{offset}", c, ln2.float() @ w.float().t(), TOL)
+    assert int(tickets.abs().sum()) == 0
     # descriptors the kernel cannot honour are rejected before any launch
     bad = lib.GemmDesc(a0=p(o), w=p(wo), c=p(h), lda0=C, ca0=C, mode=0, stride=1, ldw=C, M=M, N=C, K=C, ldc=C, rows_per_sample=M,
                        tile=0x11, ln_out=p(chunks))
@@ -861,9 +911,10 @@ def test_gemm_fused_lora_down(dev, tile):
 
 @pytest.mark.parametrize("tile", [0x20412, 0x40421, 0x80422, 0x44412, 0x30011, 0x20022, 0xf0412])
 def test_gemm_splitk(dev, tile):
-    """Split-K (slh_gemm_desc.tile bits 16-19): every K slice writes its own fp32 slab (whatever the workspace held), the
-    second launch adds the slabs in slice order and applies the epilogue - bit-reproducible.  Dense + bias + residual,
-    3x3 convolution, fused LoRA down/up (T reduced too, and written out for the backward), two-source K."""
+    """Split-K (slh_gemm_desc.tile bits 16-19): every K slice publishes its partial tile in its own fp32 slab (whatever the
+    workspace held), the slice of a tile that arrives last adds the slabs in slice order and runs the ordinary epilogue -
+    one launch, bit-reproducible, tickets left zero.  Dense + bias + residual, 3x3 convolution, fused LoRA down/up (T reduced
+    too, and written out for the backward), two-source K."""
     torch.manual_seed(tile & 0xff)
     S = (tile >> 16) & 15
     M, N, K = 300, 320, 1280
@@ -872,18 +923,25 @@ def test_gemm_splitk(dev, tile):
     bias = bf(torch.randn(N, device=dev))
     res = bf(torch.randn(M, N, device=dev))
     c = torch.zeros(M, N, device=dev, dtype=torch.bfloat16)
-    ws = torch.full((S, M, N), float("nan"), device=dev)
+    ws = torch.full((S, 512, 384), float("nan"), device=dev)      # slabs of roundup(M, 256) x roundup(N, 128)
+    tickets = torch.zeros(((M + 63) // 64) * ((N + 63) // 64), device=dev, dtype=torch.int64)
     d = lib.GemmDesc(a0=p(x), w=p(w), bias=p(bias), residual=p(res), c=p(c), lda0=K, ca0=K, mode=0, stride=1, ldw=K,
-                     M=M, N=N, K=K, ld_res=N, ldc=N, rows_per_sample=M, tile=tile, splitk_c32=p(ws), splitk_slabs=S)
+                     M=M, N=N, K=K, ld_res=N, ldc=N, rows_per_sample=M, tile=tile, splitk_c32=p(ws), splitk_slabs=S,
+                     splitk_ticket=p(tickets))
     lib.call(lib.OP_GEMM, d, stream())
     torch.cuda.synchronize()
     report(f"splitk dense tile{tile:x}", c, x.float() @ w.float().t() + bias.float() + res.float(), TOL)
+    assert int(tickets.abs().sum()) == 0, "the last slice of every tile re-arms its ticket"
     c0 = c.clone()
     for _ in range(3):
         c.zero_()
         lib.call(lib.OP_GEMM, d, stream())
         torch.cuda.synchronize()
         assert torch.equal(c, c0), "split-K must be bit-reproducible"
+    d.splitk_ticket = 0
+    with pytest.raises(lib.SlidersHipError, match="ticket"):
+        lib.call(lib.OP_GEMM, d, stream())
+    d.splitk_ticket = p(tickets)
     d.splitk_slabs = 1
     with pytest.raises(lib.SlidersHipError, match="slabs"):
         lib.call(lib.OP_GEMM, d, stream())
@@ -892,11 +950,11 @@ def test_gemm_splitk(dev, tile):
     up = bf(torch.randn(N, 4, device=dev))
     scale = torch.tensor([0.25], device=dev)
     ws.fill_(float("nan"))
-    T32 = torch.full((2 * S, M, 8), float("nan"), device=dev)
+    T32 = torch.full(((N + 63) // 64 * 2 * S, M, 8), float("nan"), device=dev)     # per column tile (sized for 64-column tiles)
     Tout = torch.full((M, 8), float("nan"), device=dev)
     d = lib.GemmDesc(a0=p(x), w=p(w), bias=p(bias), c=p(c), lora_down=p(A), lora_up=p(up), lora_scale=p(scale), lda0=K, ca0=K,
                      mode=0, stride=1, ldw=K, M=M, N=N, K=K, ldc=N, rows_per_sample=M, ld_t=8, lora_groups=2, lora_rank=8,
-                     tile=tile, splitk_c32=p(ws), splitk_t32=p(T32), splitk_slabs=S, lora_t_out=p(Tout))
+                     tile=tile, splitk_c32=p(ws), splitk_t32=p(T32), splitk_slabs=S, lora_t_out=p(Tout), splitk_ticket=p(tickets))
     lib.call(lib.OP_GEMM, d, stream())
     torch.cuda.synchronize()
     T = x.float() @ A.float().t()
@@ -913,10 +971,11 @@ def test_gemm_splitk(dev, tile):
     x0, x1 = bf(_to_pix(i0.float())), bf(_to_pix(i1.float()))
     Mc = B * H * W
     cc = torch.zeros(Mc, Co, device=dev, dtype=torch.bfloat16)
-    wsc = torch.full((S, Mc, Co), float("nan"), device=dev)
+    wsc = torch.full((S, 256, 128), float("nan"), device=dev)
     d = lib.GemmDesc(a0=p(x0), a1=p(x1), w=p(_pack_conv(w4)), c=p(cc), lda0=C0, lda1=C1, ca0=C0, ca1=C1, mode=1, batch=B, hs=H,
                      ws=W, stride=1, ho=H, wo=W, ldw=9 * (C0 + C1), M=Mc, N=Co, K=9 * (C0 + C1), ldc=Co, rows_per_sample=H * W,
-                     tile=tile, splitk_c32=p(wsc), splitk_slabs=S)
+                     tile=tile, splitk_c32=p(wsc), splitk_slabs=S, splitk_ticket=p(tickets))
     lib.call(lib.OP_GEMM, d, stream())
     torch.cuda.synchronize()
     report(f"splitk conv 2src tile{tile:x}", cc, ref, TOL)
+    assert int(tickets.abs().sum()) == 0
