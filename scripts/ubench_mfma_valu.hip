@@ -56,6 +56,29 @@ __device__ __forceinline__ void interleaved(Work& w) {
     }
 }
 
+// attention-like dependent structure: 8 score MFMAs (2 chains of 4) -> 32 fma + 32 exp + 16 cvt on the RESULTS -> 8 MFMAs that
+// take the converted values as their B operand
+__device__ __forceinline__ void dependent(Work& w) {
+    f32x16 s0 = {0}, s1 = {0};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.a, w.b, s0, 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.b, w.a, s1, 0, 0, 0);
+    bf16x8 pb[4];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const float e0 = __builtin_amdgcn_exp2f(__builtin_fmaf(s0[r], 0.01f, -1.f));
+        const float e1 = __builtin_amdgcn_exp2f(__builtin_fmaf(s1[r], 0.01f, -1.f));
+        w.x[r] += e0 + e1;
+        pb[r >> 3][r & 7] = (__bf16)e0;
+        pb[2 + (r >> 3)][r & 7] = (__bf16)e1;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) w.acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.a, pb[i], w.acc[0], 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) w.acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.a, pb[i], w.acc[1], 0, 0, 0);
+}
+
 template <int mode>
 __global__ __launch_bounds__(1024) void bench(int iters, float* out, unsigned long long* clk) {
     Work w;
@@ -78,6 +101,7 @@ __global__ __launch_bounds__(1024) void bench(int iters, float* out, unsigned lo
         if constexpr (mode == 2 || mode == 13) exp32(w);
         if constexpr (mode == 3) pk32(w);
         if constexpr (mode == 4) interleaved(w);
+        if constexpr (mode >= 15) dependent(w);
         if constexpr (mode == 5 || mode == 8 || mode == 14) { mfma16(w); PIN; fma64(w); PIN; exp32(w); }   // the same work in blocks
         PIN;
     }
@@ -115,12 +139,14 @@ int main() {
                            "8 waves: w0-3 16 mfma | w4-7 64 fma + 32 exp", "8 waves: w4-7 64 fma + 32 exp, w0-3 idle",
                            "8 waves: all [16 mfma ; 64 fma ; 32 exp] free running", "8 waves: same, w4-7 in the opposite phase order",
                            "8 waves: all 16 mfma", "8 waves: all 64 v_fma_f32", "16 waves: all 64 v_fma_f32", "8 waves: all 32 v_exp_f32",
-                           "16 waves: all [16 mfma ; 64 fma ; 32 exp] free running"};
-    const int threads[] = {256, 256, 256, 256, 256, 256, 512, 512, 512, 512, 512, 512, 1024, 512, 1024};
+                           "16 waves: all [16 mfma ; 64 fma ; 32 exp] free running",
+                           "4 waves: [8 mfma -> 32 fma+32 exp+16 cvt on results -> 8 mfma]", "8 waves: the same dependent structure",
+                           "12 waves: the same dependent structure", "16 waves: the same dependent structure"};
+    const int threads[] = {256, 256, 256, 256, 256, 256, 512, 512, 512, 512, 512, 512, 1024, 512, 1024, 256, 512, 768, 1024};
     const int iters = 4000;
     typedef void (*kern_t)(int, float*, unsigned long long*);
-    const kern_t kerns[] = {bench<0>, bench<1>, bench<2>, bench<3>, bench<4>, bench<5>, bench<6>, bench<7>, bench<8>, bench<9>, bench<10>, bench<11>, bench<12>, bench<13>, bench<14>};
-    for (int mode = 0; mode < 15; ++mode) {
+    const kern_t kerns[] = {bench<0>, bench<1>, bench<2>, bench<3>, bench<4>, bench<5>, bench<6>, bench<7>, bench<8>, bench<9>, bench<10>, bench<11>, bench<12>, bench<13>, bench<14>, bench<15>, bench<16>, bench<17>, bench<18>};
+    for (int mode = 0; mode < 19; ++mode) {
         hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
         hipLaunchKernelGGL(kerns[mode], dim3(256), dim3(threads[mode]), 0, 0, 100, out, clk);
         hipDeviceSynchronize();
