@@ -69,8 +69,6 @@ def valid(d, tile):
         return False
     if d.ln_out and ni != 2:                    # folded LayerNorm: the producer writes 64-column chunk statistics
         return False
-    if d.lora_down and d.lora_up_rmajor and (tile >> 16) & 15:     # backward-data product with the adapter fused in
-        return False
     if wm == 4 and d.M * d.N < 256 * 128 * 32:
         return False
     return True

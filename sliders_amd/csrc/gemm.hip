@@ -1012,9 +1012,8 @@ extern "C" int slh_gemm(const slh_gemm_desc* d, slh_stream_t stream) {
         if (d->lora_up_rmajor) {
             // backward-data form: lora_down = the k-major copy of the up matrices ([rank][K], block-diagonal over a fused
             // q|k|v group), lora_up = the down matrices as stored ([rank][N]); U = dY . B leaves through lora_t_out
-            SLH_CHECK(d->lora_groups == 1 && (d->lora_rank == 4 || d->lora_rank == 8 || d->lora_rank == 12) &&
-                          ((d->tile >> 16) & 15) <= 1,
-                      "slh_gemm: fused r-major lora needs groups = 1, rank in {4, 8, 12}, no split-K");
+            SLH_CHECK(d->lora_groups == 1 && (d->lora_rank == 4 || d->lora_rank == 8 || d->lora_rank == 12),
+                      "slh_gemm: fused r-major lora needs groups = 1, rank in {4, 8, 12}");
         } else {
             SLH_CHECK(d->lora_groups >= 1 && d->lora_groups <= 3 && d->lora_rank == 4 * d->lora_groups &&
                           d->N % d->lora_groups == 0 && (d->N / d->lora_groups) % 4 == 0,

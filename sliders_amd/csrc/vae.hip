@@ -212,11 +212,14 @@ __global__ __launch_bounds__(256, 2) void sgemm_bf16x3_kernel(const slh_sgemm_de
         wok[e] = wnr < d.N;
         woff[e] = (long)(wok[e] ? wnr : d.N - 1) * d.ldw;
     }
+    // Every load is UNCONDITIONAL, from a selected address (the zero page for rows / taps that do not exist): a load behind a
+    // condition makes hipcc branch around it and wait vmcnt(0) at the join - inside the K loop that drained the three-step
+    // prefetch on every step (the loop then ran at the memory latency: 7100 cycles per step pair against ~1500 of MFMA).
+    const float* zero4 = (const float*)slh_zero_page;
     auto load_x = [&](int k0, f4* v) {
-        const f4 z = {0.f, 0.f, 0.f, 0.f};
         if (d.mode == 0) {
 #pragma unroll
-            for (int e = 0; e < XE; ++e) v[e] = xok[e] ? *(const f4*)(X + xoff[e] + k0 + 4 * k4) : z;
+            for (int e = 0; e < XE; ++e) v[e] = *(const f4*)(xok[e] ? X + xoff[e] + k0 + 4 * k4 : zero4);
         } else {
             const int tap = k0 / cin, c0 = k0 - tap * cin;
             const int ky = tap / 3, kx = tap - ky * 3;
@@ -225,14 +228,13 @@ __global__ __launch_bounds__(256, 2) void sgemm_bf16x3_kernel(const slh_sgemm_de
             for (int e = 0; e < XE; ++e) {
                 const int iy = xoy[e] * d.stride + ky - d.pad, ix = xox[e] * d.stride + kx - d.pad;
                 const bool ok = xok[e] && iy >= 0 && iy < (d.hs << sh) && ix >= 0 && ix < (d.ws << sh);
-                v[e] = ok ? *(const f4*)(X + (((long)xb[e] * d.hs + (iy >> sh)) * d.ws + (ix >> sh)) * d.ldx + c0 + 4 * k4) : z;
+                v[e] = *(const f4*)(ok ? X + (((long)xb[e] * d.hs + (iy >> sh)) * d.ws + (ix >> sh)) * d.ldx + c0 + 4 * k4 : zero4);
             }
         }
     };
     auto load_w = [&](int k0, f4* v) {
-        const f4 z = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = wok[e] ? *(const f4*)(W + woff[e] + k0 + 4 * k4) : z;
+        for (int e = 0; e < 4; ++e) v[e] = *(const f4*)(wok[e] ? W + woff[e] + k0 + 4 * k4 : zero4);
     };
     // 4 floats -> 8 bytes of bf16 high parts and 8 bytes of bf16 remainders (half k4 & 1 of 16-byte slot k4 >> 1)
     auto split_store4 = [&](const f4& a, char* hi_img, char* lo_img, int row) {
@@ -274,16 +276,18 @@ __global__ __launch_bounds__(256, 2) void sgemm_bf16x3_kernel(const slh_sgemm_de
     using I2 = std::integral_constant<int, 2>;
     load_x(0, xs[0]);
     load_w(0, ws[0]);
-    if (nk > 1) { load_x(TBK, xs[1]); load_w(TBK, ws[1]); }
-    if (nk > 2) { load_x(2 * TBK, xs[2]); load_w(2 * TBK, ws[2]); }
+    { const int k1 = nk > 1 ? 1 : 0; load_x(k1 * TBK, xs[1]); load_w(k1 * TBK, ws[1]); }
+    { const int k2 = nk > 2 ? 2 : nk - 1; load_x(k2 * TBK, xs[2]); load_w(k2 * TBK, ws[2]); }
     store_stage(I0{}, 0);
     __syncthreads();
     int cur = 0;
     auto step = [&](auto set_c, auto next_c, const int k) {
         constexpr int SET = decltype(set_c)::value;
-        if (k + 3 < nk && !(d.split_bf16 & 8)) {   // into the set step k just vacated
-            load_x((k + 3) * TBK, xs[SET]);
-            load_w((k + 3) * TBK, ws[SET]);
+        {   // into the set step k just vacated.  ALWAYS issued (the last steps re-request the final K tile): a conditional
+            // issue makes the number of loads in flight path-dependent and hipcc then waits for all of them
+            const int kn = k + 3 < nk ? k + 3 : nk - 1;
+            load_x(kn * TBK, xs[SET]);
+            load_w(kn * TBK, ws[SET]);
         }
         const char* base = smem + cur * BUF;
 #pragma unroll
@@ -317,11 +321,14 @@ __global__ __launch_bounds__(256, 2) void sgemm_bf16x3_kernel(const slh_sgemm_de
         __syncthreads();
         cur ^= 1;
     };
-    for (int k = 0; k < nk; k += 3) {
+    int k = 0;
+    for (; k + 2 < nk; k += 3) {          // whole triples: straight-line, the in-flight load count is the same on every path
         step(I0{}, I1{}, k);
-        if (k + 1 < nk) step(I1{}, I2{}, k + 1);
-        if (k + 2 < nk) step(I2{}, I0{}, k + 2);
+        step(I1{}, I2{}, k + 1);
+        step(I2{}, I0{}, k + 2);
     }
+    if (k < nk) step(I0{}, I1{}, k);
+    if (k + 1 < nk) step(I1{}, I2{}, k + 1);
     // acc[i][j][e] = C[m = m0 + wm*32*MI + i*32 + lrow][n = n0 + wn*64 + j*32 + (e&3) + 8*(e>>2) + 4*lhi]
     const float* bias = (const float*)d.bias;
     const float* res = (const float*)d.residual;

@@ -862,13 +862,10 @@ class BackwardPlan:
             Ts = T.ptr + 4 * self.b0 * (Ho * Wo) * 4 * ng
             # U = dY . B (the up matrices as a rank-4 down-projection of the output gradient): inside the backward-data GEMM
             # of a dense module - third operand tile = the k-major copy of B (LoraStore.up_t), written out through lora_t_out
-            # for the down-gradient - unless that product runs split-K or does not exist (no gradient needed upstream)
+            # for the down-gradient - unless that product does not exist (no gradient needed upstream)
             up_t_off = self.lora.up_t_offset(grp) if (self.fuse_u and conv is None and x1 is None and (need0 or need1)) else None
             if up_t_off is not None:
-                probe = lib.GemmDesc(M=Ms, N=x0.C, K=N, mode=0, stride=1)
-                probe.lora_down = 1
-                tile = tuned_tile(probe)
-                fused_u = not (((tile >> 16) & 15) > 1 or (not tile and splitk_wanted(probe)))
+                fused_u = True          # (split-K included: the slice that arrives last reduces T as well)
             if not fused_u:
                 for g_i, e in enumerate(grp):
                     d = lib.SkinnyDesc(a0=gy.ptr + 2 * g_i * Ng, w=self.lora.up_ptr(e), out=U.ptr + 4 * 4 * g_i, lda0=gy.ld,
@@ -923,8 +920,6 @@ class BackwardPlan:
                 else:
                     d.lora_t = U.ptr
             self._splitk(d, name)
-            if fused_u:
-                assert ((d.tile >> 16) & 15) <= 1, name
             self.prog.add(lib.OP_GEMM, d, name + ".dgrad")
             for dA, nm in dA_after:
                 self._wgrad(dA, nm, defer=True)

@@ -858,6 +858,21 @@ def test_gemm_fused_lora_backward_data_form(dev, tile):
         torch.cuda.synchronize()
         report(f"fused dgrad+lora groups{groups} tile{tile:x}", dx, ref, TOL)
         report(f"fused dgrad U groups{groups} tile{tile:x}", U, U_ref, 1e-5)
+        if tile in (0x4412, 0x22, 0x4322):
+            # K cut into slices: U's partials are reduced by the slice that arrives last, like the product's
+            S = 2
+            dx.zero_()
+            U.fill_(float("nan"))
+            slabs = torch.full((S, (M + 255) // 256 * 256, (Kf + 127) // 128 * 128), float("nan"), device=dev)
+            tslabs = torch.full(((Kf + 63) // 64 * 2 * S, M, 4 * groups), float("nan"), device=dev)
+            tickets = torch.zeros(((M + 63) // 64) * ((Kf + 63) // 64), device=dev, dtype=torch.int64)
+            d.tile = tile | (S << 16)
+            d.splitk_c32, d.splitk_t32, d.splitk_slabs, d.splitk_ticket = p(slabs), p(tslabs), S, p(tickets)
+            lib.call(lib.OP_GEMM, d, stream())
+            torch.cuda.synchronize()
+            report(f"fused dgrad+lora splitk groups{groups} tile{tile:x}", dx, ref, TOL)
+            report(f"fused dgrad U splitk groups{groups} tile{tile:x}", U, U_ref, 1e-5)
+            assert int(tickets.abs().sum()) == 0
 
 
 @pytest.mark.parametrize("tile", [0x22, 0x21, 0x12, 0x11, 0x311, 0x4022, 0x4322, 0x4012, 0x4011, 0x422, 0x421, 0x4412, 0x4411])
