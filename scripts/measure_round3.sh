@@ -8,7 +8,6 @@ export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out
 cd $R
-timeout 600 python bench.py > $O/r03_bench_line.json 2> $O/r03_bench_line.err
 cd /tmp
 timeout 500 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_bench -o bench -- python $R/bench.py --no-cpu-baseline --no-extra > $O/r03_prof_bench.log 2>&1
 find /tmp/prof_bench -name "*kernel_stats.csv" -exec cp {} $O/r03_bench_sdxl1024_kernel_stats.csv \;
@@ -23,6 +22,9 @@ timeout 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCL
 python $R/scripts/pmc_summary.py /tmp/pmc7 > $O/r03_pmc_mfma_busy_fwd_lora_on.csv 2>&1
 python $R/scripts/make_pmc_traffic.py $O/r03_pmc_fetch_size_fwd_lora_on.csv $O/r03_pmc_write_size_l2hit_fwd_lora_on.csv $O/r03_pmc_traffic.json ${R03_HEAD:-unrecorded}
 cd $R
+# the bench line reads the counter file of THIS tree (copied next to the sources on the box)
+cp $O/r03_pmc_traffic.json $R/profiles/r03_pmc_traffic.json
+timeout 600 python bench.py > $O/r03_bench_line.json 2> $O/r03_bench_line.err
 timeout 300 python scripts/time_train_iter.py --breakdown > $O/r03_iteration_pieces.txt 2>&1
 timeout 200 python scripts/probe_gn.py > $O/r03_probe_gn.txt 2>&1
 timeout 200 python scripts/probe_attn.py > $O/r03_probe_attn.txt 2>&1

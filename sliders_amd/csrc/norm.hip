@@ -368,47 +368,47 @@ __global__ void gn_bwd_apply_kernel(const slh_gn_bwd_desc d, int nchunk, int rpi
 }
 
 // ---- LayerNorm: one wave per row, up to 3 x 8 elements per lane (C <= 1536) -------------------------
+// Every load is unconditional, at a clamped column (lanes past C re-read column 0 and mask the value): a load behind
+// `if (c < C)` makes hipcc branch around it and wait vmcnt(0) at the join, i.e. three serial memory round trips per row
+// instead of one (norm.s before: load / vmcnt(0) / load / vmcnt(0) / load / vmcnt(0)).  gamma / beta are requested with x.
 __global__ __launch_bounds__(256) void layernorm_kernel(const slh_ln_desc d) {
     const int lane = threadIdx.x & 63;
     const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (m >= d.M) return;
     const __bf16* x = (const __bf16*)d.x + (long)m * d.ldx;
+    bf16x8 xv[3], gv[3], bv[3];
+    bool in[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const int c = (lane + 64 * j) * 8;
+        in[j] = c < d.C;
+        const int cc = in[j] ? c : 0;
+        xv[j] = *(const bf16x8*)(x + cc);
+        gv[j] = *(const bf16x8*)((const __bf16*)d.gamma + cc);
+        bv[j] = *(const bf16x8*)((const __bf16*)d.beta + cc);
+    }
     float v[3][8];
     float sum = 0.f;
 #pragma unroll
-    for (int j = 0; j < 3; ++j) {
-        const int c = (lane + 64 * j) * 8;
-        if (c < d.C) {
-            const bf16x8 t = *(const bf16x8*)(x + c);
+    for (int j = 0; j < 3; ++j)
 #pragma unroll
-            for (int e = 0; e < 8; ++e) { v[j][e] = (float)t[e]; sum += v[j][e]; }
-        } else {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[j][e] = 0.f;
-        }
-    }
+        for (int e = 0; e < 8; ++e) { v[j][e] = in[j] ? (float)xv[j][e] : 0.f; sum += v[j][e]; }
     const float mean = wave_sum(sum) / (float)d.C;
     float sq = 0.f;
 #pragma unroll
-    for (int j = 0; j < 3; ++j) {
-        const int c = (lane + 64 * j) * 8;
-        if (c < d.C) {
+    for (int j = 0; j < 3; ++j)
 #pragma unroll
-            for (int e = 0; e < 8; ++e) { const float t = v[j][e] - mean; sq += t * t; }
-        }
-    }
+        for (int e = 0; e < 8; ++e) { const float t = in[j] ? v[j][e] - mean : 0.f; sq += t * t; }
     const float rstd = rsqrtf(wave_sum(sq) / (float)d.C + d.eps);
     if (d.mean_rstd && lane == 0) { d.mean_rstd[(long)m * 2] = mean; d.mean_rstd[(long)m * 2 + 1] = rstd; }
     __bf16* y = (__bf16*)d.y + (long)m * d.ldy;
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
         const int c = (lane + 64 * j) * 8;
-        if (c < d.C) {
-            const bf16x8 g = *(const bf16x8*)((const __bf16*)d.gamma + c);
-            const bf16x8 bt = *(const bf16x8*)((const __bf16*)d.beta + c);
+        if (in[j]) {
             bf16x8 o;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) o[e] = (__bf16)((v[j][e] - mean) * rstd * (float)g[e] + (float)bt[e]);
+            for (int e = 0; e < 8; ++e) o[e] = (__bf16)((v[j][e] - mean) * rstd * (float)gv[j][e] + (float)bv[j][e]);
             *(bf16x8*)(y + c) = o;
         }
     }
@@ -420,36 +420,40 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const slh_ln_bwd_des
     if (m >= d.M) return;
     const __bf16* x = (const __bf16*)d.x + (long)m * d.ldx;
     const __bf16* dy = (const __bf16*)d.dy + (long)m * d.lddy;
+    __bf16* dx = (__bf16*)d.dx + (long)m * d.lddx;
+    bf16x8 xv[3], gv[3], dv[3], ov[3];
+    bool in[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {         // unconditional loads at clamped columns (see layernorm_kernel)
+        const int c = (lane + 64 * j) * 8;
+        in[j] = c < d.C;
+        const int cc = in[j] ? c : 0;
+        xv[j] = *(const bf16x8*)(x + cc);
+        gv[j] = *(const bf16x8*)((const __bf16*)d.gamma + cc);
+        dv[j] = *(const bf16x8*)(dy + cc);
+        ov[j] = *(const bf16x8*)(dx + (d.accumulate ? cc : 0));      // read only where it is accumulated into
+    }
     const float mean = d.mean_rstd[(long)m * 2], rstd = d.mean_rstd[(long)m * 2 + 1];
     float xh[3][8], dyh[3][8];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-    for (int j = 0; j < 3; ++j) {
-        const int c = (lane + 64 * j) * 8;
-        if (c < d.C) {
-            const bf16x8 xv = *(const bf16x8*)(x + c);
-            const bf16x8 gv = *(const bf16x8*)((const __bf16*)d.gamma + c);
-            const bf16x8 dv = *(const bf16x8*)(dy + c);
+    for (int j = 0; j < 3; ++j)
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                xh[j][e] = ((float)xv[e] - mean) * rstd;
-                dyh[j][e] = (float)dv[e] * (float)gv[e];
-                s1 += dyh[j][e]; s2 += dyh[j][e] * xh[j][e];
-            }
+        for (int e = 0; e < 8; ++e) {
+            xh[j][e] = in[j] ? ((float)xv[j][e] - mean) * rstd : 0.f;
+            dyh[j][e] = in[j] ? (float)dv[j][e] * (float)gv[j][e] : 0.f;
+            s1 += dyh[j][e]; s2 += dyh[j][e] * xh[j][e];
         }
-    }
     const float m1 = wave_sum(s1) / (float)d.C, m2 = wave_sum(s2) / (float)d.C;
-    __bf16* dx = (__bf16*)d.dx + (long)m * d.lddx;
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
         const int c = (lane + 64 * j) * 8;
-        if (c < d.C) {
+        if (in[j]) {
             bf16x8 o;
-            if (d.accumulate) o = *(const bf16x8*)(dx + c);
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 float v = rstd * (dyh[j][e] - m1 - xh[j][e] * m2);
-                if (d.accumulate) v += (float)o[e];
+                if (d.accumulate) v += (float)ov[j][e];
                 o[e] = (__bf16)v;
             }
             *(bf16x8*)(dx + c) = o;

@@ -62,7 +62,6 @@ __global__ __launch_bounds__(256) void sgemm_kernel(const slh_sgemm_desc d) {
     }
     const int cin = d.cin;
     auto load_x = [&](int k0, f4& a, f4& b) {
-        const f4 z = {0.f, 0.f, 0.f, 0.f};
         const float* src;
         bool ok = xvalid;
         if (d.mode == 0) {
@@ -75,14 +74,16 @@ __global__ __launch_bounds__(256) void sgemm_kernel(const slh_sgemm_desc d) {
             ok = ok && iy >= 0 && iy < (d.hs << sh) && ix >= 0 && ix < (d.ws << sh);
             src = X + (((long)xb * d.hs + (iy >> sh)) * d.ws + (ix >> sh)) * d.ldx + c0;
         }
-        a = ok ? *(const f4*)(src + 4 * kq) : z;
-        b = ok ? *(const f4*)(src + 4 * (kq + 2)) : z;
+        // unconditional loads from a selected address (see sgemm_bf16x3_kernel: a load behind a condition costs a vmcnt(0))
+        const float* sa = ok ? src + 4 * kq : (const float*)slh_zero_page;
+        const float* sb = ok ? src + 4 * (kq + 2) : (const float*)slh_zero_page;
+        a = *(const f4*)sa;
+        b = *(const f4*)sb;
     };
     auto load_w = [&](int k0, f4& a, f4& b) {
-        const f4 z = {0.f, 0.f, 0.f, 0.f};
         const float* src = W + (long)wnr * d.ldw + k0;
-        a = wvalid ? *(const f4*)(src + 4 * kq) : z;
-        b = wvalid ? *(const f4*)(src + 4 * (kq + 2)) : z;
+        a = *(const f4*)(wvalid ? src + 4 * kq : (const float*)slh_zero_page);
+        b = *(const f4*)(wvalid ? src + 4 * (kq + 2) : (const float*)slh_zero_page);
     };
     f32x16 acc[2][2];
 #pragma unroll
