@@ -79,8 +79,8 @@ __global__ __launch_bounds__(128 * WM, gemm_waves_per_simd(MI, NI, STAGES, LORA,
     // operand tile; every wave multiplies it with the X fragments it already holds, so T = X.A^T of the block's own
     // rows is available in registers for the epilogue without a separate pass over X (lora.py:108-112 fused).
     constexpr int LROWS = LORA ? 32 : 0;
-    static_assert(!LORA || 2 * WM * (2048 * NI + 2048 * MI) <= STAGES * (32 * MI * WM + 64 * NI + 32) * 128,
-                  "epilogue patches + adapter exchange must fit the operand stages");
+    static_assert(2 * WM * (2048 * NI + (LORA ? 2048 * MI : 0)) + 4 * BN * 4 <= STAGES * (BM + BN + LROWS) * 128,
+                  "epilogue patches + adapter exchange + column vectors must fit the operand stages");
     __shared__ __attribute__((aligned(16))) char smem[STAGES * (BM + BN + LROWS) * 128];
     char* sX = smem;                        // [STAGES][BM][128 B]
     char* sW = smem + STAGES * BM * 128;    // [STAGES][BN][128 B]
@@ -638,9 +638,31 @@ __global__ __launch_bounds__(128 * WM, gemm_waves_per_simd(MI, NI, STAGES, LORA,
         if (local) reduce(std::true_type{});
         else reduce(std::false_type{});
     }
+    // ---- per-column epilogue vectors (bias, per-sample row bias, LayerNorm-fold s / b'), once per workgroup through LDS -------
+    // Read per accumulator quad from global memory they were 4-16 SERIAL round trips at the end of every tile (each load sat
+    // behind a condition: hipcc waits vmcnt(0) at the join); a tile's columns share them, so one thread per column fetches its
+    // four values in one round trip, behind the patches of the store staging.  A row bias qualifies when the tile's rows belong
+    // to one sample (rows_per_sample a multiple of the tile height); otherwise it stays a per-row load below.
+    constexpr int S = 4 * NI;                  // 16-byte slots per staged row
+    constexpr int LOG2S = NI == 2 ? 3 : 2;
+    float* sCol = (float*)(smem + NW * (32 * S * 16) + (LORA ? NW * MI * 2048 : 0));     // [4][BN]
+    const bool rb_tile = p.rowbias != nullptr && p.rows_per_sample % BM == 0;
+    {
+        const int n = n0 + tid;
+        const bool nok = tid < BN && n < p.N;
+        const __bf16* zb = (const __bf16*)slh_zero_page;
+        const float* zf = (const float*)slh_zero_page;
+        const float c0 = (float)*((p.bias && nok) ? p.bias + n : zb);
+        const float c1 = (float)*((rb_tile && nok) ? p.rowbias + (long)(m0 / p.rows_per_sample) * p.ld_rowbias + n : zb);
+        const float c2 = *((ln_on && nok) ? p.ln_s + n : zf);
+        const float c3 = *((ln_on && nok) ? p.ln_b + n : zf);
+        __syncthreads();                       // every wave is done reading the operand stages being reused below
+        if (tid < BN) { sCol[tid] = c0; sCol[BN + tid] = c1; sCol[2 * BN + tid] = c2; sCol[3 * BN + tid] = c3; }
+    }
     if (p.geglu) {
         // GEGLU: W rows are stored in 64-row blocks [32 value rows | 32 gate rows]; NI is 2 here, so
         // sub-tile j=0 holds the values and j=1 the gates of the same 32 output columns.
+        __syncthreads();
         if (NI == 2) {
 #pragma unroll
             for (int i = 0; i < MI; ++i) {
@@ -654,9 +676,10 @@ __global__ __launch_bounds__(128 * WM, gemm_waves_per_simd(MI, NI, STAGES, LORA,
                     float a[4], g[4];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) { a[e] = acc[i][0][q * 4 + e]; g[e] = acc[i][NI - 1][q * 4 + e]; }
+                    const int cl = n - n0;                                  // column inside the tile
                     if (MODE == 0 && ln_on) {
-                        const f32x4 sa = *(const f32x4*)(p.ln_s + n), sg = *(const f32x4*)(p.ln_s + n + 32);
-                        const f32x4 ba = *(const f32x4*)(p.ln_b + n), bg = *(const f32x4*)(p.ln_b + n + 32);
+                        const f32x4 sa = *(const f32x4*)(sCol + 2 * BN + cl), sg = *(const f32x4*)(sCol + 2 * BN + cl + 32);
+                        const f32x4 ba = *(const f32x4*)(sCol + 3 * BN + cl), bg = *(const f32x4*)(sCol + 3 * BN + cl + 32);
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
                             a[e] = ln_rstd[i] * (a[e] - ln_mean[i] * sa[e]) + ba[e];
@@ -664,10 +687,9 @@ __global__ __launch_bounds__(128 * WM, gemm_waves_per_simd(MI, NI, STAGES, LORA,
                         }
                     }
                     if (p.bias) {
-                        const bf16x4 ba = *(const bf16x4*)(p.bias + n);
-                        const bf16x4 bg = *(const bf16x4*)(p.bias + n + 32);
+                        const f32x4 ba = *(const f32x4*)(sCol + cl), bg = *(const f32x4*)(sCol + cl + 32);
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) { a[e] += (float)ba[e]; g[e] += (float)bg[e]; }
+                        for (int e = 0; e < 4; ++e) { a[e] += ba[e]; g[e] += bg[e]; }
                     }
                     bf16x4 o;
 #pragma unroll
@@ -686,9 +708,6 @@ __global__ __launch_bounds__(128 * WM, gemm_waves_per_simd(MI, NI, STAGES, LORA,
     // The MFMA result layout gives a lane 4 consecutive columns of ONE row, so a direct store touches 32 rows per
     // instruction with 8-byte pieces (store-issue bound).  Each wave therefore transposes its 32 x (32*NI) sub-tile
     // through a private, swizzled LDS patch and writes whole 64/128-byte row segments with 16-byte stores.
-    constexpr int S = 4 * NI;                  // 16-byte slots per staged row
-    constexpr int LOG2S = NI == 2 ? 3 : 2;
-    __syncthreads();                           // every wave is done reading the operand stages being reused below
     if (LORA) {
         // T = x . A^T of a row block was accumulated half by each of the two waves that own those rows (wn = 0 took the
         // even k-steps, wn = 1 the odd ones: the adapter costs half an MFMA per k-step and wave instead of one); the
@@ -703,6 +722,8 @@ __global__ __launch_bounds__(128 * WM, gemm_waves_per_simd(MI, NI, STAGES, LORA,
         for (int i = 0; i < MI; ++i)
 #pragma unroll
             for (int r = 0; r < 8; ++r) accl[i][r] += ex[((wave ^ 1) * MI * 8 + i * 8 + r) * 64 + lane];
+    } else {
+        __syncthreads();                       // the column vectors are in LDS
     }
     char* sE = smem + wave * (32 * S * 16);
     const float lscale = (LORA || p.lora_t != nullptr) ? *p.lora_scale : 0.f;
@@ -771,26 +792,44 @@ __global__ __launch_bounds__(128 * WM, gemm_waves_per_simd(MI, NI, STAGES, LORA,
             for (int g = 0; g < 3; ++g)
                 if (g * 4 < p.ld_t) tv[g] = *(const f32x4*)(p.lora_t + (long)m * p.ld_t + g * 4);
         }
-        const __bf16* rb = (p.rowbias && mok) ? p.rowbias + (long)(m / p.rows_per_sample) * p.ld_rowbias : nullptr;
+        // a row bias whose tile spans samples stays a per-row load
+        const __bf16* rb = (p.rowbias && !rb_tile && mok) ? p.rowbias + (long)(m / p.rows_per_sample) * p.ld_rowbias : nullptr;
         const int hb = (lrow >> LOG2S) & 1;
+        // the residual quads of the whole 32-row block are requested together (one round trip instead of one per quad)
+        bf16x4 res4[NI][4];
+        if (p.residual) {
+#pragma unroll
+            for (int j = 0; j < NI; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int n = ncol0 + j * 32 + q * 8 + lhi * 4;
+                    res4[j][q] = *((mok && n < p.N) ? (const bf16x4*)(p.residual + (long)m * p.ld_res + n) : (const bf16x4*)slh_zero_page);
+                }
+        }
 #pragma unroll
         for (int j = 0; j < NI; ++j) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int n = ncol0 + j * 32 + q * 8 + lhi * 4;
+                const int cl = n - n0;                                      // column inside the tile
                 float v[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = acc[i][j][q * 4 + e];
                 if (mok && n < p.N) {
                     if (MODE == 0 && ln_on) {
-                        const f32x4 s4 = *(const f32x4*)(p.ln_s + n), b4 = *(const f32x4*)(p.ln_b + n);
+                        const f32x4 s4 = *(const f32x4*)(sCol + 2 * BN + cl), b4 = *(const f32x4*)(sCol + 3 * BN + cl);
 #pragma unroll
                         for (int e = 0; e < 4; ++e) v[e] = ln_rstd[i] * (v[e] - ln_mean[i] * s4[e]) + b4[e];
                     }
                     if (p.bias) {
-                        const bf16x4 b4 = *(const bf16x4*)(p.bias + n);
+                        const f32x4 b4 = *(const f32x4*)(sCol + cl);
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] += (float)b4[e];
+                        for (int e = 0; e < 4; ++e) v[e] += b4[e];
+                    }
+                    if (rb_tile) {
+                        const f32x4 b4 = *(const f32x4*)(sCol + BN + cl);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] += b4[e];
                     }
                     if (rb) {
                         const bf16x4 b4 = *(const bf16x4*)(rb + n);
@@ -824,9 +863,8 @@ __global__ __launch_bounds__(128 * WM, gemm_waves_per_simd(MI, NI, STAGES, LORA,
                         for (int e = 0; e < 4; ++e) v[e] += lscale * s4[e];
                     }
                     if (p.residual) {
-                        const bf16x4 r4 = *(const bf16x4*)(p.residual + (long)m * p.ld_res + n);
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] += (float)r4[e];
+                        for (int e = 0; e < 4; ++e) v[e] += (float)res4[j][q][e];
                     }
                 }
                 bf16x4 o;
