@@ -34,8 +34,7 @@ __global__ __launch_bounds__(256) void skinny_kernel(AddrArgs A, const __bf16* _
     for (int r = 0; r < RMAX; ++r) acc[r] = 0.f;
     const int cin = A.ca0 + A.ca1;
 
-    auto fma_chunk = [&](const __bf16* src, int k) {
-        const bf16x8 x = *(const bf16x8*)src;
+    auto fma_chunk = [&](const bf16x8 x, int k) {
         float xf[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) xf[e] = (float)x[e];
@@ -54,21 +53,30 @@ __global__ __launch_bounds__(256) void skinny_kernel(AddrArgs A, const __bf16* _
             }
             return;
         }
+        bf16x8 wv[RMAX];        // requested together, unconditionally (rows past R re-read row 0 and are not accumulated)
+#pragma unroll
+        for (int r = 0; r < RMAX; ++r) wv[r] = *(const bf16x8*)(w + (long)(r < R ? r : 0) * K + k);
 #pragma unroll
         for (int r = 0; r < RMAX; ++r) {
             if (r < R) {
-                const bf16x8 wv = *(const bf16x8*)(w + (long)r * K + k);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) acc[r] += xf[e] * (float)wv[e];
+                for (int e = 0; e < 8; ++e) acc[r] += xf[e] * (float)wv[r][e];
             }
         }
     };
 
+    // The activation chunk of step s+1 is requested before the products of step s (one register of lookahead): the loop is a
+    // chain of dependent global round trips otherwise (a row's K / (8 LPR) chunks one after the other).
     if (A.mode == 0) {
+        auto src_of = [&](int k) {
+            const int kc = k < K ? k : sub * 8;
+            return kc < A.ca0 ? A.a0 + (long)mm * A.lda0 + kc : A.a1 + (long)mm * A.lda1 + (kc - A.ca0);
+        };
+        bf16x8 cur = *(const bf16x8*)src_of(sub * 8);
         for (int k = sub * 8; k < K; k += LPR * 8) {
-            const __bf16* src = k < A.ca0 ? A.a0 + (long)mm * A.lda0 + k
-                                          : A.a1 + (long)mm * A.lda1 + (k - A.ca0);
-            fma_chunk(src, k);
+            const bf16x8 nxt = *(const bf16x8*)src_of(k + LPR * 8);
+            fma_chunk(cur, k);
+            cur = nxt;
         }
     } else {
         const int hw = A.ho * A.wo;
@@ -84,9 +92,15 @@ __global__ __launch_bounds__(256) void skinny_kernel(AddrArgs A, const __bf16* _
             if (A.src_xform == 2) ok = ok & (((iy | ix) & 1) == 0);
             if (!ok) continue;
             const long pix = ((long)b * A.hs + (iy >> sh)) * A.ws + (ix >> sh);
+            auto src_of = [&](int c) {
+                const int cc = c < cin ? c : sub * 8;
+                return cc < A.ca0 ? A.a0 + pix * A.lda0 + cc : A.a1 + pix * A.lda1 + (cc - A.ca0);
+            };
+            bf16x8 cur = *(const bf16x8*)src_of(sub * 8);
             for (int c = sub * 8; c < cin; c += LPR * 8) {
-                const __bf16* src = c < A.ca0 ? A.a0 + pix * A.lda0 + c : A.a1 + pix * A.lda1 + (c - A.ca0);
-                fma_chunk(src, tap * cin + c);
+                const bf16x8 nxt = *(const bf16x8*)src_of(c + LPR * 8);
+                fma_chunk(cur, tap * cin + c);
+                cur = nxt;
             }
         }
     }
@@ -125,18 +139,22 @@ __global__ __launch_bounds__(256) void gemv_kernel(const slh_gemv_desc d) {
     float acc[8];
 #pragma unroll
     for (int b = 0; b < 8; ++b) acc[b] = 0.f;
+    // all loads of a k step are issued together and unconditionally (samples past nb re-read the last one and are masked): a
+    // load behind `if (b < nb)` is branched around by hipcc with a vmcnt(0) at the join - ten serial round trips for K = 1280
     for (int k = lane * 8; k < d.K; k += 512) {
         const bf16x8 wv = *(const bf16x8*)(w + k);
+        bf16x8 xv[8];
+#pragma unroll
+        for (int b = 0; b < 8; ++b) xv[b] = *(const bf16x8*)(x + (long)(b < d.nb ? b : d.nb - 1) * d.ldx + k);
         float wf[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) wf[e] = (float)wv[e];
 #pragma unroll
         for (int b = 0; b < 8; ++b) {
-            if (b < d.nb) {
-                const bf16x8 xv = *(const bf16x8*)(x + (long)b * d.ldx + k);
+            if (b < d.nb) {          // (the accumulation order of a sample is what it was: no arithmetic on the masked ones)
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
-                    float xe = (float)xv[e];
+                    float xe = (float)xv[b][e];
                     if (d.in_act == 1) xe = round_bf16(silu_f(xe));  // reference: nonlinearity(temb) in bf16
                     acc[b] += xe * wf[e];
                 }

@@ -52,14 +52,41 @@ __global__ void conv_in_kernel(const slh_convin_desc d, int nchunk, int ppb) {
         float acc[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) acc[e] = bias[e];
-        for (int tap = 0; tap < 9; ++tap) {
-            const int iy = oy + tap / 3 - 1, ix = ox + tap % 3 - 1;
-            if (iy < 0 || iy >= d.h || ix < 0 || ix >= d.wd) continue;
-            for (int ci = 0; ci < d.cin; ++ci) {
-                const float xv = (float)x[(long)ci * hw + iy * d.wd + ix];
-                const bf16x8 wv = *(const bf16x8*)(sw + (tap * d.cin + ci) * d.cout + chunk * 8);
+        if (d.cin <= 4) {
+            // the pixel's 9 x cin inputs are requested together, unconditionally (clamped coordinates, masked afterwards): as
+            // 36 loads each behind the bounds test they were 36 serial round trips per pixel (hipcc waits at every join)
+            __bf16 xin[9][4];
+            bool tin[9];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) acc[e] += xv * (float)wv[e];
+            for (int tap = 0; tap < 9; ++tap) {
+                const int iy = oy + tap / 3 - 1, ix = ox + tap % 3 - 1;
+                tin[tap] = iy >= 0 && iy < d.h && ix >= 0 && ix < d.wd;
+                const int cy = iy < 0 ? 0 : (iy >= d.h ? d.h - 1 : iy), cx = ix < 0 ? 0 : (ix >= d.wd ? d.wd - 1 : ix);
+#pragma unroll
+                for (int ci = 0; ci < 4; ++ci) xin[tap][ci] = x[(long)(ci < d.cin ? ci : 0) * hw + cy * d.wd + cx];
+            }
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) {
+                if (!tin[tap]) continue;
+#pragma unroll
+                for (int ci = 0; ci < 4; ++ci) {
+                    if (ci >= d.cin) break;
+                    const float xv = (float)xin[tap][ci];
+                    const bf16x8 wv = *(const bf16x8*)(sw + (tap * d.cin + ci) * d.cout + chunk * 8);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) acc[e] += xv * (float)wv[e];
+                }
+            }
+        } else {
+            for (int tap = 0; tap < 9; ++tap) {
+                const int iy = oy + tap / 3 - 1, ix = ox + tap % 3 - 1;
+                if (iy < 0 || iy >= d.h || ix < 0 || ix >= d.wd) continue;
+                for (int ci = 0; ci < d.cin; ++ci) {
+                    const float xv = (float)x[(long)ci * hw + iy * d.wd + ix];
+                    const bf16x8 wv = *(const bf16x8*)(sw + (tap * d.cin + ci) * d.cout + chunk * 8);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) acc[e] += xv * (float)wv[e];
+                }
             }
         }
         bf16x8 o;
