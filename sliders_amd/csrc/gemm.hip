@@ -154,6 +154,16 @@ __global__ __launch_bounds__(128 * WM, gemm_waves_per_simd(MI, NI, STAGES, LORA,
     }
     const int wkstep = p.w_packed ? 4096 : BK;   // elements between consecutive K tiles of one W row group
 
+    // 2-slot loop: the copies are issued from inline asm (glds16_hidden) - a compiler-visible LDS-DMA makes hipcc treat the
+    // LGKM counter as out of order and wait lgkmcnt(0) in front of every MFMA, which defeats the register double-buffering of
+    // the fragment reads in compute() (SLH_GEMM_VISIBLE_STAGE restores the builtin for A/B)
+    auto stage_copy = [&](const void* src, void* lds_dst) {
+#ifdef SLH_GEMM_VISIBLE_STAGE
+        glds16(src, lds_dst);
+#else
+        glds16_hidden(src, lds_addr_of(lds_dst));
+#endif
+    };
     auto stage = [&](int buf, int kt) {
         const int k0 = kt * BK;
         char* dX = sX + buf * (BM * 128);
@@ -165,7 +175,7 @@ __global__ __launch_bounds__(128 * WM, gemm_waves_per_simd(MI, NI, STAGES, LORA,
 #pragma unroll
             for (int i = 0; i < XI; ++i) {
                 const __bf16* src = base + (s1 ? xrow_off1[i] : xrow_off0[i]) + kk + (xks[i] << 3);
-                glds16(src, dX + (wave + NW * i) * 1024);
+                stage_copy(src, dX + (wave + NW * i) * 1024);
             }
         } else {
             const int tap = k0 / cin;
@@ -187,17 +197,17 @@ __global__ __launch_bounds__(128 * WM, gemm_waves_per_simd(MI, NI, STAGES, LORA,
                 const long pix = ((long)xb[i] * p.hs + sy) * p.ws + sx;
                 const __bf16* src = ok ? base + pix * ld + cc + (xks[i] << 3)
                                        : (const __bf16*)slh_zero_page;
-                glds16(src, dX + (wave + NW * i) * 1024);
+                stage_copy(src, dX + (wave + NW * i) * 1024);
             }
         }
 #pragma unroll
-        for (int i = 0; i < WI; ++i) glds16(wptr[i] + (long)kt * wkstep, dW + (wave + NW * i) * 1024);
+        for (int i = 0; i < WI; ++i) stage_copy(wptr[i] + (long)kt * wkstep, dW + (wave + NW * i) * 1024);
         if (LORA) {
             const int row = (wave & 3) * 8 + frow;   // with 8 waves the upper four re-issue the same rows (benign)
             const __bf16* src = row < p.lora_rank
                                     ? p.lora_down + (long)row * p.K + k0 + ((fslot ^ ((row >> 1) & 7)) << 3)
                                     : (const __bf16*)slh_zero_page;
-            glds16(src, sL + buf * (32 * 128) + (wave & 3) * 1024);
+            stage_copy(src, sL + buf * (32 * 128) + (wave & 3) * 1024);
         }
     };
 
