@@ -25,11 +25,25 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "sliders_amd", "csrc")
 
 
+def per_file_flags(src):
+    """Target-specific CXXFLAGS of the library's Makefile (`$(OBJDIR)/<name>.o: CXXFLAGS += ...`): the checks must look at the
+    code the build produces, not at a differently-flagged compile of the same source."""
+    base = os.path.splitext(os.path.basename(src))[0]
+    mk = os.path.join(os.path.dirname(os.path.abspath(src)), "Makefile")
+    flags = []
+    if os.path.exists(mk):
+        for line in open(mk):
+            m = re.match(r"\$\(OBJDIR\)/" + re.escape(base) + r"\.o:\s*CXXFLAGS\s*\+=\s*(.*)", line)
+            if m:
+                flags += m.group(1).split()
+    return flags
+
+
 def device_asm(src):
     src = os.path.abspath(src)
     out = tempfile.mkdtemp(prefix="ldsdma_")
     base = os.path.splitext(os.path.basename(src))[0]
-    subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I", os.path.join(ROOT, "include"),
+    subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", *per_file_flags(src), "-I", os.path.join(ROOT, "include"),
                     "-c", src, "-o", os.path.join(out, base + ".o"), "-save-temps=obj"],
                    check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, cwd=out)
     for f in os.listdir(out):
@@ -106,6 +120,30 @@ def check_kernel(body):
                 pending_in[j] = pending_in[j] or p
                 work.append(j)
     return [(i, ins[i]) for i in range(len(ins)) if ins[i].startswith("s_barrier") and pending_in[i]]
+
+
+def serial_load_sites(body):
+    """(sites, loads): global / buffer loads that are waited for with vmcnt(0) before another load is issued - the signature of
+    hipcc branching around a load that sits behind a condition (`if (c < C) v = *p;`) and waiting at the join: N such loads
+    are N serial memory round trips.  Kernels avoid it with unconditional loads from a selected / clamped address."""
+    ins = []
+    for l in body.split("\n"):
+        t = l.strip()
+        if not t or t.startswith(";") or t.startswith("."):
+            continue
+        ins.append(t.split(";")[0].strip())
+    is_load = lambda t: t.startswith(("global_load", "buffer_load")) and "_lds" not in t.split()[0]
+    hits = 0
+    for i, t in enumerate(ins):
+        if not is_load(t):
+            continue
+        for k in range(1, 4):
+            if i + k >= len(ins) or is_load(ins[i + k]):
+                break
+            if ins[i + k].startswith("s_waitcnt") and "vmcnt(0)" in ins[i + k]:
+                hits += 1
+                break
+    return hits, sum(1 for t in ins if is_load(t))
 
 
 STRICT = False

@@ -154,14 +154,14 @@ __global__ __launch_bounds__(128 * WM, gemm_waves_per_simd(MI, NI, STAGES, LORA,
     }
     const int wkstep = p.w_packed ? 4096 : BK;   // elements between consecutive K tiles of one W row group
 
-    // 2-slot loop: the copies are issued from inline asm (glds16_hidden) - a compiler-visible LDS-DMA makes hipcc treat the
-    // LGKM counter as out of order and wait lgkmcnt(0) in front of every MFMA, which defeats the register double-buffering of
-    // the fragment reads in compute() (SLH_GEMM_VISIBLE_STAGE restores the builtin for A/B)
+    // 2-slot loop: compiler-visible LDS-DMA.  (Issued from inline asm like the deep ring - SLH_GEMM_HIDDEN_STAGE - hipcc counts
+    // lgkmcnt in front of the MFMAs instead of waiting lgkmcnt(0), but the pass time did not change in a same-box A/B, and the
+    // compiler's own vmcnt(0) in front of the epilogue barriers, which scripts/check_lds_dma_waits.py relies on, goes away.)
     auto stage_copy = [&](const void* src, void* lds_dst) {
-#ifdef SLH_GEMM_VISIBLE_STAGE
-        glds16(src, lds_dst);
-#else
+#ifdef SLH_GEMM_HIDDEN_STAGE
         glds16_hidden(src, lds_addr_of(lds_dst));
+#else
+        glds16(src, lds_dst);
 #endif
     };
     auto stage = [&](int buf, int kt) {

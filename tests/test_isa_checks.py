@@ -69,3 +69,19 @@ def test_no_kernel_spills_to_scratch(src):
     for name, r in res.items():
         assert r["scratch"] == 0, (name, r)
         assert r["lds"] <= 160 * 1024, (name, r)
+
+
+@pytest.mark.skipif(shutil.which("hipcc") is None, reason="hipcc not on PATH")
+def test_row_kernels_issue_their_loads_together():
+    """LayerNorm forward / backward read a row as up to three 16-byte chunks per lane (+ gamma / beta / dy): as loads behind
+    `if (c < C)` hipcc emitted load / s_waitcnt vmcnt(0) three times in a row - three serial round trips per row.  The kernels
+    load unconditionally at clamped columns; this guards the compiled code against the pattern coming back."""
+    asm = _asm("norm.hip")
+    seen = 0
+    for name, body in chk.kernels(asm):
+        if "layernorm" not in name:
+            continue
+        seen += 1
+        sites, loads = chk.serial_load_sites(body)
+        assert loads >= 9 and sites == 0, (name, sites, loads)
+    assert seen == 2
