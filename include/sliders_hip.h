@@ -114,6 +114,12 @@ typedef struct slh_gemm_desc {
     float ln_eps;
     void* splitk_ticket;     /* with S > 1: one 64-bit arrival ticket per output tile ([ceil(M/64) * ceil(N/64)] is enough for
                                 every tile shape), zero before the first launch, left zero by every launch */
+    float* ln_mr_out;        /* with ln_in, optional: [M][2] fp32 receives the merged (mean, rstd) of every row - what
+                                slh_layernorm would have left in mean_rstd for slh_layernorm_bwd (training passes) */
+    void* geglu_pre;         /* with geglu, optional: [M][ld_pre] bf16 receives proj(x) itself (bf16-rounded, this product's
+                                column order = what the same call without geglu writes to c) for slh_elementwise GEGLU_BWD */
+    int32_t ld_pre;
+    int32_t reserved2_;
 } slh_gemm_desc;
 int slh_gemm(const slh_gemm_desc* d, slh_stream_t stream);
 /* (WM<<12)|(MI<<8)|(NI<<4)|mode of the kernel instantiation gemm_kernel<MI,NI,mode,..,WM> slh_gemm would launch for d

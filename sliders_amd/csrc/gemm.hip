@@ -43,6 +43,8 @@ struct GemmArgs {
     // LayerNorm folded into the product (slh_gemm_desc.ln_*): producer side writes per-row chunk statistics of its
     // bf16-rounded output, consumer side normalises the A operand algebraically (weights pre-scaled by gamma)
     float* ln_out; const float* ln_in; const float* ln_s; const float* ln_b;
+    float* ln_mr_out;     // consumer side: the merged (mean, rstd) of every row, for the LayerNorm backward (slh_gemm_desc.ln_mr_out)
+    __bf16* geglu_pre; int ld_pre;   // GEGLU: the bf16 pre-activation [M][N] kept for the backward (slh_gemm_desc.geglu_pre)
     int ln_in_chunks; float ln_eps;
     int probe;   // diagnostics (slh_gemm_desc.reserved_): 1 skip tile refills, 2 skip MFMA work, 4 skip the epilogue,
                  // 8 skip the first tile fill, 16 return at once
@@ -278,6 +280,10 @@ __global__ __launch_bounds__(128 * WM, gemm_waves_per_simd(MI, NI, STAGES, LORA,
                 ln_mean[i] = m0v + dm;
                 const float M2 = (qa + qb) + nc * fmaxf((pa + pb) - S * dm, 0.f);
                 ln_rstd[i] = 1.0f / sqrtf(M2 / (float)p.K + p.ln_eps);
+                if (p.ln_mr_out && tile_n == 0 && wn == 0 && lhi == 0) {
+                    const int m = m0 + wm * (32 * MI) + i * 32 + lrow;
+                    if (m < p.M) *(f32x2*)(p.ln_mr_out + (long)m * 2) = f32x2{ln_mean[i], ln_rstd[i]};
+                }
             }
         }
     };
@@ -709,6 +715,10 @@ __global__ __launch_bounds__(128 * WM, gemm_waves_per_simd(MI, NI, STAGES, LORA,
                         o[e] = (__bf16)(av * round_bf16(gelu_erf_f(gv)));
                     }
                     *(bf16x4*)(p.c + (long)m * p.ldc + nout) = o;
+                    if (p.geglu_pre) {      // training: proj(x) itself, in the column order of this product, for the GEGLU backward
+                        *(bf16x4*)(p.geglu_pre + (long)m * p.ld_pre + n) = bf16x4{(__bf16)a[0], (__bf16)a[1], (__bf16)a[2], (__bf16)a[3]};
+                        *(bf16x4*)(p.geglu_pre + (long)m * p.ld_pre + n + 32) = bf16x4{(__bf16)g[0], (__bf16)g[1], (__bf16)g[2], (__bf16)g[3]};
+                    }
                 }
             }
         }
@@ -1133,6 +1143,11 @@ extern "C" int slh_gemm(const slh_gemm_desc* d, slh_stream_t stream) {
     a.c32 = d->splitk_c32;
     a.t32 = d->splitk_t32;
     a.ticket = (unsigned long long*)d->splitk_ticket;
+    a.ln_mr_out = d->ln_mr_out;
+    a.geglu_pre = (__bf16*)d->geglu_pre; a.ld_pre = d->ld_pre;
+    SLH_CHECK(!d->ln_mr_out || d->ln_in, "slh_gemm: ln_mr_out without ln_in");
+    SLH_CHECK(!d->geglu_pre || (d->geglu && d->ld_pre >= d->N && d->ld_pre % 4 == 0 && ((uintptr_t)d->geglu_pre & 7) == 0),
+              "slh_gemm: geglu_pre needs the GEGLU epilogue, ld_pre >= N, 8-byte alignment");
     if (a.splitk > 1) {
         // every slice must be non-empty: each publishes its whole partial tile, the last one to arrive reads them all
         const int nk = d->K / 64;

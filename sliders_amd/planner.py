@@ -239,7 +239,8 @@ class UNetPlan:
              rowbias: Optional[Tuple[int, int]] = None, residual: Optional[Act] = None,
              lora_paths: Optional[List[str]] = None, geglu: bool = False, out: Optional[Act] = None,
              w_ptr: Optional[int] = None, bias_ptr: Optional[int] = None, vt_heads: Optional[int] = None,
-             ln_stats: bool = False, ln_fold: Optional[Act] = None) -> Optional[Act]:
+             ln_stats: bool = False, ln_fold: Optional[Act] = None, geglu_pre: Optional[Act] = None,
+             ln_mr: Optional[Buf] = None, tape_x: Optional[Act] = None) -> Optional[Act]:
         """y = x . W^T (+bias)(+rowbias per sample)(+LoRA)(+residual).  conv: {'stride','xform'} for 3x3.
         vt_heads: the product is a fused q|k|v projection of that many heads; where the kernel supports it (no-grad
         passes, head_dim % 64 == 0) its V third is written head-transposed for slh_attn_fwd straight from the epilogue
@@ -247,7 +248,10 @@ class UNetPlan:
         ln_stats: also leave per-row statistics of the result for a LayerNorm folded into the NEXT product (out.ln, set only
         when the tile that will run supports it).  ln_fold = the un-normalised activation x whose producer left such
         statistics: this product computes Linear(LayerNorm(x)) from x itself with the gamma-scaled copy of the weights
-        (weights.py _put_ln_folded); returns None - nothing emitted - when the tile that would run cannot (split-K)."""
+        (weights.py _put_ln_folded); returns None - nothing emitted - when the tile that would run cannot (split-K).
+        Training passes: geglu_pre receives proj(x) itself next to the GEGLU output (the backward's pre-activation; the tape
+        records this product with it as its output), ln_mr the rows' (mean, rstd) of a folded LayerNorm, and tape_x stands
+        in for the normalised tensor that was never written (a key for the gradient chain: nothing reads its memory)."""
         x0, x1 = _src_parts(x)
         cin = x0.C + (x1.C if x1 else 0)
         B = x0.B
@@ -300,9 +304,15 @@ class UNetPlan:
             d.w, d.bias = self.w.ptr(wname + ".lnw"), 0
             d.ln_in, d.ln_in_chunks, d.ln_eps = ln_fold.ln[0].ptr, ln_fold.ln[1], 1e-5
             d.ln_s, d.ln_b = self.w.ptr(wname + ".lns"), self.w.ptr(wname + ".lnb")
+            if ln_mr is not None:
+                d.ln_mr_out = ln_mr.ptr
         else:
             provision_splitk(self, d, name)
-        if ln_stats and not self.train and not geglu and N % 64 == 0 and not d.splitk_c32 and \
+        if geglu_pre is not None:
+            assert geglu and geglu_pre.C == N
+            d.geglu_pre, d.ld_pre = geglu_pre.ptr, geglu_pre.ld
+        train_fold = self.train and os.environ.get("SLIDERS_TRAIN_NO_LN_FOLD") is None
+        if ln_stats and (not self.train or train_fold) and not geglu and N % 64 == 0 and not d.splitk_c32 and \
                 (lib.gemm_variant(d) >> 4) & 15 == 2:
             st = self.f32((N // 64, M, 2), name + ".ln_chunks")
             d.ln_out = st.ptr
@@ -317,8 +327,9 @@ class UNetPlan:
                 self.last_vt = (vt.ptr, 0)
         self.prog.add(lib.OP_GEMM, d, name)
         if self.train:
-            self.tape.append(dict(op="gemm", x=x, out=out, wname=wname, N=N, K=K, conv=conv, grp=grp, T=T,
-                                  residual=residual, rowbias=rowbias, name=name, Ho=Ho, Wo=Wo))
+            self.tape.append(dict(op="gemm", x=tape_x if tape_x is not None else x,
+                                  out=geglu_pre if geglu_pre is not None else out, wname=wname, N=N, K=K, conv=conv, grp=grp,
+                                  T=T, residual=residual, rowbias=rowbias, name=name, Ho=Ho, Wo=Wo))
         return out
 
     def groupnorm(self, x: Src, wname: str, eps: float, act: int, name: str) -> Act:
@@ -356,17 +367,31 @@ class UNetPlan:
         return y
 
     def ln_gemm(self, h: Act, norm: str, wname: str, N: int, bias: bool = True, lora_paths: Optional[List[str]] = None,
-                geglu: bool = False, vt_heads: Optional[int] = None) -> Act:
+                geglu: bool = False, vt_heads: Optional[int] = None, geglu_pre: Optional[Act] = None) -> Act:
         """Linear(LayerNorm(h)): folded into one product when h's producer left row statistics, the consumer carries no adapter
         and the pass keeps no tape; the LayerNorm launch + the plain product otherwise."""
         grp = self._lora_group(lora_paths) if lora_paths else None
-        if not self.train and grp is None and h.ln is not None and getattr(self.w, "ln_fold", False) and \
+        if grp is None and h.ln is not None and getattr(self.w, "ln_fold", False) and \
                 self.w.has(wname + ".lnw") and h.C % 64 == 0 and h.C <= 1280 and h.ld == h.C:
-            y = self.gemm(h, wname, N, wname, bias=False, geglu=geglu, vt_heads=vt_heads, ln_fold=h)
-            if y is not None:
-                return y
+            if not self.train:
+                y = self.gemm(h, wname, N, wname, bias=False, geglu=geglu, vt_heads=vt_heads, ln_fold=h)
+                if y is not None:
+                    return y
+            elif os.environ.get("SLIDERS_TRAIN_NO_LN_FOLD") is None:
+                # training pass: the same fold; the product also leaves (mean, rstd) per row for the LayerNorm backward, and the
+                # tape keeps the LayerNorm and the product as two records around a stand-in for the normalised tensor
+                mr = self.f32((h.M, 2), norm + ".mean_rstd")
+                stand_in = self.act(h.B, h.H, h.W, h.C, norm + ".unwritten")
+                mark = len(self.tape)
+                self.tape.append(dict(op="ln", x=h, out=stand_in, wname=norm, mr=mr, name=norm))
+                y = self.gemm(h, wname, N, wname, bias=False, geglu=geglu, ln_fold=h, ln_mr=mr, tape_x=stand_in,
+                              geglu_pre=geglu_pre)
+                if y is not None:
+                    return y
+                del self.tape[mark:]
         n = self.layernorm(h, norm, norm)
-        return self.gemm(n, wname, N, wname, bias=bias, lora_paths=lora_paths, geglu=geglu, vt_heads=vt_heads)
+        return self.gemm(n, wname, N, wname, bias=bias, lora_paths=lora_paths, geglu=geglu, vt_heads=vt_heads,
+                         geglu_pre=geglu_pre)
 
     def attention(self, q: Act, k: Act, v: Act, Tk: int, heads: int, name: str, vt_pre=None) -> Act:
         """q [B*Tq][C] view, k/v [B*Tk][C] views (any ld); returns [B*Tq][C].  vt_pre = (pointer to this layer's first
@@ -502,12 +527,19 @@ class UNetPlan:
             self.nograd_kv.add(kv.buf.ptr)      # text K/V carry no gradient unless they are adapted
         o2 = self.attention(q2, k2, v2, self.ctx_len, heads, a2 + ".sdpa", vt_pre=vt_pre)
         h2 = self.gemm(o2, a2 + ".out", C, a2 + ".out", residual=h1, lora_paths=[a2 + ".to_out.0"], ln_stats=True)
-        if self.train:
+        if self.train and (self._lora_group([path + ".ff.net.0.proj"]) is not None or
+                           os.environ.get("SLIDERS_TRAIN_UNFUSED_GEGLU") is not None):
             n3 = self.layernorm(h2, path + ".norm3", path + ".norm3")
             pre = self.gemm(n3, path + ".ff1", 8 * C, path + ".ff1", lora_paths=[path + ".ff.net.0.proj"])
             ff = self.act(h.B, h.H, h.W, 4 * C, path + ".geglu")
             self.prog.add(lib.OP_ELEMENTWISE, lib.EwDesc(a=pre.ptr, out=ff.ptr, M=pre.M, C=4 * C, lda=pre.ld, ldo=ff.ld,
                                                          op=lib.EW_GEGLU_FWD), path + ".geglu")
+            self.tape.append(dict(op="geglu", pre=pre, out=ff, name=path + ".geglu"))
+        elif self.train:
+            # one launch: the GEGLU epilogue also stores proj(x) for the backward (and norm3 folds into it when h2's producer
+            # left row statistics)
+            pre = self.act(h.B, h.H, h.W, 8 * C, path + ".ff1")
+            ff = self.ln_gemm(h2, path + ".norm3", path + ".ff1", 8 * C, geglu=True, geglu_pre=pre)
             self.tape.append(dict(op="geglu", pre=pre, out=ff, name=path + ".geglu"))
         else:
             grp = self._lora_group([path + ".ff.net.0.proj"])

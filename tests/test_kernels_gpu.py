@@ -182,6 +182,20 @@ def test_gemm_geglu(dev):
         proj = bf(x.float() @ w.float().t() + b.float()).float()
         ref = proj[:, :n_out] * bf(F.gelu(proj[:, n_out:])).float()
         report(f"gemm_geglu tile{tile:x}", c, ref, TOL)
+    # training form: the same launch also leaves proj(x) (bf16, this product's column order) for the GEGLU backward
+    c = torch.zeros(M, n_out, device=dev, dtype=torch.bfloat16)
+    pre_f = torch.full((M, N + 8), 7.0, device=dev, dtype=torch.bfloat16)
+    d = lib.GemmDesc(a0=p(x), w=p(wp), bias=p(bp), c=p(c), lda0=K, ca0=K, mode=0, stride=1, ldw=K, M=M, N=N, K=K,
+                     ldc=n_out, geglu=1, rows_per_sample=M, tile=0x4412, geglu_pre=p(pre_f), ld_pre=N + 8)
+    lib.call(lib.OP_GEMM, d, stream())
+    plain = torch.zeros(M, N, device=dev, dtype=torch.bfloat16)
+    d2 = lib.GemmDesc(a0=p(x), w=p(wp), bias=p(bp), c=p(plain), lda0=K, ca0=K, mode=0, stride=1, ldw=K, M=M, N=N, K=K,
+                      ldc=N, rows_per_sample=M, tile=0x4412)
+    lib.call(lib.OP_GEMM, d2, stream())
+    torch.cuda.synchronize()
+    report("gemm_geglu with pre-activation output", c, ref, TOL)
+    assert torch.equal(pre_f[:, :N], plain), "geglu_pre must be what the same product writes without the GEGLU epilogue"
+    assert (pre_f[:, N:].float() == 7.0).all()
     # split-K with the GEGLU epilogue (the last slice of a tile to arrive runs the ordinary epilogue on the slice-ordered sums)
     for tile in (0x24412, 0x44012):
         S = tile >> 16
@@ -254,11 +268,18 @@ def test_gemm_layernorm_folded(dev, C, offset):
         ref = ln.float() @ w.float().t()
         for tile in (0x4412, 0x22, 0x11, 0x4322):
             c = torch.zeros(M, N, device=dev, dtype=torch.bfloat16)
+            mr = torch.full((M, 2), float("nan"), device=dev)
             d = lib.GemmDesc(a0=p(h), w=p(wf), c=p(c), lda0=C, ca0=C, mode=0, stride=1, ldw=C, M=M, N=N, K=C, ldc=N,
-                             rows_per_sample=M, tile=tile, ln_in=p(chunks), ln_in_chunks=C // 64, ln_s=p(sv), ln_b=p(bp), ln_eps=1e-5)
+                             rows_per_sample=M, tile=tile, ln_in=p(chunks), ln_in_chunks=C // 64, ln_s=p(sv), ln_b=p(bp), ln_eps=1e-5,
+                             ln_mr_out=p(mr))
             lib.call(lib.OP_GEMM, d, stream())
             torch.cuda.synchronize()
             report(f"ln consumer plain tile{tile:x} C{C} off{offset}", c, ref, TOL)
+            # the rows' (mean, rstd), as slh_layernorm leaves them for the backward
+            hd = h.double()
+            mean_ref, var_ref = hd.mean(-1), hd.var(-1, unbiased=False)
+            assert float((mr[:, 0].double() - mean_ref).abs().max()) < 1e-5 * max(1.0, float(mean_ref.abs().max()))
+            assert float((mr[:, 1].double() * torch.sqrt(var_ref + 1e-5) - 1).abs().max()) < 1e-4
         # (b) GEGLU consumer with bias (ff.net.0.proj)
         n_out = 256
         wg = bf(torch.randn(2 * n_out, C, device=dev) / math.sqrt(C))
