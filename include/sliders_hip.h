@@ -119,7 +119,8 @@ typedef struct slh_gemm_desc {
     void* geglu_pre;         /* with geglu, optional: [M][ld_pre] bf16 receives proj(x) itself (bf16-rounded, this product's
                                 column order = what the same call without geglu writes to c) for slh_elementwise GEGLU_BWD */
     int32_t ld_pre;
-    int32_t reserved2_;
+    int32_t vt_also_c;       /* with vt_out: 1 = the head-transposed columns are ALSO written row-major into c (training passes
+                                keep V, and the backward dO, in both layouts: no separate transpose launch) */
 } slh_gemm_desc;
 int slh_gemm(const slh_gemm_desc* d, slh_stream_t stream);
 /* (WM<<12)|(MI<<8)|(NI<<4)|mode of the kernel instantiation gemm_kernel<MI,NI,mode,..,WM> slh_gemm would launch for d

@@ -44,6 +44,7 @@ struct GemmArgs {
     // bf16-rounded output, consumer side normalises the A operand algebraically (weights pre-scaled by gamma)
     float* ln_out; const float* ln_in; const float* ln_s; const float* ln_b;
     float* ln_mr_out;     // consumer side: the merged (mean, rstd) of every row, for the LayerNorm backward (slh_gemm_desc.ln_mr_out)
+    int vt_also_c;        // the head-transposed columns are written to c as well (slh_gemm_desc.vt_also_c)
     __bf16* geglu_pre; int ld_pre;   // GEGLU: the bf16 pre-activation [M][N] kept for the backward (slh_gemm_desc.geglu_pre)
     int ln_in_chunks; float ln_eps;
     int probe;   // diagnostics (slh_gemm_desc.reserved_): 1 skip tile refills, 2 skip MFMA work, 4 skip the epilogue,
@@ -815,6 +816,7 @@ __global__ __launch_bounds__(128 * WM, gemm_waves_per_simd(MI, NI, STAGES, LORA,
         // a row bias whose tile spans samples stays a per-row load
         const __bf16* rb = (p.rowbias && !rb_tile && mok) ? p.rowbias + (long)(m / p.rows_per_sample) * p.ld_rowbias : nullptr;
         const int hb = (lrow >> LOG2S) & 1;
+        bf16x4 okeep[NI][4];          // vt_also_c: the rounded quads, for the row-major store behind the transposed one
         // the residual quads of the whole 32-row block are requested together (one round trip instead of one per quad)
         bf16x4 res4[NI][4];
         if (p.residual) {
@@ -901,6 +903,7 @@ __global__ __launch_bounds__(128 * WM, gemm_waves_per_simd(MI, NI, STAGES, LORA,
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
                         *(__bf16*)(sE + ((j * 32 + q * 8 + lhi * 4 + e) * 32 + lrow) * 2) = o[e];
+                    okeep[j][q] = o;
                     continue;
                 }
                 // logical 16-byte slot j*4+q, 8-byte half lhi of row lrow; slot ^ row and half ^ row-bit keep both
@@ -938,7 +941,17 @@ __global__ __launch_bounds__(128 * WM, gemm_waves_per_simd(MI, NI, STAGES, LORA,
                 }
             }
             __builtin_amdgcn_wave_barrier();
-            continue;
+            if (!p.vt_also_c) continue;
+            // ... and row-major into c as well (training: the backward reads V / dO in both layouts): the same quads through the
+            // row patch
+#pragma unroll
+            for (int j = 0; j < NI; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int slot = (j * 4 + q) ^ (lrow & (S - 1));
+                    *(bf16x4*)(sE + lrow * (S * 16) + slot * 16 + ((lhi ^ hb) << 3)) = okeep[j][q];
+                }
+            __builtin_amdgcn_wave_barrier();
         }
 #pragma unroll
         for (int it = 0; it < S / 2; ++it) {
@@ -1145,6 +1158,8 @@ extern "C" int slh_gemm(const slh_gemm_desc* d, slh_stream_t stream) {
     a.ticket = (unsigned long long*)d->splitk_ticket;
     a.ln_mr_out = d->ln_mr_out;
     a.geglu_pre = (__bf16*)d->geglu_pre; a.ld_pre = d->ld_pre;
+    a.vt_also_c = d->vt_also_c;
+    SLH_CHECK(!d->vt_also_c || d->vt_out, "slh_gemm: vt_also_c without vt_out");
     SLH_CHECK(!d->ln_mr_out || d->ln_in, "slh_gemm: ln_mr_out without ln_in");
     SLH_CHECK(!d->geglu_pre || (d->geglu && d->ld_pre >= d->N && d->ld_pre % 4 == 0 && ((uintptr_t)d->geglu_pre & 7) == 0),
               "slh_gemm: geglu_pre needs the GEGLU epilogue, ld_pre >= N, 8-byte alignment");

@@ -318,12 +318,14 @@ class UNetPlan:
             d.ln_out = st.ptr
             out.ln = (st, N // 64)
         self.last_vt = None
-        if vt_heads and not self.train and not geglu and conv is None and os.environ.get("SLIDERS_NO_FUSED_VT") is None:
+        if vt_heads and not geglu and conv is None and os.environ.get("SLIDERS_NO_FUSED_VT") is None and \
+                (not self.train or os.environ.get("SLIDERS_TRAIN_NO_FUSED_VT") is None):
             Cq = N // 3
             Dh, Tk = Cq // vt_heads, Ho * Wo
             if Dh % 64 == 0 and (2 * Cq) % 128 == 0 and Tk % 64 == 0 and not (d.tile >> 16) & 15:
                 vt = self.arena.alloc((B, vt_heads, Dh, Tk), torch.bfloat16, name + ".vt")
                 d.vt_out, d.vt_col0, d.vt_D, d.vt_heads, d.vt_tokens, d.vt_ld = vt.ptr, 2 * Cq, Dh, vt_heads, Tk, Tk
+                d.vt_also_c = 1 if self.train else 0      # the backward reads V row-major
                 self.last_vt = (vt.ptr, 0)
         self.prog.add(lib.OP_GEMM, d, name)
         if self.train:
@@ -661,6 +663,13 @@ class BackwardPlan:
         # (slh_batch_desc): the head transposes of FORWARD activations (K^T, Q^T of every attention layer) at the head of the
         # program, and the adapters' weight gradients at its tail - except the up-gradient (dB) of a module whose output
         # gradient buffer doubles as its residual input's (alias_grad): later accumulations would change dY under it
+        # dO^T of a self-attention (for dK / dV) comes out of the backward-data product that produces dO (vt_out + vt_also_c)
+        # instead of a transpose launch: attention output buffer -> (heads, Tq), filled from the tape; -> (buffer, ldt) once made
+        self._wants_dot: Dict[int, Tuple[int, int]] = {}
+        self._dot_made: Dict[int, Tuple] = {}
+        for rec in fwd.tape:
+            if rec["op"] == "attn" and rec["k"].buf.ptr not in fwd.nograd_kv and os.environ.get("SLIDERS_BWD_DOT_LAUNCH") is None:
+                self._wants_dot[rec["o"].buf.ptr] = (rec["heads"], rec["q"].HW)
         self._tr_batch: List = []
         self._wg_batch: Dict[int, List] = {4: [], 12: []}
         self._keep: List = []            # device tables of the batched launches
@@ -830,7 +839,12 @@ class BackwardPlan:
                             ldkt=ldkt, lddq=gq.ld, scale=(q.C // heads) ** -0.5, need_dkv=need_dkv, D=q.C // heads)
         if need_dkv:
             qt, ldqt = self._transpose(qs, heads, Tq, "bwd." + rec["name"] + ".qt", forward_data=True)
-            dot, _ = self._transpose(go, heads, Tq, "bwd." + rec["name"] + ".dot")
+            made = self._dot_made.get(o.buf.ptr)
+            if made is not None:
+                dot = made[0]                 # written head-transposed by the product that produced dO
+                assert made[1] == ldqt
+            else:
+                dot, _ = self._transpose(go, heads, Tq, "bwd." + rec["name"] + ".dot")
             gk, ak = self.grad(k)
             gv, av = self.grad(v)
             assert not ak and not av
@@ -952,6 +966,15 @@ class BackwardPlan:
                 else:
                     d.lora_t = U.ptr
             self._splitk(d, name)
+            want = self._wants_dot.get(x0.buf.ptr) if (x1 is None and not tacc and tgt.ptr == gx.ptr) else None
+            if want is not None:
+                heads, Tq = want
+                Dh = cin // heads
+                if Dh % 64 == 0 and Tq % 64 == 0 and Ms == self.nb * Tq and cin == x0.C and tgt.ld % 8 == 0:
+                    dot = self.arena.alloc((self.nb, heads, Dh, Tq), torch.bfloat16, name + ".dot")
+                    d.vt_out, d.vt_col0, d.vt_D, d.vt_heads, d.vt_tokens, d.vt_ld = dot.ptr, 0, Dh, heads, Tq, Tq
+                    d.vt_also_c = 1
+                    self._dot_made[x0.buf.ptr] = (dot, Tq)
             self.prog.add(lib.OP_GEMM, d, name + ".dgrad")
             for dA, nm in dA_after:
                 self._wgrad(dA, nm, defer=True)

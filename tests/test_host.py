@@ -141,9 +141,13 @@ def test_planner_fusions_of_the_no_grad_pass(name, hw):
         assert n_tr <= n_self          # what is left are the cross-attention V transposes (one per block here: fake weights have no batched K/V)
     else:
         assert n_vt == 0 and n_tr >= n_self
-    # train-mode plans keep V row-major for the attention backward
+    # train-mode plans keep V row-major for the attention backward: the transposed copy comes on top (vt_also_c), and the
+    # GEGLU product keeps its pre-activation (geglu_pre) instead of a separate elementwise launch
     pt = UNetPlan(cfg, _FakeWeights(cfg), Arena(1 << 50, None), Arena(1 << 40, None), 2, hw, hw, 77, store, "train", 0x10)
-    assert not any(d.vt_out for o, d in pt.prog.ops if o == lib.OP_GEMM)
+    assert all(d.vt_also_c == 1 for o, d in pt.prog.ops if o == lib.OP_GEMM and d.vt_out)
+    assert sum(1 for o, d in pt.prog.ops if o == lib.OP_GEMM and d.vt_out) == (n_self if name in ("sdxl", "sd2") else 0)
+    assert all(d.geglu_pre for o, d in pt.prog.ops if o == lib.OP_GEMM and d.geglu)
+    assert sum(1 for o, d in pt.prog.ops if o == lib.OP_GEMM and d.geglu) == n_self
     if p.prog_text_cached is not None:
         assert p.prog_text_cached.n_ops == p.prog.n_ops - 2
 

@@ -148,6 +148,16 @@ def test_gemm_head_transposed_v_store(dev, tile):
     assert (c[:, 2 * C:].float() == 7.0).all(), "the V columns must not be written to c"
     vref = ref[:, 2 * C:].reshape(B, T, heads, D).permute(0, 2, 3, 1)
     report(f"gemm_vt tile{tile:x} v^T", vt, vref, TOL)
+    # training form: the V columns in BOTH layouts (vt_also_c)
+    c.fill_(7.0)
+    vt.fill_(7.0)
+    d.vt_also_c = 1
+    lib.call(lib.OP_GEMM, d, stream())
+    torch.cuda.synchronize()
+    report(f"gemm_vt also_c tile{tile:x} c", c, ref, TOL)
+    report(f"gemm_vt also_c tile{tile:x} v^T", vt, vref, TOL)
+    assert torch.equal(c[:, 2 * C:].reshape(B, T, heads, D).permute(0, 2, 3, 1).contiguous(), vt), "the two layouts hold the same bits"
+    d.vt_also_c = 0
     if tile in (0x4412, 0x22):
         # the same with K cut into slices: the last slice to arrive runs this epilogue on the slice-ordered sums
         c.fill_(7.0)
