@@ -69,7 +69,10 @@ typedef struct slh_gemm_desc {
     int32_t ld_rowbias, rows_per_sample;
     int32_t ld_t, lora_groups; /* N/lora_groups columns share one rank-4 slice of T */
     int32_t ld_res, ldc;
-    int32_t geglu;           /* 1: out[:, j] = a_j * gelu(g_j); W rows pre-permuted in 64-row blocks [32 a | 32 g] */
+    int32_t geglu;           /* 1: out[:, j] = a_j * gelu(g_j); W rows pre-permuted in 64-row blocks [32 a | 32 g].
+                                2: backward form, for the backward-data product of the Linear BEHIND a GEGLU: the result d(ff)
+                                [M][N] leaves as d(proj) [M][2N] in proj's blocked column order, computed with the forward's
+                                pre-activation geglu_pre (slh_elementwise GEGLU_BWD fused; bare product only) */
     int32_t tile;            /* 0 auto; else (S<<16)|(WM<<12)|(stages<<8)|(MI<<4)|NI, MI,NI in {1,2}, WM in {0|2, 4}: WM*2 waves per
                                 workgroup, block tile (32*MI*WM) x (64*NI); stages 0|2: double buffer, 3|4: deep LDS ring;
                                 S: split-K factor (0|1 none), needs splitk_c32 */
@@ -116,8 +119,8 @@ typedef struct slh_gemm_desc {
                                 every tile shape), zero before the first launch, left zero by every launch */
     float* ln_mr_out;        /* with ln_in, optional: [M][2] fp32 receives the merged (mean, rstd) of every row - what
                                 slh_layernorm would have left in mean_rstd for slh_layernorm_bwd (training passes) */
-    void* geglu_pre;         /* with geglu, optional: [M][ld_pre] bf16 receives proj(x) itself (bf16-rounded, this product's
-                                column order = what the same call without geglu writes to c) for slh_elementwise GEGLU_BWD */
+    void* geglu_pre;         /* geglu = 1, optional: [M][ld_pre] bf16 RECEIVES proj(x) itself (bf16-rounded, this product's column
+                                order = what the same call without geglu writes to c).  geglu = 2: the same array, READ */
     int32_t ld_pre;
     int32_t vt_also_c;       /* with vt_out: 1 = the head-transposed columns are ALSO written row-major into c (training passes
                                 keep V, and the backward dO, in both layouts: no separate transpose launch) */

@@ -676,6 +676,47 @@ __global__ __launch_bounds__(128 * WM, gemm_waves_per_simd(MI, NI, STAGES, LORA,
         __syncthreads();                       // every wave is done reading the operand stages being reused below
         if (tid < BN) { sCol[tid] = c0; sCol[BN + tid] = c1; sCol[2 * BN + tid] = c2; sCol[3 * BN + tid] = c3; }
     }
+    if (p.geglu == 2) {
+        // Backward of GEGLU fused into the backward-data product of the Linear behind it (ff.net.2): the accumulators are
+        // d(ff) - rounded to bf16 as the unfused path stores it - and leave as d(proj) in proj's blocked column order, computed
+        // from the forward's pre-activation (slh_elementwise GEGLU_BWD arithmetic, one launch and one HBM round trip of
+        // d(ff) less):  d_h = dd * bf16(g * Phi(g)),  d_g = bf16(dd * h) * (Phi(g) + g * phi(g)).
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            const int m = m0 + wm * (32 * MI) + i * 32 + lrow;
+            const bool mok = m < p.M;
+#pragma unroll
+            for (int j = 0; j < NI; ++j) {
+                bf16x4 h4[4], g4[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {        // the block's pre-activation quads, requested together
+                    const int n = n0 + wn * (32 * NI) + j * 32 + q * 8 + lhi * 4;
+                    const __bf16* src = (mok && n < p.N) ? p.geglu_pre + (long)m * p.ld_pre + (n >> 5) * 64 + (n & 31)
+                                                         : (const __bf16*)slh_zero_page;
+                    h4[q] = *(const bf16x4*)src;
+                    g4[q] = *(const bf16x4*)(src + ((mok && n < p.N) ? 32 : 0));
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int n = n0 + wn * (32 * NI) + j * 32 + q * 8 + lhi * 4;
+                    if (!mok || n >= p.N) continue;
+                    bf16x4 dh, dg;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float g = (float)g4[q][e], hh = (float)h4[q][e], dd = round_bf16(acc[i][j][q * 4 + e]);
+                        const float cdf = 0.5f * (1.f + erff(g * 0.70710678118654752f));
+                        const float pdf = 0.3989422804014327f * __expf(-0.5f * g * g);
+                        dh[e] = (__bf16)(dd * round_bf16(g * cdf));
+                        dg[e] = (__bf16)(round_bf16(dd * hh) * (cdf + g * pdf));
+                    }
+                    __bf16* po = p.c + (long)m * p.ldc + (n >> 5) * 64 + (n & 31);
+                    *(bf16x4*)po = dh;
+                    *(bf16x4*)(po + 32) = dg;
+                }
+            }
+        }
+        return;
+    }
     if (p.geglu) {
         // GEGLU: W rows are stored in 64-row blocks [32 value rows | 32 gate rows]; NI is 2 here, so
         // sub-tile j=0 holds the values and j=1 the gates of the same 32 output columns.
@@ -1017,7 +1058,7 @@ static void pick_tile(const slh_gemm_desc* d, int& MI, int& NI, int& WM) {
     // untuned shape: the pattern of the measured table (sliders_amd/tuning/gfx950_sdxl_128.json) - the 8-wave 128x128
     // tile once it yields enough workgroups (or fewer, but with a long K loop to amortise them), 64x64 otherwise
     const long t128 = (long)((d->M + 127) / 128) * ((d->N + 127) / 128);
-    if (d->geglu) {
+    if (d->geglu == 1) {
         NI = 2; MI = 1; WM = t128 >= 192 ? 4 : 2;
     } else if (t128 >= 256 || (t128 >= 160 && d->K >= 5760)) {
         MI = 1; NI = 2; WM = 4;
@@ -1105,14 +1146,15 @@ extern "C" int slh_gemm(const slh_gemm_desc* d, slh_stream_t stream) {
     }
     if (d->rowbias) SLH_CHECK(d->rows_per_sample > 0 && d->ld_rowbias % 4 == 0, "slh_gemm: rowbias");
     if (d->residual) SLH_CHECK(d->ld_res % 4 == 0, "slh_gemm: ld_res");
-    if (d->geglu) SLH_CHECK(d->N % 64 == 0 && !d->lora_t && !d->residual && !d->rowbias, "slh_gemm: geglu constraints");
+    if (d->geglu == 1) SLH_CHECK(d->N % 64 == 0 && !d->lora_t && !d->residual && !d->rowbias, "slh_gemm: geglu constraints");
+    SLH_CHECK(d->geglu >= 0 && d->geglu <= 2, "slh_gemm: geglu is 0, 1 (forward epilogue) or 2 (backward form)");
 
     int MI = 2, NI = 2, WM = 2;
     pick_tile(d, MI, NI, WM);
     SLH_CHECK((MI == 1 || MI == 2) && (NI == 1 || NI == 2), "slh_gemm: bad tile");
     SLH_CHECK(WM == 2 || NI == 2 || MI == 1, "slh_gemm: 8-wave tiles are 128x64, 128x128 or 256x128");
     SLH_CHECK(d->w_layout == 0 || d->w_layout == 1, "slh_gemm: bad w_layout");
-    if (d->geglu) SLH_CHECK(NI == 2, "slh_gemm: geglu needs NI=2");
+    if (d->geglu == 1) SLH_CHECK(NI == 2, "slh_gemm: geglu needs NI=2");
 
     GemmArgs a;
     a.a0 = (const __bf16*)d->a0; a.a1 = (const __bf16*)d->a1; a.w = (const __bf16*)d->w;
@@ -1161,8 +1203,13 @@ extern "C" int slh_gemm(const slh_gemm_desc* d, slh_stream_t stream) {
     a.vt_also_c = d->vt_also_c;
     SLH_CHECK(!d->vt_also_c || d->vt_out, "slh_gemm: vt_also_c without vt_out");
     SLH_CHECK(!d->ln_mr_out || d->ln_in, "slh_gemm: ln_mr_out without ln_in");
-    SLH_CHECK(!d->geglu_pre || (d->geglu && d->ld_pre >= d->N && d->ld_pre % 4 == 0 && ((uintptr_t)d->geglu_pre & 7) == 0),
-              "slh_gemm: geglu_pre needs the GEGLU epilogue, ld_pre >= N, 8-byte alignment");
+    SLH_CHECK(!d->geglu_pre || (d->geglu && d->ld_pre >= (d->geglu == 2 ? 2 * d->N : d->N) && d->ld_pre % 4 == 0 &&
+                                ((uintptr_t)d->geglu_pre & 7) == 0),
+              "slh_gemm: geglu_pre needs the GEGLU epilogue, ld_pre >= N (2N in the backward form), 8-byte alignment");
+    if (d->geglu == 2)
+        SLH_CHECK(d->geglu_pre && d->N % 32 == 0 && d->ldc >= 2 * d->N && d->ldc % 4 == 0 && !d->bias && !d->rowbias && !d->residual &&
+                      !d->lora_t && !d->lora_down && !d->vt_out && !d->ln_in && !d->ln_out,
+                  "slh_gemm: geglu = 2 (backward form) needs geglu_pre, N %% 32 == 0, ldc >= 2N and a bare product");
     if (a.splitk > 1) {
         // every slice must be non-empty: each publishes its whole partial tile, the last one to arrive reads them all
         const int nk = d->K / 64;

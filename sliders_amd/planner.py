@@ -670,6 +670,12 @@ class BackwardPlan:
         for rec in fwd.tape:
             if rec["op"] == "attn" and rec["k"].buf.ptr not in fwd.nograd_kv and os.environ.get("SLIDERS_BWD_DOT_LAUNCH") is None:
                 self._wants_dot[rec["o"].buf.ptr] = (rec["heads"], rec["q"].HW)
+        # GEGLU outputs -> their tape record: the backward-data product of the Linear that consumes one writes d(proj) itself
+        self._geglu_of: Dict[int, dict] = {}
+        if os.environ.get("SLIDERS_BWD_UNFUSED_GEGLU") is None:
+            for rec in fwd.tape:
+                if rec["op"] == "geglu":
+                    self._geglu_of[rec["out"].buf.ptr] = rec
         self._tr_batch: List = []
         self._wg_batch: Dict[int, List] = {4: [], 12: []}
         self._keep: List = []            # device tables of the batched launches
@@ -947,6 +953,20 @@ class BackwardPlan:
         wT = self.w.ptr(rec["wname"] + ".wT")
         gyimg = Act(gy.ptr, self.nb, Ho, Wo, N, gy.ld, gy.buf, gy.name)
         if conv is None:
+            geglu_rec = self._geglu_of.get(x0.buf.ptr) if (x1 is None and grp is None and not self.has_grad(x0)) else None
+            if geglu_rec is not None and x0.C % 32 == 0:
+                # the Linear behind a GEGLU (ff.net.2): its backward-data product writes d(proj) directly (GEGLU backward in
+                # the epilogue, slh_gemm_desc.geglu = 2) - no d(ff) tensor, no elementwise launch
+                pre = geglu_rec["pre"]
+                gp, pacc = self.grad(pre)
+                assert not pacc
+                ps = self._sl(pre)
+                d = lib.GemmDesc(a0=gy.ptr, w=wT, c=gp.ptr, lda0=gy.ld, ca0=N, mode=0, stride=1, ldw=N, M=Ms, N=cin, K=N,
+                                 ldc=gp.ld, rows_per_sample=Ho * Wo, w_layout=1 if self.w.packed else 0)
+                self._splitk(d, name)
+                d.geglu, d.geglu_pre, d.ld_pre = 2, ps.ptr, ps.ld
+                self.prog.add(lib.OP_GEMM, d, name + ".dgrad")
+                return
             if x1 is None:
                 gx, acc = self.grad(x0)
                 tgt, tacc = gx, acc

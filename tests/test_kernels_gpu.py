@@ -238,6 +238,41 @@ def test_gemm_geglu(dev):
     report("geglu_bwd", dpre, _perm_cols(pr.grad), 1.5e-2)
 
 
+@pytest.mark.parametrize("tile", [0, 0x4412, 0x22, 0x11, 0x4322, 0x24412])
+def test_gemm_geglu_backward_form(dev, tile):
+    """slh_gemm_desc.geglu = 2: the backward-data product of the Linear behind a GEGLU writes d(proj) itself - bit-identical to
+    the two-launch form (plain product -> bf16 d(ff) -> slh_elementwise GEGLU_BWD with the forward's pre-activation)."""
+    torch.manual_seed(17)
+    M, Nff, K = 300, 256, 320                    # d(ff) [M][Nff] = dY [M][K] . W2 [K][Nff]  (W2^T stored [Nff][K])
+    dy = bf(torch.randn(M, K, device=dev))
+    wT = bf(torch.randn(Nff, K, device=dev) / math.sqrt(K))
+    pre = bf(torch.randn(M, 2 * Nff, device=dev))
+    S = (tile >> 16) & 15
+    kw = {}
+    slabs = torch.full((max(S, 1), 512, 256), float("nan"), device=dev)          # kept alive: the descriptor only holds pointers
+    tickets = torch.zeros(64, device=dev, dtype=torch.int64)
+    if S > 1:
+        kw = dict(splitk_c32=p(slabs), splitk_slabs=S, splitk_ticket=p(tickets))
+    dff = torch.zeros(M, Nff, device=dev, dtype=torch.bfloat16)
+    d = lib.GemmDesc(a0=p(dy), w=p(wT), c=p(dff), lda0=K, ca0=K, mode=0, stride=1, ldw=K, M=M, N=Nff, K=K, ldc=Nff,
+                     rows_per_sample=M, tile=tile, **kw)
+    lib.call(lib.OP_GEMM, d, stream())
+    two = torch.zeros(M, 2 * Nff, device=dev, dtype=torch.bfloat16)
+    lib.call(lib.OP_ELEMENTWISE, lib.EwDesc(a=p(pre), b=p(dff), out=p(two), M=M, C=Nff, lda=2 * Nff, ldb=Nff, ldo=2 * Nff,
+                                            op=lib.EW_GEGLU_BWD), stream())
+    one = torch.full((M, 2 * Nff + 8), 7.0, device=dev, dtype=torch.bfloat16)
+    d = lib.GemmDesc(a0=p(dy), w=p(wT), c=p(one), lda0=K, ca0=K, mode=0, stride=1, ldw=K, M=M, N=Nff, K=K, ldc=2 * Nff + 8,
+                     rows_per_sample=M, tile=tile, geglu=2, geglu_pre=p(pre), ld_pre=2 * Nff, **kw)
+    lib.call(lib.OP_GEMM, d, stream())
+    torch.cuda.synchronize()
+    assert torch.equal(one[:, :2 * Nff], two), float((one[:, :2 * Nff].float() - two.float()).abs().max())
+    assert (one[:, 2 * Nff:].float() == 7.0).all()
+    bad = lib.GemmDesc(a0=p(dy), w=p(wT), c=p(one), bias=p(dy), lda0=K, ca0=K, mode=0, stride=1, ldw=K, M=M, N=Nff, K=K,
+                       ldc=2 * Nff + 8, rows_per_sample=M, geglu=2, geglu_pre=p(pre), ld_pre=2 * Nff)
+    with pytest.raises(lib.SlidersHipError, match="geglu = 2"):
+        lib.call(lib.OP_GEMM, bad, stream())
+
+
 @pytest.mark.parametrize("C,offset", [(640, 0.0), (1280, 0.0), (320, 0.0), (1280, 8.0)])
 def test_gemm_layernorm_folded(dev, C, offset):
     """BasicTransformerBlock.norm2 / norm3 folded into the products around them (slh_gemm_desc.ln_out / ln_in): the
