@@ -1,6 +1,7 @@
 """Where the dispatcher puts the attention workgroups (development aid; GPU box): run with the SLH_ATTN_TRACE build
 (SLIDERS_HIP_LIB=.../libsliders_hip_trace.so), prints waves per SIMD / workgroups per CU histograms and the launch time.
-Knobs of the launcher: SLH_ATTN_SPREAD=1 (LDS cap), SLH_ATTN_NW2=1 (64-query workgroups everywhere)."""
+Knob of the launcher: SLH_ATTN_NW2=1 (64-query workgroups everywhere).  (SLH_ATTN_SPREAD, an LDS cap on workgroups per CU,
+was removed after this probe showed the placement is already even: profiles/r03_attn_variants.txt.)"""
 import os
 import sys
 from collections import Counter

@@ -434,46 +434,22 @@ __global__ __launch_bounds__(256) void transpose_heads_batch_kernel(const slh_tr
     transpose_heads_body(d, D, DT, bx, rest % gy, rest / gy);
 }
 
-// Dynamic LDS that no kernel touches, sized so that at most ceil(grid / 256) workgroups fit on one CU: the dispatcher then
-// cannot stack more workgroups on some CUs than an even spread needs.
-template <typename KernelT>
-unsigned spread_lds(KernelT kernel, long grid, int static_lds, int natural_cap) {
-    const long cap = (grid + 255) / 256;
-    if (cap >= natural_cap) return 0;
-    const long per = ((160 * 1024) / cap) & ~1023L;
-    const long dyn = per - static_lds;
-    if (dyn <= 0) return 0;
-    static thread_local const void* raised[16];
-    static thread_local int nraised = 0;
-    bool done = false;
-    for (int i = 0; i < nraised; ++i) done |= raised[i] == (const void*)kernel;
-    if (!done) {
-        (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - static_lds);
-        if (nraised < 16) raised[nraised++] = (const void*)kernel;
-    }
-    return (unsigned)dyn;
-}
-
 template <int DT>
 int launch_fwd(const slh_attn_desc* d, hipStream_t s) {
     const long blocks4 = (long)((d->Tq + 127) / 128) * d->H * d->B;
     const bool tail = (d->Tk & 63) != 0;
-    static const int knob_spread = getenv("SLH_ATTN_SPREAD") ? atoi(getenv("SLH_ATTN_SPREAD")) : 0;
-    static const int knob_nw2 = getenv("SLH_ATTN_NW2") ? atoi(getenv("SLH_ATTN_NW2")) : 0;
-    const int slds = 4 * DT * 8192;
+    static const int knob_nw2 = getenv("SLH_ATTN_NW2") ? atoi(getenv("SLH_ATTN_NW2")) : 0;     // A/B: 64-query workgroups everywhere
     // 128-query workgroups once they fill every CU twice; below that the 64-query form (same waves per SIMD at most, finer
-    // placement: T = 1024 with 40 heads 31.2 -> 28.9 us, same box)
+    // placement: T = 1024 with 40 heads 31.2 -> 28.9 us, same box).  (Capping the workgroups per CU with unused dynamic LDS so
+    // that the dispatcher must spread them was tried: the hardware already places them evenly, the cap only delays backfill.)
     if (blocks4 >= 512 && !knob_nw2) {
         const dim3 grid((unsigned)blocks4);
-        const int nat = DT == 1 ? ATTN_OCC41 : (DT == 2 ? 2 : 1);
-        if (tail) hipLaunchKernelGGL((attn_fwd_kernel<4, DT, true>), grid, dim3(256), knob_spread ? spread_lds(attn_fwd_kernel<4, DT, true>, blocks4, slds, nat) : 0, s, *d);
-        else hipLaunchKernelGGL((attn_fwd_kernel<4, DT, false>), grid, dim3(256), knob_spread ? spread_lds(attn_fwd_kernel<4, DT, false>, blocks4, slds, nat) : 0, s, *d);
+        if (tail) hipLaunchKernelGGL((attn_fwd_kernel<4, DT, true>), grid, dim3(256), 0, s, *d);
+        else hipLaunchKernelGGL((attn_fwd_kernel<4, DT, false>), grid, dim3(256), 0, s, *d);
     } else {
-        const long blocks2 = (long)((d->Tq + 63) / 64) * d->H * d->B;
-        const dim3 grid((unsigned)blocks2);
-        const int nat = 160 / (32 * DT);
-        if (tail) hipLaunchKernelGGL((attn_fwd_kernel<2, DT, true>), grid, dim3(128), knob_spread ? spread_lds(attn_fwd_kernel<2, DT, true>, blocks2, slds, nat) : 0, s, *d);
-        else hipLaunchKernelGGL((attn_fwd_kernel<2, DT, false>), grid, dim3(128), knob_spread ? spread_lds(attn_fwd_kernel<2, DT, false>, blocks2, slds, nat) : 0, s, *d);
+        const dim3 grid((unsigned)((long)((d->Tq + 63) / 64) * d->H * d->B));
+        if (tail) hipLaunchKernelGGL((attn_fwd_kernel<2, DT, true>), grid, dim3(128), 0, s, *d);
+        else hipLaunchKernelGGL((attn_fwd_kernel<2, DT, false>), grid, dim3(128), 0, s, *d);
     }
     SLH_LAUNCH_CHECK("slh_attn_fwd");
     return 0;
