@@ -167,6 +167,9 @@ __global__ __launch_bounds__(128 * WM, gemm_waves_per_simd(MI, NI, STAGES, LORA,
         glds16(src, lds_dst);
 #endif
     };
+#ifdef SLH_GEMM_PROBE_W
+    bool probe_first_tile = true;
+#endif
     auto stage = [&](int buf, int kt) {
         const int k0 = kt * BK;
         char* dX = sX + buf * (BM * 128);
@@ -204,7 +207,12 @@ __global__ __launch_bounds__(128 * WM, gemm_waves_per_simd(MI, NI, STAGES, LORA,
             }
         }
 #pragma unroll
-        for (int i = 0; i < WI; ++i) stage_copy(wptr[i] + (long)kt * wkstep, dW + (wave + NW * i) * 1024);
+        for (int i = 0; i < WI; ++i) {
+#ifdef SLH_GEMM_PROBE_W        // ablation build (scripts/build_variant.sh): probe bit 32 = no W refills after the first tile
+            if ((p.probe & 32) && !probe_first_tile) continue;
+#endif
+            stage_copy(wptr[i] + (long)kt * wkstep, dW + (wave + NW * i) * 1024);
+        }
         if (LORA) {
             const int row = (wave & 3) * 8 + frow;   // with 8 waves the upper four re-issue the same rows (benign)
             const __bf16* src = row < p.lora_rank
@@ -212,6 +220,9 @@ __global__ __launch_bounds__(128 * WM, gemm_waves_per_simd(MI, NI, STAGES, LORA,
                                     : (const __bf16*)slh_zero_page;
             stage_copy(src, sL + buf * (32 * 128) + (wave & 3) * 1024);
         }
+#ifdef SLH_GEMM_PROBE_W
+        probe_first_tile = false;
+#endif
     };
 
     f32x16 acc[MI][NI];
@@ -405,6 +416,9 @@ __global__ __launch_bounds__(128 * WM, gemm_waves_per_simd(MI, NI, STAGES, LORA,
         auto piece = [&](const int j, const int slot) {
 #if defined(SLH_RING_PROBE) && (SLH_RING_PROBE & 1)
             if (i_kt >= S - 1) return;                 // ablation: no LDS-DMA after the prologue
+#endif
+#ifdef SLH_GEMM_PROBE_W        // ablation build: probe bit 32 = no W pieces, bit 64 = no X pieces after the prologue
+            if (i_kt >= S - 1 && (((p.probe & 32) && j >= XI && j < XI + WI) || ((p.probe & 64) && j < XI))) return;
 #endif
             if (j < XI) {
                 glds16_hidden(xsrc[j], lds0 + slot * (BM * 128) + (wave + NW * j) * 1024);
