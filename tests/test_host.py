@@ -114,6 +114,17 @@ def test_planner_static_invariants(name, hw, method):
             dg = [d for o, d in bw.prog.ops if o == lib.OP_GEMM]
             assert all(d.M == d_.M for d, d_ in zip(dg[:1], dg[:1]))
             assert all(d.K % 64 == 0 for d in dg)
+            # the GEGLU backward rides in the backward-data product of the Linear behind it (geglu = 2) ...
+            n_geglu = sum(1 for d in gemms if d.geglu == 1)
+            assert n_geglu > 0 and all(d.geglu_pre for d in gemms if d.geglu == 1)
+            assert sum(1 for d in dg if d.geglu == 2) == n_geglu and all(d.geglu_pre and d.ldc >= 2 * d.N for d in dg if d.geglu == 2)
+            assert not any(o == lib.OP_ELEMENTWISE and d.op == lib.EW_GEGLU_BWD for o, d in bw.prog.ops)
+            # ... and dO^T of a self-attention with 64-wide heads comes out of the product that makes dO (both layouts)
+            n_dot = sum(1 for d in dg if d.vt_out)
+            assert all(d.vt_also_c == 1 and d.vt_col0 == 0 for d in dg if d.vt_out)
+            if name == "sdxl":
+                n_self = sum(1 for n in p.prog.op_names if n.endswith("attn1.sdpa"))
+                assert n_dot == n_self and not any(n.endswith(".dot") for n in bw.prog.op_names)
     assert counts["off"] <= counts["on"] <= counts["train"]
     if name == "sdxl":
         assert counts["off"] < 1300     # one launch per fused op: ~1.15k for the whole SDXL UNet
