@@ -16,47 +16,12 @@
 // (ResnetBlock2D.conv1/conv2/conv_shortcut, Downsample2D.conv, Upsample2D.conv, Attention.to_q/k/v/out,
 // GEGLU.proj, FeedForward.net.2, Transformer2DModel.proj_in/out) plus the LoRA branch of
 // trainscripts/textsliders/lora.py:108-112.
-#include "common.h"
+#include "gemm_common.h"
 #include <cstdlib>
-#include <cstdint>
-#include <type_traits>
-#include "../../include/sliders_hip.h"
+
+using namespace slh_gemm_detail;
 
 namespace {
-
-struct GemmArgs {
-    const __bf16* a0; const __bf16* a1; const __bf16* w;
-    const __bf16* bias; const __bf16* rowbias; const float* lora_t; const __bf16* lora_up;
-    const float* lora_scale; const __bf16* residual; __bf16* c;
-    const __bf16* lora_down; float* lora_t_out;
-    int lda0, lda1, ca0, ca1;
-    int hs, ws, src_xform, stride, ho, wo;
-    int ldw, M, N, K;
-    int ld_rowbias, rows_per_sample, ld_t, lora_cols_per_group, ld_res, ldc, geglu;
-    int lora_rank, lora_up_rmajor, w_packed;
-    int tiles_m, tiles_n, group_m;
-    float* c32; float* t32;   // split-K: fp32 partial sums (zeroed by the caller), see slh_gemm_desc.splitk_c32
-    int splitk;
-    unsigned long long* ticket;   // split-K arrival tickets, one per output tile (slh_gemm_desc.splitk_ticket)
-    __bf16* vt; int vt_col0, vt_D, vt_heads, vt_tokens, vt_ld;   // head-transposed store of the V columns (slh_gemm_desc.vt_out)
-    int store16;  // c and ldc allow 16-byte row stores
-    // LayerNorm folded into the product (slh_gemm_desc.ln_*): producer side writes per-row chunk statistics of its
-    // bf16-rounded output, consumer side normalises the A operand algebraically (weights pre-scaled by gamma)
-    float* ln_out; const float* ln_in; const float* ln_s; const float* ln_b;
-    float* ln_mr_out;     // consumer side: the merged (mean, rstd) of every row, for the LayerNorm backward (slh_gemm_desc.ln_mr_out)
-    int vt_also_c;        // the head-transposed columns are written to c as well (slh_gemm_desc.vt_also_c)
-    __bf16* geglu_pre; int ld_pre;   // GEGLU: the bf16 pre-activation [M][N] kept for the backward (slh_gemm_desc.geglu_pre)
-    int ln_in_chunks; float ln_eps;
-    int probe;   // diagnostics (slh_gemm_desc.reserved_): 1 skip tile refills, 2 skip MFMA work, 4 skip the epilogue,
-                 // 8 skip the first tile fill, 16 return at once
-};
-
-constexpr int BK = 64;
-
-// swizzled byte offset of (row, 16-byte slot) inside a [rows][64] bf16 LDS tile
-__device__ __forceinline__ int lds_off(int row, int slot) {
-    return row * 128 + ((slot ^ ((row >> 1) & 7)) << 4);
-}
 
 // WM = waves along M (2: 4-wave workgroup, tile 64*MI x 64*NI; 4: 8-wave workgroup, tile 128*MI x 64*NI - twice
 // the W-tile reuse per byte pulled from L2, which is what bounds these kernels)
@@ -68,6 +33,24 @@ constexpr int gemm_waves_per_simd(int MI, int NI, int STAGES, bool LORA, int WM)
     int w = blocks * 2 * WM / 4;
     if (LORA && MI * NI == 1 && WM == 2 && w > 4) w = 4;   // 64x64 + fused LoRA needs ~110 registers: 4 waves, not 5
     return w < 1 ? 1 : (w > 8 ? 8 : w);
+}
+
+
+// timing experiment (-DSLH_GEMM_M16, wrong numbers): the operand registers and FLOPs of one 32x32x16 MFMA as two 16x16x32 MFMAs
+// on quarters of the accumulator block (half the accumulator register traffic per FLOP)
+__device__ __forceinline__ f32x16 mfma_slot(const bf16x8 a, const bf16x8 b, f32x16 c, const int ks) {
+#ifdef SLH_GEMM_M16
+    const int k0 = ks & 3, k1 = (ks & 3) ^ 2;
+    f32x4 q0 = {c[k0 * 4], c[k0 * 4 + 1], c[k0 * 4 + 2], c[k0 * 4 + 3]};
+    f32x4 q1 = {c[k1 * 4], c[k1 * 4 + 1], c[k1 * 4 + 2], c[k1 * 4 + 3]};
+    q0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, q0, 0, 0, 0);
+    q1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, q1, 0, 0, 0);
+    c[k0 * 4] = q0[0]; c[k0 * 4 + 1] = q0[1]; c[k0 * 4 + 2] = q0[2]; c[k0 * 4 + 3] = q0[3];
+    c[k1 * 4] = q1[0]; c[k1 * 4 + 1] = q1[1]; c[k1 * 4 + 2] = q1[2]; c[k1 * 4 + 3] = q1[3];
+    return c;
+#else
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+#endif
 }
 
 template <int MI, int NI, int MODE, int STAGES, bool LORA, int WM>
@@ -89,35 +72,16 @@ __global__ __launch_bounds__(128 * WM, gemm_waves_per_simd(MI, NI, STAGES, LORA,
     char* sW = smem + STAGES * BM * 128;    // [STAGES][BN][128 B]
     char* sL = smem + STAGES * (BM + BN) * 128;   // [STAGES][32][128 B]
 
+#ifdef SLH_GEMM_PROBE
     if (p.probe & 16) return;   // diagnostics: launch + dispatch cost only
+#endif
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
 
-    // ---- XCD-aware tile mapping: block b runs on XCD b%8 (own 4 MB L2); give each XCD a contiguous chunk of a
-    // grouped tile sequence: groups of group_m consecutive m-tiles, inside a group m fastest, then n.  The host
-    // sizes the groups so that one group's X rows stay resident in the XCD's L2 while the W panels stream past
-    // once (measured before grouping: L2 hit rate 62-78 %, fabric fetches 6-14x the unique operand bytes).
-    int bid = blockIdx.x;
-    {
-        const int nblk = gridDim.x;
-        const int q = nblk >> 3, r = nblk & 7;
-        const int xcd = bid & 7, idx = bid >> 3;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    }
-    int ks_id = 0;                 // split-K: consecutive block ids = the K slices of one tile (same XCD, same L2)
-    if (p.splitk > 1) { ks_id = bid % p.splitk; bid = bid / p.splitk; }
-    int tile_m, tile_n;
-    {
-        const int gsz = p.group_m * p.tiles_n;
-        const int g = bid / gsz;
-        const int first_m = g * p.group_m;
-        const int gm = min(p.group_m, p.tiles_m - first_m);
-        const int r = bid - g * gsz;
-        tile_n = r / gm;
-        tile_m = first_m + r - tile_n * gm;
-    }
+    int tile_m, tile_n, ks_id;
+    gemm_map_tile(p, tile_m, tile_n, ks_id);
     const int m0 = tile_m * BM, n0 = tile_n * BN;
 
     // ---- per-lane fill geometry --------------------------------------------------------------
@@ -167,7 +131,7 @@ __global__ __launch_bounds__(128 * WM, gemm_waves_per_simd(MI, NI, STAGES, LORA,
         glds16(src, lds_dst);
 #endif
     };
-#ifdef SLH_GEMM_PROBE_W
+#if defined(SLH_GEMM_PROBE_W)
     bool probe_first_tile = true;
 #endif
     auto stage = [&](int buf, int kt) {
@@ -249,55 +213,12 @@ __global__ __launch_bounds__(128 * WM, gemm_waves_per_simd(MI, NI, STAGES, LORA,
     }
     const int lrow = lane & 31, lhi = lane >> 5;
 
-    // LayerNorm of the A operand, folded (consumer side).  The producer of A left per-row (mean, M2) pairs of 64-column
-    // chunks (ln_in, laid out [chunk][row], written by its epilogue below); they are requested here, ahead of the first operand tiles, merged
-    // in a fixed order (Chan's merge for equal counts: cancellation-free) into the row's mean and 1/sigma, and applied in the epilogue:
-    //   LN(x) . W^T = rstd * (x . W'^T - mean * s) + b',   W' = W * gamma, s = row sums of W', b' = bias + W . beta
-    constexpr int LN_MAXC = 20;
     float ln_mean[MI], ln_rstd[MI];
-    f32x2 ln_pairs[MI][MODE == 0 ? LN_MAXC : 1];
+    f32x2 ln_pairs[MI][LN_MAXC];
     const bool ln_on = MODE == 0 && !LORA && p.ln_in != nullptr;   // (never with a fused adapter: slh_gemm rejects it)
-    if (MODE == 0 && ln_on) {
-#pragma unroll
-        for (int i = 0; i < MI; ++i) {
-            int m = m0 + wm * (32 * MI) + i * 32 + lrow;
-            m = m < p.M ? m : p.M - 1;
-            const f32x2* src = (const f32x2*)p.ln_in + m;        // chunk-major [chunks][M]: the 32 rows of a wave-load are contiguous
-#pragma unroll
-            for (int c = 0; c < LN_MAXC; ++c)
-                if (c < p.ln_in_chunks) ln_pairs[i][c] = src[(long)c * p.M];
-        }
-    }
+    if (MODE == 0 && ln_on) gemm_ln_request<MI>(p, m0 + wm * (32 * MI), lrow, ln_pairs);
     auto ln_finish = [&]() {
-        if (MODE == 0 && ln_on) {
-            // equal-sized chunks, one pass over the pairs with the chunk means shifted by the first one (d_c = mean_c - mean_0):
-            //   mean = mean_0 + S/k,  M2 = sum M2_c + n_chunk * (sum d_c^2 - S^2/k),  S = sum d_c
-            // = Chan's merge for equal counts; two interleaved accumulator sets keep the dependent chains short; fixed order
-            const float nc = (float)(p.K / p.ln_in_chunks);
-            const float inv_chunks = 1.f / (float)p.ln_in_chunks;
-#pragma unroll
-            for (int i = 0; i < MI; ++i) {
-                const float m0v = ln_pairs[i][0][0];
-                float sa = 0.f, sb = 0.f, pa = 0.f, pb = 0.f, qa = ln_pairs[i][0][1], qb = 0.f;
-#pragma unroll
-                for (int c = 1; c < LN_MAXC; c += 2) {
-                    if (c < p.ln_in_chunks) { const float dl = ln_pairs[i][c][0] - m0v; sa += dl; pa += dl * dl; qa += ln_pairs[i][c][1]; }
-                    if (c + 1 < p.ln_in_chunks && c + 1 < LN_MAXC) {
-                        const float dl = ln_pairs[i][c + 1 < LN_MAXC ? c + 1 : c][0] - m0v;
-                        sb += dl; pb += dl * dl; qb += ln_pairs[i][c + 1 < LN_MAXC ? c + 1 : c][1];
-                    }
-                }
-                const float S = sa + sb;
-                const float dm = S * inv_chunks;
-                ln_mean[i] = m0v + dm;
-                const float M2 = (qa + qb) + nc * fmaxf((pa + pb) - S * dm, 0.f);
-                ln_rstd[i] = 1.0f / sqrtf(M2 / (float)p.K + p.ln_eps);
-                if (p.ln_mr_out && tile_n == 0 && wn == 0 && lhi == 0) {
-                    const int m = m0 + wm * (32 * MI) + i * 32 + lrow;
-                    if (m < p.M) *(f32x2*)(p.ln_mr_out + (long)m * 2) = f32x2{ln_mean[i], ln_rstd[i]};
-                }
-            }
-        }
+        if (MODE == 0 && ln_on) gemm_ln_finish<MI>(p, m0 + wm * (32 * MI), lrow, tile_n == 0 && wn == 0 && lhi == 0, ln_pairs, ln_mean, ln_rstd);
     };
 
     auto compute = [&](int buf) {
@@ -324,7 +245,7 @@ __global__ __launch_bounds__(128 * WM, gemm_waves_per_simd(MI, NI, STAGES, LORA,
             for (int i = 0; i < MI; ++i)
 #pragma unroll
                 for (int j = 0; j < NI; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks & 1][j], xf[ks & 1][i], acc[i][j], 0, 0, 0);
+                    acc[i][j] = mfma_slot(wf[ks & 1][j], xf[ks & 1][i], acc[i][j], ks);
             if (LORA && (ks & 1) == wn) {     // the two waves that share these rows split the adapter's K steps (see epilogue)
 #pragma unroll
                 for (int i = 0; i < MI; ++i)
@@ -334,14 +255,25 @@ __global__ __launch_bounds__(128 * WM, gemm_waves_per_simd(MI, NI, STAGES, LORA,
     };
 
     if constexpr (STAGES == 2) {
+#ifdef SLH_GEMM_PROBE          // ablation build (scripts/build_variant.sh <name> gemm.hip -DSLH_GEMM_PROBE): see GemmArgs.probe
         if (!(p.probe & 8)) stage(0, kt_begin);
+#else
+        stage(0, kt_begin);
+#endif
         ln_finish();
         for (int kt = 0; kt < nk; ++kt) {
             lds_dma_syncthreads();  // drains this wave's glds (explicit vmcnt(0)) and orders all waves
+#ifdef SLH_GEMM_PROBE
             if (kt + 1 < nk && !(p.probe & 1)) stage((kt + 1) & 1, kt_begin + kt + 1);
             if (!(p.probe & 2)) compute(kt & 1);
+#else
+            if (kt + 1 < nk) stage((kt + 1) & 1, kt_begin + kt + 1);
+            compute(kt & 1);
+#endif
         }
+#ifdef SLH_GEMM_PROBE
         if (p.probe & 4) return;
+#endif
     } else {
         // ---- deep LDS ring (STAGES = 3 or 4 slots), for launches that leave ONE workgroup per CU -----------------
         // A CU with a single resident workgroup hides nothing behind other workgroups: with the 2-slot loop above
@@ -477,7 +409,7 @@ __global__ __launch_bounds__(128 * WM, gemm_waves_per_simd(MI, NI, STAGES, LORA,
                     if (j < NI) asm volatile("" ::"v"(wf[set][j]), "v"(xf[set][i]));      // ablation: no MFMA (fragments stay live)
                     else asm volatile("" ::"v"(lf[set]), "v"(xf[set][i]));
 #else
-                    if (j < NI) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[set][j], xf[set][i], acc[i][j], 0, 0, 0);
+                    if (j < NI) acc[i][j] = mfma_slot(wf[set][j], xf[set][i], acc[i][j], set);
                     else if (set == wn) accl[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lf[set], xf[set][i], accl[i], 0, 0, 0);
 #endif
                     if (with_pieces) {
@@ -553,484 +485,7 @@ __global__ __launch_bounds__(128 * WM, gemm_waves_per_simd(MI, NI, STAGES, LORA,
         if (g < nk) body(F_{}, F_{}, F_{});
     }
 
-    // ---- epilogue ---------------------------------------------------------------------------------
-    // acc[i][j][r] = C[m = m0 + wm*32*MI + i*32 + lrow][n = n0 + wn*32*NI + j*32 + (r&3) + 8*(r>>2) + 4*lhi]
-    if (p.splitk > 1) {
-        // split-K, reduced inside the launch in a FIXED order (no fp32 atomics: they commit in arrival order, the sum's last
-        // bits - hence bf16 roundings downstream - would differ from run to run).  Every K slice publishes its partial tile
-        // in ITS OWN fp32 slab (write-through stores), drains them and takes a ticket of the tile; the slice that draws the
-        // last ticket adds all slabs IN SLICE ORDER (its own included, read back like the others: which slice is last
-        // varies, the arithmetic does not) and runs the ordinary epilogue below.  The other slices are done.
-        // The ticket also counts arrivals per XCD (7-bit fields above the 8-bit count): when every slice ran on the reader's
-        // XCD - the launch order puts the slices of a tile on consecutive block ids of one XCD - the partials are read from
-        // that XCD's L2 (workgroup-scope loads: only the L1 is bypassed); otherwise from memory (agent scope).
-        // Slab layout = the accumulator layout: slab[slice][tile][wave][block i,j][q][lane] holds 4 floats, so every store /
-        // load instruction of a wave moves 1 KB of consecutive addresses and nothing needs a bounds check (rows / columns past
-        // M / N are padding inside the slab).  (8-byte row-major pieces, written through, cost ~50 us per launch.)
-        constexpr int TILE_BYTES = BM * BN * 4;
-        const unsigned slab_bytes = (unsigned)(p.tiles_m * p.tiles_n) * TILE_BYTES;
-        const __amdgpu_buffer_rsrc_t slabs = __builtin_amdgcn_make_buffer_rsrc(p.c32, 0, (int)(p.splitk * slab_bytes), 0x00020000);
-        unsigned lane_off = (unsigned)(tile_m * p.tiles_n + tile_n) * TILE_BYTES + wave * (MI * NI * 4096) + lane * 16;
-        asm volatile("" : "+v"(lane_off));      // not to be formed ahead of the K loop and carried through it
-        int lrow_s = lrow;
-        asm volatile("" : "+v"(lrow_s));
-#pragma unroll
-        for (int i = 0; i < MI; ++i) {
-#pragma unroll
-            for (int j = 0; j < NI; ++j)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const f32x4 v = {acc[i][j][q * 4], acc[i][j][q * 4 + 1], acc[i][j][q * 4 + 2], acc[i][j][q * 4 + 3]};
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), slabs,
-                                                           ks_id * slab_bytes + lane_off + ((i * NI + j) * 4 + q) * 1024, 0, 16 /* sc1 */);
-                }
-            const int m = m0 + wm * (32 * MI) + i * 32 + lrow_s;
-            if (m >= p.M) continue;
-            if (LORA) {
-                // T of the tile's rows: each wave of a row pair holds the partial of its own k-steps -> 2 slabs per slice, per
-                // column tile (every column tile reduces its own copy: its last slice cannot wait for another tile's slices)
-                // rank index of accl[i][r]: (r&3) + 8*(r>>2) + 4*lhi  ->  ranks 0-3 / 8-11 in the lhi=0 half, 4-7 in lhi=1
-                float* ts = p.t32 + (((long)tile_n * 2 * p.splitk + ks_id * 2 + wn) * p.M + m) * p.ld_t;
-                if (4 * lhi < p.lora_rank) {
-                    store_pair_sc1(ts + 4 * lhi, accl[i][0], accl[i][1]);
-                    store_pair_sc1(ts + 4 * lhi + 2, accl[i][2], accl[i][3]);
-                }
-                if (lhi == 0 && 8 < p.lora_rank) {
-                    store_pair_sc1(ts + 8, accl[i][4], accl[i][5]);
-                    store_pair_sc1(ts + 10, accl[i][6], accl[i][7]);
-                }
-            }
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's partials have reached the memory side
-        __syncthreads();                                       // ... and every wave is done with the operand stages
-        unsigned long long& arrival = *(unsigned long long*)smem;
-        const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 7;   // HW_REG_XCC_ID
-        if (tid == 0) {
-            unsigned long long* ticket = p.ticket + (long)tile_m * p.tiles_n + tile_n;
-            const unsigned long long mine = 1ull + (1ull << (8 + 7 * xcc));
-            const unsigned long long seen = __hip_atomic_fetch_add(ticket, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + mine;
-            if ((int)(seen & 255) == p.splitk) __hip_atomic_store(ticket, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            arrival = seen;
-        }
-        __syncthreads();
-        const unsigned long long seen = arrival;
-        if ((int)(seen & 255) != p.splitk) return;
-        const bool local = (int)((seen >> (8 + 7 * xcc)) & 127) == p.splitk;     // uniform over the workgroup
-        // slice 0 is loaded straight into the accumulators (their contents are in the slabs now), every further slice as
-        // batches of independent 16-byte loads (one 32-row block): the serial part is one round trip per slice and block
-        auto reduce = [&](auto kLocal) {
-            constexpr int kAux = decltype(kLocal)::value ? 1 /* sc0: this XCD's L2 */ : 16 /* sc1: memory */;
-            auto ld = [&](const float* q) { return decltype(kLocal)::value ? load_pair_l2(q) : load_pair_sc1(q); };
-#pragma unroll
-            for (int i = 0; i < MI; ++i) {
-#pragma unroll
-                for (int j = 0; j < NI; ++j)
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
-                            slabs, lane_off + ((i * NI + j) * 4 + q) * 1024, 0, kAux));
-                        acc[i][j][q * 4] = v[0]; acc[i][j][q * 4 + 1] = v[1]; acc[i][j][q * 4 + 2] = v[2]; acc[i][j][q * 4 + 3] = v[3];
-                    }
-                for (int k = 1; k < p.splitk; ++k) {
-                    f32x4 t[NI * 4];
-#pragma unroll
-                    for (int j = 0; j < NI; ++j)
-#pragma unroll
-                        for (int q = 0; q < 4; ++q)
-                            t[j * 4 + q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
-                                slabs, k * slab_bytes + lane_off + ((i * NI + j) * 4 + q) * 1024, 0, kAux));
-#pragma unroll
-                    for (int j = 0; j < NI; ++j)
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            acc[i][j][q * 4] += t[j * 4 + q][0]; acc[i][j][q * 4 + 1] += t[j * 4 + q][1];
-                            acc[i][j][q * 4 + 2] += t[j * 4 + q][2]; acc[i][j][q * 4 + 3] += t[j * 4 + q][3];
-                        }
-                }
-                const int m = m0 + wm * (32 * MI) + i * 32 + lrow_s;
-                if (m >= p.M) continue;
-                if (LORA) {
-                    // this wave's own half (wn) of every slice, in slice order; the halves meet in the epilogue's exchange
-                    const long tstride = 2L * p.M * p.ld_t;
-                    const float* ts = p.t32 + (((long)tile_n * 2 * p.splitk + wn) * p.M + m) * p.ld_t;
-                    const bool r0 = 4 * lhi < p.lora_rank, r8 = lhi == 0 && 8 < p.lora_rank;
-                    f32x2 t0 = {0.f, 0.f}, t1 = {0.f, 0.f}, t2 = {0.f, 0.f}, t3 = {0.f, 0.f};
-                    for (int k = 0; k < p.splitk; ++k) {
-                        const float* tk = ts + k * tstride;
-                        const f32x2 a0 = r0 ? ld(tk + 4 * lhi) : f32x2{0.f, 0.f}, a1 = r0 ? ld(tk + 4 * lhi + 2) : f32x2{0.f, 0.f};
-                        const f32x2 a2 = r8 ? ld(tk + 8) : f32x2{0.f, 0.f}, a3 = r8 ? ld(tk + 10) : f32x2{0.f, 0.f};
-                        t0 += a0; t1 += a1; t2 += a2; t3 += a3;
-                    }
-                    accl[i][0] = t0[0]; accl[i][1] = t0[1]; accl[i][2] = t1[0]; accl[i][3] = t1[1];
-                    accl[i][4] = t2[0]; accl[i][5] = t2[1]; accl[i][6] = t3[0]; accl[i][7] = t3[1];
-                }
-            }
-        };
-        if (local) reduce(std::true_type{});
-        else reduce(std::false_type{});
-    }
-    // ---- per-column epilogue vectors (bias, per-sample row bias, LayerNorm-fold s / b'), once per workgroup through LDS -------
-    // Read per accumulator quad from global memory they were 4-16 SERIAL round trips at the end of every tile (each load sat
-    // behind a condition: hipcc waits vmcnt(0) at the join); a tile's columns share them, so one thread per column fetches its
-    // four values in one round trip, behind the patches of the store staging.  A row bias qualifies when the tile's rows belong
-    // to one sample (rows_per_sample a multiple of the tile height); otherwise it stays a per-row load below.
-    constexpr int S = 4 * NI;                  // 16-byte slots per staged row
-    constexpr int LOG2S = NI == 2 ? 3 : 2;
-    float* sCol = (float*)(smem + NW * (32 * S * 16) + (LORA ? NW * MI * 2048 : 0));     // [4][BN]
-    const bool rb_tile = p.rowbias != nullptr && p.rows_per_sample % BM == 0;
-    {
-        const int n = n0 + tid;
-        const bool nok = tid < BN && n < p.N;
-        const __bf16* zb = (const __bf16*)slh_zero_page;
-        const float* zf = (const float*)slh_zero_page;
-        const float c0 = (float)*((p.bias && nok) ? p.bias + n : zb);
-        const float c1 = (float)*((rb_tile && nok) ? p.rowbias + (long)(m0 / p.rows_per_sample) * p.ld_rowbias + n : zb);
-        const float c2 = *((ln_on && nok) ? p.ln_s + n : zf);
-        const float c3 = *((ln_on && nok) ? p.ln_b + n : zf);
-        __syncthreads();                       // every wave is done reading the operand stages being reused below
-        if (tid < BN) { sCol[tid] = c0; sCol[BN + tid] = c1; sCol[2 * BN + tid] = c2; sCol[3 * BN + tid] = c3; }
-    }
-    if (p.geglu == 2) {
-        // Backward of GEGLU fused into the backward-data product of the Linear behind it (ff.net.2): the accumulators are
-        // d(ff) - rounded to bf16 as the unfused path stores it - and leave as d(proj) in proj's blocked column order, computed
-        // from the forward's pre-activation (slh_elementwise GEGLU_BWD arithmetic, one launch and one HBM round trip of
-        // d(ff) less):  d_h = dd * bf16(g * Phi(g)),  d_g = bf16(dd * h) * (Phi(g) + g * phi(g)).
-#pragma unroll
-        for (int i = 0; i < MI; ++i) {
-            const int m = m0 + wm * (32 * MI) + i * 32 + lrow;
-            const bool mok = m < p.M;
-#pragma unroll
-            for (int j = 0; j < NI; ++j) {
-                bf16x4 h4[4], g4[4];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {        // the block's pre-activation quads, requested together
-                    const int n = n0 + wn * (32 * NI) + j * 32 + q * 8 + lhi * 4;
-                    const __bf16* src = (mok && n < p.N) ? p.geglu_pre + (long)m * p.ld_pre + (n >> 5) * 64 + (n & 31)
-                                                         : (const __bf16*)slh_zero_page;
-                    h4[q] = *(const bf16x4*)src;
-                    g4[q] = *(const bf16x4*)(src + ((mok && n < p.N) ? 32 : 0));
-                }
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int n = n0 + wn * (32 * NI) + j * 32 + q * 8 + lhi * 4;
-                    if (!mok || n >= p.N) continue;
-                    bf16x4 dh, dg;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float g = (float)g4[q][e], hh = (float)h4[q][e], dd = round_bf16(acc[i][j][q * 4 + e]);
-                        const float cdf = 0.5f * (1.f + erff(g * 0.70710678118654752f));
-                        const float pdf = 0.3989422804014327f * __expf(-0.5f * g * g);
-                        dh[e] = (__bf16)(dd * round_bf16(g * cdf));
-                        dg[e] = (__bf16)(round_bf16(dd * hh) * (cdf + g * pdf));
-                    }
-                    __bf16* po = p.c + (long)m * p.ldc + (n >> 5) * 64 + (n & 31);
-                    *(bf16x4*)po = dh;
-                    *(bf16x4*)(po + 32) = dg;
-                }
-            }
-        }
-        return;
-    }
-    if (p.geglu) {
-        // GEGLU: W rows are stored in 64-row blocks [32 value rows | 32 gate rows]; NI is 2 here, so
-        // sub-tile j=0 holds the values and j=1 the gates of the same 32 output columns.
-        __syncthreads();
-        if (NI == 2) {
-#pragma unroll
-            for (int i = 0; i < MI; ++i) {
-                const int m = m0 + wm * (32 * MI) + i * 32 + lrow;
-                if (m >= p.M) continue;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int n = n0 + wn * 64 + q * 8 + lhi * 4;          // row index of the value rows
-                    const int nout = ((n0 + wn * 64) >> 1) + q * 8 + lhi * 4;
-                    if (n + 32 >= p.N) continue;
-                    float a[4], g[4];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) { a[e] = acc[i][0][q * 4 + e]; g[e] = acc[i][NI - 1][q * 4 + e]; }
-                    const int cl = n - n0;                                  // column inside the tile
-                    if (MODE == 0 && ln_on) {
-                        const f32x4 sa = *(const f32x4*)(sCol + 2 * BN + cl), sg = *(const f32x4*)(sCol + 2 * BN + cl + 32);
-                        const f32x4 ba = *(const f32x4*)(sCol + 3 * BN + cl), bg = *(const f32x4*)(sCol + 3 * BN + cl + 32);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            a[e] = ln_rstd[i] * (a[e] - ln_mean[i] * sa[e]) + ba[e];
-                            g[e] = ln_rstd[i] * (g[e] - ln_mean[i] * sg[e]) + bg[e];
-                        }
-                    }
-                    if (p.bias) {
-                        const f32x4 ba = *(const f32x4*)(sCol + cl), bg = *(const f32x4*)(sCol + cl + 32);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) { a[e] += ba[e]; g[e] += bg[e]; }
-                    }
-                    bf16x4 o;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        // reference rounds proj(x) to bf16 before chunk/gelu
-                        const float av = round_bf16(a[e]), gv = round_bf16(g[e]);
-                        o[e] = (__bf16)(av * round_bf16(gelu_erf_f(gv)));
-                    }
-                    *(bf16x4*)(p.c + (long)m * p.ldc + nout) = o;
-                    if (p.geglu_pre) {      // training: proj(x) itself, in the column order of this product, for the GEGLU backward
-                        *(bf16x4*)(p.geglu_pre + (long)m * p.ld_pre + n) = bf16x4{(__bf16)a[0], (__bf16)a[1], (__bf16)a[2], (__bf16)a[3]};
-                        *(bf16x4*)(p.geglu_pre + (long)m * p.ld_pre + n + 32) = bf16x4{(__bf16)g[0], (__bf16)g[1], (__bf16)g[2], (__bf16)g[3]};
-                    }
-                }
-            }
-        }
-        return;
-    }
-
-    // The MFMA result layout gives a lane 4 consecutive columns of ONE row, so a direct store touches 32 rows per
-    // instruction with 8-byte pieces (store-issue bound).  Each wave therefore transposes its 32 x (32*NI) sub-tile
-    // through a private, swizzled LDS patch and writes whole 64/128-byte row segments with 16-byte stores.
-    if (LORA) {
-        // T = x . A^T of a row block was accumulated half by each of the two waves that own those rows (wn = 0 took the
-        // even k-steps, wn = 1 the odd ones: the adapter costs half an MFMA per k-step and wave instead of one); the
-        // partials are exchanged through LDS behind the staging patches.  Only registers 0-7 of accl carry ranks < 12.
-        float* ex = (float*)(smem + NW * (32 * S * 16));
-#pragma unroll
-        for (int i = 0; i < MI; ++i)
-#pragma unroll
-            for (int r = 0; r < 8; ++r) ex[(wave * MI * 8 + i * 8 + r) * 64 + lane] = accl[i][r];
-        __syncthreads();
-#pragma unroll
-        for (int i = 0; i < MI; ++i)
-#pragma unroll
-            for (int r = 0; r < 8; ++r) accl[i][r] += ex[((wave ^ 1) * MI * 8 + i * 8 + r) * 64 + lane];
-    } else {
-        __syncthreads();                       // the column vectors are in LDS
-    }
-    char* sE = smem + wave * (32 * S * 16);
-    const float lscale = (LORA || p.lora_t != nullptr) ? *p.lora_scale : 0.f;
-    const int ncol0 = n0 + wn * (32 * NI);
-    // Fused adapter, forward form (lora_up [N][4]): the up-projection  scale * T . B^T  is one more MFMA per accumulator
-    // tile.  T (ranks x rows, already in the accumulator layout of a B operand up to a fixed permutation of the rank
-    // index) is scaled and rounded to bf16 - the reference's down-projection output is a bf16 tensor too - and the A
-    // operand holds, for output column n of group g, B[n][0..3] at the k positions of ranks 4g..4g+3 and zeros elsewhere.
-    // k index of a lane: 8*lhi + e  <->  rank: lhi = 0: e < 4 -> e, e >= 4 -> 8 + (e - 4);  lhi = 1: e < 4 -> 4 + e, else unused
-    const bool mfma_up = LORA && !p.lora_up_rmajor;
-    if (mfma_up) {
-        bf16x8 ua[NI];
-#pragma unroll
-        for (int j = 0; j < NI; ++j) {
-            const int n = ncol0 + j * 32 + lrow;
-            bf16x4 u4 = {(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
-            int g = -1;
-            if (n < p.N) { u4 = *(const bf16x4*)(p.lora_up + (long)n * 4); g = n / p.lora_cols_per_group; }
-            const bool lo = lhi == 0 ? g == 0 : g == 1;        // e < 4: ranks 0-3 (lhi 0) / 4-7 (lhi 1)
-            const bool hi = lhi == 0 && g == 2;                // e >= 4: ranks 8-11 (lhi 0 only)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                ua[j][e] = lo ? u4[e] : (__bf16)0.f;
-                ua[j][4 + e] = hi ? u4[e] : (__bf16)0.f;
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < MI; ++i) {
-            bf16x8 tb;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) tb[e] = (__bf16)(lscale * accl[i][e]);
-#pragma unroll
-            for (int j = 0; j < NI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ua[j], tb, acc[i][j], 0, 0, 0);
-        }
-    }
-    const bool have_t = (LORA || p.lora_t != nullptr) && !mfma_up;      // the per-element forms below
-    // wave-uniform: this wave's columns belong to the V block that slh_attn_fwd wants head-transposed
-    const bool to_vt = p.vt != nullptr && ncol0 >= p.vt_col0;
-#pragma unroll
-    for (int i = 0; i < MI; ++i) {
-        const int mbase = m0 + wm * (32 * MI) + i * 32;
-        const int m = mbase + lrow;
-        const bool mok = m < p.M;
-        float ln_k = 0.f, ln_sum = 0.f, ln_sq = 0.f;
-        f32x4 tv[3];
-#pragma unroll
-        for (int g = 0; g < 3; ++g) tv[g] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (LORA && (have_t || p.lora_t_out)) {
-            // ranks 0-3 sit in registers 0-3 of the lhi=0 half, 4-7 in registers 0-3 of the lhi=1 half, 8-11 in
-            // registers 4-7 of the lhi=0 half: one exchange with lane^32 gives every lane all of its row's T
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float x0 = accl[i][e], x1 = accl[i][4 + e];
-                const float y0 = __shfl_xor(x0, 32, 64), y1 = __shfl_xor(x1, 32, 64);
-                tv[0][e] = lhi == 0 ? x0 : y0;
-                tv[1][e] = lhi == 1 ? x0 : y0;
-                tv[2][e] = lhi == 0 ? x1 : y1;
-            }
-            if (mok && p.lora_t_out && tile_n == 0 && wn == 0 && lhi == 0) {
-#pragma unroll
-                for (int g = 0; g < 3; ++g)
-                    if (g * 4 < p.lora_rank) *(f32x4*)(p.lora_t_out + (long)m * p.ld_t + g * 4) = tv[g];
-            }
-        } else if (!LORA && p.lora_t && mok) {
-#pragma unroll
-            for (int g = 0; g < 3; ++g)
-                if (g * 4 < p.ld_t) tv[g] = *(const f32x4*)(p.lora_t + (long)m * p.ld_t + g * 4);
-        }
-        // a row bias whose tile spans samples stays a per-row load
-        const __bf16* rb = (p.rowbias && !rb_tile && mok) ? p.rowbias + (long)(m / p.rows_per_sample) * p.ld_rowbias : nullptr;
-        const int hb = (lrow >> LOG2S) & 1;
-        bf16x4 okeep[NI][4];          // vt_also_c: the rounded quads, for the row-major store behind the transposed one
-        // the residual quads of the whole 32-row block are requested together (one round trip instead of one per quad)
-        bf16x4 res4[NI][4];
-        if (p.residual) {
-#pragma unroll
-            for (int j = 0; j < NI; ++j)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int n = ncol0 + j * 32 + q * 8 + lhi * 4;
-                    res4[j][q] = *((mok && n < p.N) ? (const bf16x4*)(p.residual + (long)m * p.ld_res + n) : (const bf16x4*)slh_zero_page);
-                }
-        }
-#pragma unroll
-        for (int j = 0; j < NI; ++j) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int n = ncol0 + j * 32 + q * 8 + lhi * 4;
-                const int cl = n - n0;                                      // column inside the tile
-                float v[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = acc[i][j][q * 4 + e];
-                if (mok && n < p.N) {
-                    if (MODE == 0 && ln_on) {
-                        const f32x4 s4 = *(const f32x4*)(sCol + 2 * BN + cl), b4 = *(const f32x4*)(sCol + 3 * BN + cl);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = ln_rstd[i] * (v[e] - ln_mean[i] * s4[e]) + b4[e];
-                    }
-                    if (p.bias) {
-                        const f32x4 b4 = *(const f32x4*)(sCol + cl);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] += b4[e];
-                    }
-                    if (rb_tile) {
-                        const f32x4 b4 = *(const f32x4*)(sCol + BN + cl);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] += b4[e];
-                    }
-                    if (rb) {
-                        const bf16x4 b4 = *(const bf16x4*)(rb + n);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] += (float)b4[e];
-                    }
-                    if (have_t && !p.lora_up_rmajor) {
-                        const int g = n / p.lora_cols_per_group;
-                        const f32x4 t = g == 0 ? tv[0] : (g == 1 ? tv[1] : tv[2]);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            const bf16x4 u = *(const bf16x4*)(p.lora_up + (long)(n + e) * 4);
-                            v[e] += lscale * (t[0] * (float)u[0] + t[1] * (float)u[1] +
-                                              t[2] * (float)u[2] + t[3] * (float)u[3]);
-                        }
-                    } else if (have_t) {
-                        // backward-data form: the "up" matrix is lora_down as stored, [rank][N], rank 4..12
-                        float s4[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                        for (int g = 0; g < 3; ++g) {
-                            if (g * 4 < p.lora_rank) {
-#pragma unroll
-                                for (int r = 0; r < 4; ++r) {
-                                    const bf16x4 u = *(const bf16x4*)(p.lora_up + (long)(g * 4 + r) * p.N + n);
-#pragma unroll
-                                    for (int e = 0; e < 4; ++e) s4[e] += tv[g][r] * (float)u[e];
-                                }
-                            }
-                        }
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] += lscale * s4[e];
-                    }
-                    if (p.residual) {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] += (float)res4[j][q][e];
-                    }
-                }
-                bf16x4 o;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) o[e] = (__bf16)v[e];
-                if (p.ln_out) {                 // statistics of the stored (rounded) values, shifted by the lane's first one
-                    if (j == 0 && q == 0) { ln_k = (float)o[0]; ln_sum = 0.f; ln_sq = 0.f; }
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) { const float dlt = (float)o[e] - ln_k; ln_sum += dlt; ln_sq += dlt * dlt; }
-                }
-                if (to_vt) {
-                    // transposed patch sT[n_local][m_local] (32*NI rows of 32 bf16): column n of the tile becomes a
-                    // 64-byte run along m
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        *(__bf16*)(sE + ((j * 32 + q * 8 + lhi * 4 + e) * 32 + lrow) * 2) = o[e];
-                    okeep[j][q] = o;
-                    continue;
-                }
-                // logical 16-byte slot j*4+q, 8-byte half lhi of row lrow; slot ^ row and half ^ row-bit keep both
-                // the 8-byte writes and the 16-byte row reads off each other's banks
-                const int slot = (j * 4 + q) ^ (lrow & (S - 1));
-                *(bf16x4*)(sE + lrow * (S * 16) + slot * 16 + ((lhi ^ hb) << 3)) = o;
-            }
-        }
-        if (NI == 2 && p.ln_out) {
-            // LayerNorm statistics of this row's 64 columns (producer side of the folded LayerNorm): the lane holds 32 of
-            // them, its partner lane^32 the other 32; (mean, M2) from sums shifted by a sample of the row (no cancellation), merged (Chan)
-            const float dm = ln_sum * (1.f / (16 * NI));
-            const float mu = ln_k + dm;
-            const float m2 = fmaxf(ln_sq - ln_sum * dm, 0.f);
-            const float mu_o = __shfl_xor(mu, 32, 64), m2_o = __shfl_xor(m2, 32, 64);
-            const float delta = mu_o - mu;
-            if (lhi == 0 && mok && ncol0 < p.N)
-                *(f32x2*)(p.ln_out + ((long)(ncol0 >> 6) * p.M + m) * 2) =
-                    f32x2{mu + 0.5f * delta, m2 + m2_o + delta * delta * (8.f * NI)};
-        }
-        __builtin_amdgcn_wave_barrier();       // same-wave LDS ops retire in order; only the compiler must not reorder
-        if (to_vt) {
-            const int Dp = (p.vt_D + 63) & ~63;
-#pragma unroll
-            for (int it = 0; it < 2 * NI; ++it) {
-                const int idx = it * 64 + lane;
-                const int nl = idx >> 2, seg = idx & 3;
-                const bf16x8 t8 = *(const bf16x8*)(sE + nl * 64 + seg * 16);
-                const int m2 = mbase + seg * 8, n2 = ncol0 + nl;
-                if (m2 < p.M && n2 < p.N) {
-                    const int nv = n2 - p.vt_col0;
-                    const int hh = nv / p.vt_D, dd = nv - hh * p.vt_D;
-                    const int bb = m2 / p.vt_tokens, tt = m2 - bb * p.vt_tokens;
-                    *(bf16x8*)(p.vt + (((long)bb * p.vt_heads + hh) * Dp + dd) * p.vt_ld + tt) = t8;
-                }
-            }
-            __builtin_amdgcn_wave_barrier();
-            if (!p.vt_also_c) continue;
-            // ... and row-major into c as well (training: the backward reads V / dO in both layouts): the same quads through the
-            // row patch
-#pragma unroll
-            for (int j = 0; j < NI; ++j)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int slot = (j * 4 + q) ^ (lrow & (S - 1));
-                    *(bf16x4*)(sE + lrow * (S * 16) + slot * 16 + ((lhi ^ hb) << 3)) = okeep[j][q];
-                }
-            __builtin_amdgcn_wave_barrier();
-        }
-#pragma unroll
-        for (int it = 0; it < S / 2; ++it) {
-            const int idx = it * 64 + lane;
-            const int row = idx / S, slot = idx % S;
-            bf16x8 t8 = *(const bf16x8*)(sE + row * (S * 16) + ((slot ^ (row & (S - 1))) << 4));
-            if ((row >> LOG2S) & 1) t8 = __builtin_shufflevector(t8, t8, 4, 5, 6, 7, 0, 1, 2, 3);
-            const int m2 = mbase + row, n2 = ncol0 + slot * 8;
-            if (m2 < p.M && n2 < p.N) {
-                __bf16* dst = p.c + (long)m2 * p.ldc + n2;
-                if (n2 + 8 <= p.N) {
-                    if (p.store16) {
-                        *(bf16x8*)dst = t8;
-                    } else {
-                        *(bf16x4*)dst = __builtin_shufflevector(t8, t8, 0, 1, 2, 3);
-                        *(bf16x4*)(dst + 4) = __builtin_shufflevector(t8, t8, 4, 5, 6, 7);
-                    }
-                } else {
-                    *(bf16x4*)dst = __builtin_shufflevector(t8, t8, 0, 1, 2, 3);   // N % 4 == 0: exactly 4 columns left
-                }
-            }
-        }
-        __builtin_amdgcn_wave_barrier();
-    }
+    gemm_epilogue<MI, NI, MODE, LORA, NW, 2>(p, smem, acc, accl, ln_mean, ln_rstd, ln_on, tile_m, tile_n, ks_id, wave, wm, wn);
 }
 
 template <int MI, int NI, int MODE, bool LORA, int WM>
@@ -1065,7 +520,9 @@ static void pick_tile(const slh_gemm_desc* d, int& MI, int& NI, int& WM) {
     MI = 2; NI = 2; WM = 2;
     if (d->tile) {
         MI = (d->tile >> 4) & 15; NI = d->tile & 15;
-        WM = ((d->tile >> 12) & 15) == 4 ? 4 : 2;
+        const int wcode = (d->tile >> 12) & 15;
+        WM = wcode == 4 ? 4 : 2;
+        if (wcode == 8) { WM = 8; MI = 4; NI = 2; }      // 256 x 256, ping-pong K loop (gemm8p.hip)
         if (MI) return;
         MI = 2; NI = 2; WM = 2;
     }
@@ -1165,8 +622,12 @@ extern "C" int slh_gemm(const slh_gemm_desc* d, slh_stream_t stream) {
 
     int MI = 2, NI = 2, WM = 2;
     pick_tile(d, MI, NI, WM);
-    SLH_CHECK((MI == 1 || MI == 2) && (NI == 1 || NI == 2), "slh_gemm: bad tile");
-    SLH_CHECK(WM == 2 || NI == 2 || MI == 1, "slh_gemm: 8-wave tiles are 128x64, 128x128 or 256x128");
+    if (WM == 8) {
+        SLH_CHECK(!d->lora_down, "slh_gemm: the 256 x 256 tile does not take a fused adapter (lora_down)");
+    } else {
+        SLH_CHECK((MI == 1 || MI == 2) && (NI == 1 || NI == 2), "slh_gemm: bad tile");
+        SLH_CHECK(WM == 2 || NI == 2 || MI == 1, "slh_gemm: 8-wave tiles are 128x64, 128x128 or 256x128");
+    }
     SLH_CHECK(d->w_layout == 0 || d->w_layout == 1, "slh_gemm: bad w_layout");
     if (d->geglu == 1) SLH_CHECK(NI == 2, "slh_gemm: geglu needs NI=2");
 
@@ -1207,7 +668,11 @@ extern "C" int slh_gemm(const slh_gemm_desc* d, slh_stream_t stream) {
         SLH_CHECK(((uintptr_t)d->ln_in & 7) == 0 && ((uintptr_t)d->ln_s & 15) == 0 && ((uintptr_t)d->ln_b & 15) == 0,
                   "slh_gemm: ln_in / ln_s / ln_b alignment");
     }
-    a.probe = d->reserved_;
+#ifdef SLH_GEMM_PROBE
+    a.probe = d->reserved_;      // ablation builds only; the default library ignores the field (it is reserved)
+#else
+    a.probe = 0;
+#endif
     a.splitk = (d->tile >> 16) & 15;
     a.c32 = d->splitk_c32;
     a.t32 = d->splitk_t32;
@@ -1235,7 +700,7 @@ extern "C" int slh_gemm(const slh_gemm_desc* d, slh_stream_t stream) {
         SLH_CHECK(d->splitk_slabs >= a.splitk, "slh_gemm: split-K into %d slices but the workspace holds %d slabs", a.splitk,
                   d->splitk_slabs);
         SLH_CHECK(d->splitk_ticket, "slh_gemm: split-K needs the arrival tickets splitk_ticket (zeroed once)");
-        SLH_CHECK((long)a.splitk * ((d->M + 255) / 256 * 256L) * ((d->N + 127) / 128 * 128L) * 4 < (1L << 31),
+        SLH_CHECK((long)a.splitk * ((d->M + 255) / 256 * 256L) * ((d->N + 255) / 256 * 256L) * 4 < (1L << 31),
                   "slh_gemm: split-K slabs beyond 2 GB");
         SLH_CHECK(((uintptr_t)d->splitk_ticket & 7) == 0 && d->N % 4 == 0, "slh_gemm: split-K needs N %% 4 == 0 and 8-byte aligned tickets");
         SLH_CHECK(!d->lora_down || a.t32, "slh_gemm: split-K with a fused adapter needs the slab workspace splitk_t32");
@@ -1244,6 +709,12 @@ extern "C" int slh_gemm(const slh_gemm_desc* d, slh_stream_t stream) {
         a.splitk = 1;
     }
     a.store16 = (d->ldc % 8 == 0) && (((uintptr_t)d->c & 15) == 0);
+    if (WM == 8) {
+        a.tiles_m = (d->M + 255) / 256;
+        a.tiles_n = (d->N + 255) / 256;
+        a.group_m = pick_group_m(d, a.tiles_m);
+        return launch_gemm8p(a, d->mode, (hipStream_t)stream);
+    }
     a.tiles_m = (d->M + 32 * MI * WM - 1) / (32 * MI * WM);
     a.tiles_n = (d->N + 64 * NI - 1) / (64 * NI);
     a.group_m = pick_group_m(d, a.tiles_m);

@@ -41,7 +41,7 @@ def _pack_conv(w):
 
 
 @pytest.mark.parametrize("tile", [0x22, 0x21, 0x12, 0x11, 0x321, 0x312, 0x311, 0x4022, 0x4322, 0x4012, 0x4312, 0x4011,
-                                  0x322, 0x422, 0x421, 0x412, 0x411, 0x4422, 0x4412, 0x4411])
+                                  0x322, 0x422, 0x421, 0x412, 0x411, 0x4422, 0x4412, 0x4411, 0x8042])
 @pytest.mark.parametrize("M,N,K", [(256, 128, 64), (300, 320, 320), (1024, 640, 1280), (154, 256, 2048)])
 def test_gemm_dense(dev, M, N, K, tile):
     torch.manual_seed(M + N + K)
@@ -58,7 +58,7 @@ def test_gemm_dense(dev, M, N, K, tile):
     report(f"gemm_dense M{M} N{N} K{K} tile{tile:x}", c, ref, TOL)
 
 
-@pytest.mark.parametrize("tile", [0x22, 0x21, 0x12, 0x11, 0x311, 0x4022, 0x4012, 0x4011, 0x4312, 0x422, 0x412, 0x4412, 0x4322])
+@pytest.mark.parametrize("tile", [0x22, 0x21, 0x12, 0x11, 0x311, 0x4022, 0x4012, 0x4011, 0x4312, 0x422, 0x412, 0x4412, 0x4322, 0x8042])
 def test_gemm_packed_weights(dev, tile):
     """w_layout = 1: the frozen weights in the tile-packed, pre-swizzled order (sliders_amd.weights.pack_gemm_w)."""
     from sliders_amd.weights import pack_gemm_w
@@ -92,7 +92,7 @@ def test_gemm_packed_weights(dev, tile):
     report(f"conv_packed tile{tile:x}", c, _to_pix(ref_img), TOL)
 
 
-@pytest.mark.parametrize("tile", [0, 0x422, 0x4412, 0x4322, 0x312])
+@pytest.mark.parametrize("tile", [0, 0x422, 0x4412, 0x4322, 0x312, 0x8042])
 def test_gemm_two_source_rowbias_lora(dev, tile):
     torch.manual_seed(1)
     B, HW, C0, C1, N = 2, 160, 128, 64, 320
@@ -121,7 +121,7 @@ def test_gemm_two_source_rowbias_lora(dev, tile):
         report(f"gemm_2src_rowbias_lora g{groups}", c, ref, TOL)
 
 
-@pytest.mark.parametrize("tile", [0, 0x22, 0x12, 0x21, 0x11, 0x4012, 0x4011, 0x4022, 0x422, 0x4412, 0x4322, 0x312])
+@pytest.mark.parametrize("tile", [0, 0x22, 0x12, 0x21, 0x11, 0x4012, 0x4011, 0x4022, 0x422, 0x4412, 0x4322, 0x312, 0x8042])
 def test_gemm_head_transposed_v_store(dev, tile):
     """vt_out: the V third of a fused q|k|v projection leaves the epilogue in slh_attn_fwd's [B][H][D][T] layout
     (what slh_transpose_heads would make of c[:, 2C:]); q and k still land in c.  With the LoRA term of to_q/k/v."""
@@ -183,7 +183,7 @@ def test_gemm_geglu(dev):
     b = bf(torch.randn(N, device=dev))
     from sliders_amd.weights import _geglu_perm
     wp, bp = _geglu_perm(w), _geglu_perm(b)
-    for tile in (0x22, 0x12, 0x4022, 0x4312, 0x422, 0x412, 0x4412, 0x4322):
+    for tile in (0x22, 0x12, 0x4022, 0x4312, 0x422, 0x412, 0x4412, 0x4322, 0x8042):
         c = torch.zeros(M, n_out, device=dev, dtype=torch.bfloat16)
         d = lib.GemmDesc(a0=p(x), w=p(wp), bias=p(bp), c=p(c), lda0=K, ca0=K, mode=0, stride=1, ldw=K, M=M, N=N, K=K,
                          ldc=n_out, geglu=1, rows_per_sample=M, tile=tile)
@@ -238,7 +238,7 @@ def test_gemm_geglu(dev):
     report("geglu_bwd", dpre, _perm_cols(pr.grad), 1.5e-2)
 
 
-@pytest.mark.parametrize("tile", [0, 0x4412, 0x22, 0x11, 0x4322, 0x24412])
+@pytest.mark.parametrize("tile", [0, 0x4412, 0x22, 0x11, 0x4322, 0x24412, 0x8042])
 def test_gemm_geglu_backward_form(dev, tile):
     """slh_gemm_desc.geglu = 2: the backward-data product of the Linear behind a GEGLU writes d(proj) itself - bit-identical to
     the two-launch form (plain product -> bf16 d(ff) -> slh_elementwise GEGLU_BWD with the forward's pre-activation)."""
@@ -290,7 +290,7 @@ def test_gemm_layernorm_folded(dev, C, offset):
     res = bf(torch.randn(M, C, device=dev) * 2)
     gamma, beta = bf(torch.randn(C, device=dev) * 0.5 + 1.0), bf(torch.randn(C, device=dev) * 0.3)
     h_ref = bf(o.float() @ wo.float().t() + bo.float() + res.float())
-    for ptile in (0x4412, 0x422, 0x12, 0x4022):
+    for ptile in (0x4412, 0x422, 0x12, 0x4022, 0x8042):
         h = torch.zeros(M, C, device=dev, dtype=torch.bfloat16)
         chunks = torch.full((C // 64, M, 2), float("nan"), device=dev)      # chunk-major
         d = lib.GemmDesc(a0=p(o), w=p(wo), bias=p(bo), residual=p(res), c=p(h), lda0=C, ca0=C, mode=0, stride=1, ldw=C, M=M, N=C,
@@ -311,7 +311,7 @@ def test_gemm_layernorm_folded(dev, C, offset):
         w = bf(torch.randn(N, C, device=dev) / math.sqrt(C))
         wf, sv, bp = fold_layernorm(w, None, gamma, beta)
         ref = ln.float() @ w.float().t()
-        for tile in (0x4412, 0x22, 0x11, 0x4322):
+        for tile in (0x4412, 0x22, 0x11, 0x4322, 0x8042):
             c = torch.zeros(M, N, device=dev, dtype=torch.bfloat16)
             mr = torch.full((M, 2), float("nan"), device=dev)
             d = lib.GemmDesc(a0=p(h), w=p(wf), c=p(c), lda0=C, ca0=C, mode=0, stride=1, ldw=C, M=M, N=N, K=C, ldc=N,
@@ -333,7 +333,7 @@ def test_gemm_layernorm_folded(dev, C, offset):
         wf, sv, bp = _geglu_perm(wf), _geglu_perm(sv).contiguous(), _geglu_perm(bp).contiguous()
         proj = bf(ln.float() @ wg.float().t() + bg.float()).float()
         refg = proj[:, :n_out] * bf(F.gelu(proj[:, n_out:])).float()
-        for tile in (0x4412, 0x12, 0x4012):
+        for tile in (0x4412, 0x12, 0x4012, 0x8042):
             c = torch.zeros(M, n_out, device=dev, dtype=torch.bfloat16)
             d = lib.GemmDesc(a0=p(h), w=p(wf), c=p(c), lda0=C, ca0=C, mode=0, stride=1, ldw=C, M=M, N=2 * n_out, K=C, ldc=n_out,
                              geglu=1, rows_per_sample=M, tile=tile, ln_in=p(chunks), ln_in_chunks=C // 64, ln_s=p(sv), ln_b=p(bp),
@@ -382,7 +382,7 @@ def _perm_cols(g):
 
 
 @pytest.mark.parametrize("stride,xform", [(1, 0), (2, 0), (1, 1), (1, 2)])
-@pytest.mark.parametrize("tile", [0x22, 0x11, 0x312, 0x311, 0x4022, 0x4312, 0x4011, 0x422, 0x411, 0x4412, 0x4322])
+@pytest.mark.parametrize("tile", [0x22, 0x11, 0x312, 0x311, 0x4022, 0x4312, 0x4011, 0x422, 0x411, 0x4412, 0x4322, 0x8042])
 def test_gemm_conv3x3(dev, stride, xform, tile):
     torch.manual_seed(3 + stride + xform)
     B, H, W, Ci, Co = 2, 12, 20, 128, 192
@@ -403,7 +403,7 @@ def test_gemm_conv3x3(dev, stride, xform, tile):
     report(f"gemm_conv s{stride} x{xform} tile{tile:x}", c, _to_pix(ref_img), TOL)
 
 
-@pytest.mark.parametrize("tile", [0, 0x422, 0x4412, 0x4322])
+@pytest.mark.parametrize("tile", [0, 0x422, 0x4412, 0x4322, 0x8042])
 def test_gemm_conv_two_source_and_skinny(dev, tile):
     torch.manual_seed(5)
     B, H, W, C0, C1, Co = 2, 16, 16, 128, 64, 128
