@@ -72,10 +72,13 @@ typedef struct slh_gemm_desc {
     int32_t geglu;           /* 1: out[:, j] = a_j * gelu(g_j); W rows pre-permuted in 64-row blocks [32 a | 32 g].
                                 2: backward form, for the backward-data product of the Linear BEHIND a GEGLU: the result d(ff)
                                 [M][N] leaves as d(proj) [M][2N] in proj's blocked column order, computed with the forward's
-                                pre-activation geglu_pre (slh_elementwise GEGLU_BWD fused; bare product only) */
+                                pre-activation geglu_pre (slh_elementwise GEGLU_BWD fused; bare product only).
+                                3: as 1 with W rows pre-permuted in 32-row blocks [16 a | 16 g] (any tile; no geglu_pre) */
     int32_t tile;            /* 0 auto; else (S<<16)|(WM<<12)|(stages<<8)|(MI<<4)|NI, MI,NI in {1,2}, WM in {0|2, 4}: WM*2 waves per
                                 workgroup, block tile (32*MI*WM) x (64*NI); stages 0|2: double buffer, 3|4: deep LDS ring;
-                                S: split-K factor (0|1 none), needs splitk_c32 */
+                                S: split-K factor (0|1 none), needs splitk_c32.
+                                WM = 8: ping-pong K loops, one 8-wave workgroup per CU (csrc/gemm8p.hip): 0x8042 = 256 x 256
+                                (no fused adapter), 0x801<NI> = 128 x 64*NI, NI = 3..5 (geglu 0 | 3 only, no ln_out / vt_out) */
     int32_t lora_rank;       /* 0 = 4.  With lora_up_rmajor: total rank 4 | 8 | 12 (T has that many columns) */
     int32_t lora_up_rmajor;  /* 1: lora_up is [rank][N] (= lora_down as stored): backward-data LoRA term */
     int32_t w_layout;        /* 0: w is [N][ldw].  1: frozen weights repacked once at load time into the order the kernel

@@ -17,7 +17,7 @@ from sliders_amd import lib
 from sliders_amd.config import CONFIGS
 from sliders_amd.lora_store import LoraStore
 from sliders_amd.random_init import random_state_dict
-from sliders_amd.tuning import gemm_key
+from sliders_amd.tuning import gemm_key, tile_ok
 from sliders_amd.unet import UNetEngine
 
 ap = argparse.ArgumentParser()
@@ -26,7 +26,7 @@ ap.add_argument("--hw", type=int, default=128)
 ap.add_argument("--out", default=None)
 ap.add_argument("--reps", type=int, default=2)
 ap.add_argument("--tiles", default="11,12,21,22,4011,4012,4022,322,422,412,421,4412,4322,4411,"
-                "20412,40412,80412,20421,40421,80421,20422,40422,24412,44412,40411,80411,f0412")
+                "20412,40412,80412,20421,40421,80421,20422,40422,24412,44412,40411,80411,f0412,8015,8014,8013,8042,28015,28014")
 ap.add_argument("--fwd-only", action="store_true")
 ap.add_argument("--incremental", action="store_true",
                 help="baseline = the committed table; a candidate replaces an entry only when it is > 2 %% faster")
@@ -62,6 +62,8 @@ def launch(op, d):
 
 def valid(d, tile):
     mi, ni, wm = (tile >> 4) & 15, tile & 15, (tile >> 12) & 15
+    if not tile_ok(d, tile):
+        return False
     if (tile >> 16) & 15:                       # split-K candidates only where the planner provisioned a workspace
         if not d.splitk_c32 or (d.K // 64) < 4 * ((tile >> 16) & 15) or ((tile >> 16) & 15) > d.splitk_slabs:
             return False

@@ -360,17 +360,297 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const GemmArgs p) {
     gemm_epilogue<MI, NI, MODE, LORA, NW, WN>(p, smem, acc, accl, ln_mean, ln_rstd, ln_on, tile_m, tile_n, ks_id, wave, grp, wc);
 }
 
+
+// ---- layout B: 128 x (64*NI) block tile, waves 4 (M) x 2 (N) as in gemm.hip's 8-wave tiles, 32 x (32*NI) per wave ---------------
+// The same ping-pong schedule with the phases cut along N: phase p multiplies the wave's 32 rows with its column blocks 2p, 2p+1
+// (the last phase one block when NI is odd; one block per phase for NI < 5, which keeps >= 3 phases per K tile).  Group g = waves 4g .. 4g+3 = rows g*64 .. +64.  Staging units in need order:
+// UX (all 128 X rows, 2 pieces per wave, read in phase 0), UW_p (the W rows of phase p's blocks for both wave columns: 64 rows
+// = 1 piece per wave and block).  A unit needed in phase f is issued NP + 1 phases ahead (into the rows its buffer's previous
+// tile gave up NP + 1 - 2*NP + ... >= 2 phases earlier) and waited for in phase f - 1 with vmcnt(G), G = NI + 2 = the pieces of
+// one K tile per wave: exactly one K tile of LDS-DMA stays in flight across every barrier.
+template <int NI, int MODE, bool LORA>
+__global__ __launch_bounds__(512, 2) void gemm8pb_kernel(const GemmArgs p) {
+    constexpr int MI = 1, NW = 8, WN = 2;
+    constexpr int BM = 128, BN = 64 * NI;
+    constexpr int XB = BM * 128, WB = BN * 128, LB = LORA ? 32 * 128 : 0, BUF = XB + WB + LB;
+    constexpr int BP = NI >= 5 ? 2 : 1;              // column blocks per phase
+    constexpr int NP = (NI + BP - 1) / BP;           // phases per K tile; re-staging a region NP + 1 phases ahead of its next read
+                                                     // leaves NP - 1 >= 2 phases behind its last one (see the 256 x 256 kernel)
+    constexpr int G = NI + 2 + (LORA ? 1 : 0);       // LDS-DMA pieces per wave and K tile
+    // LORA: the rank-r down matrix (lora_down [r][K], r <= 12, zero-padded to 32 rows) rides along as a third operand tile, as in
+    // gemm.hip: its piece travels with the X unit, the two waves that share 32 rows split its k-steps (wn = 0 the even ones), their
+    // MFMAs go into the last - shortest - phase, and the shared epilogue's exchange (wave ^ 1) joins the halves.
+    static_assert(NI >= 3 && NI <= 5 && NP >= 3, "128 x 192 ... 128 x 320");
+    static_assert(gemm_epilogue_lds(MI, NI, NW, WN, LORA) <= 2 * BUF, "epilogue staging must fit the operand buffers");
+    static_assert(2 * BUF <= 160 * 1024, "LDS");
+    __shared__ __attribute__((aligned(16))) char smem[2 * BUF];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1, grp = wave >> 2;
+    const int lrow = lane & 31, lhi = lane >> 5;
+
+    int tile_m, tile_n, ks_id;
+    gemm_map_tile(p, tile_m, tile_n, ks_id);
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+    int kt_begin = 0, nk = p.K / BK;
+    if (p.splitk > 1) {
+        const int per = (nk + p.splitk - 1) / p.splitk;
+        kt_begin = ks_id * per;
+        nk = min(nk, kt_begin + per) - kt_begin;
+        if (nk <= 0) return;
+    }
+
+    // ---- staging geometry ---------------------------------------------------------------------------------------------------------
+    // X: 16 groups of 8 rows, wave w copies groups w and w + 8 (rows w*8, 64 + w*8).
+    // W block j (both wave columns: 64 rows = 8 groups): wave w copies group w = (wn' = w >> 2, r8 = w & 3): row wn'*32*NI + j*32 + r8*8
+    const int frow = lane >> 3, fslot = lane & 7;
+    const int cin = p.ca0 + p.ca1;
+    const int xrow0 = wave * 8;                                      // + {0, 64}
+    const int wrow0 = (wave >> 2) * (32 * NI) + (wave & 3) * 8;      // + j*32
+    int xb[2], xoy[2], xox[2];
+    if (MODE == 1) {
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            int m = m0 + xrow0 + a * 64 + frow;
+            m = m < p.M ? m : p.M - 1;
+            const int hw = p.ho * p.wo;
+            const int b = m / hw;
+            const int rem = m - b * hw;
+            const int oy = rem / p.wo;
+            xb[a] = b; xoy[a] = oy; xox[a] = rem - oy * p.wo;
+        }
+    }
+    const int wkstep = p.w_packed ? 4096 : BK;
+    const char* wsrc[NI];
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+        const int row = wrow0 + j * 32 + frow;
+        int n = n0 + row;
+        n = n < p.N ? n : p.N - 1;
+        const __bf16* wp = p.w_packed ? p.w + ((long)(n >> 6) * (p.K >> 6)) * 4096 + ((n & 63) << 6) + (fslot << 3)
+                                      : p.w + (long)n * p.ldw + ((fslot ^ ((row >> 1) & 7)) << 3);
+        wsrc[j] = (const char*)(wp + (long)kt_begin * wkstep);
+    }
+    int wkbytes = wkstep * 2;
+    const char* lsrc = nullptr;
+    int ladv = 0;
+    const char* xsrc[2];
+    int xadv[2];
+    const char* zero_page = (const char*)slh_zero_page;
+    asm volatile("" : "+s"(zero_page));
+    int i_c0 = kt_begin * BK, i_tap = 0;
+    if (LORA) {
+        const int row = (wave & 3) * 8 + frow;       // waves 4-7 re-issue the rows of waves 0-3 (same bytes, same place: benign)
+        const bool ok = row < p.lora_rank;
+        lsrc = ok ? (const char*)(p.lora_down + (long)row * p.K + kt_begin * BK + ((fslot ^ ((row >> 1) & 7)) << 3)) : zero_page;
+        ladv = ok ? 128 : 0;
+    }
+    if (MODE == 1) { i_tap = i_c0 / cin; i_c0 -= i_tap * cin; }
+    bool i_first = true;
+    int x_left = nk, w_left = nk;
+    auto rebase_x = [&]() {
+        const bool s1 = i_c0 >= p.ca0;
+        const __bf16* base = s1 ? p.a1 : p.a0;
+        const int cc = s1 ? i_c0 - p.ca0 : i_c0;
+        if (MODE == 0) {
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                const int row = xrow0 + a * 64 + frow;
+                int m = m0 + row;
+                m = m < p.M ? m : p.M - 1;
+                xsrc[a] = (const char*)(base + (long)m * (s1 ? p.lda1 : p.lda0) + cc + ((fslot ^ ((row >> 1) & 7)) << 3));
+                xadv[a] = 128;
+            }
+        } else {
+            const int ld = s1 ? p.lda1 : p.lda0;
+            const int ky = i_tap / 3, kx = i_tap - ky * 3;
+            const int sh = p.src_xform ? 1 : 0;
+            const int HL = p.hs << sh, WL = p.ws << sh;
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                const int row = xrow0 + a * 64 + frow;
+                const int iy = xoy[a] * p.stride + ky - 1;
+                const int ix = xox[a] * p.stride + kx - 1;
+                bool ok = (iy >= 0) & (iy < HL) & (ix >= 0) & (ix < WL);
+                if (p.src_xform == 2) ok = ok & (((iy | ix) & 1) == 0);
+                const int sy = iy >> sh, sx = ix >> sh;
+                const long pix = ((long)xb[a] * p.hs + sy) * p.ws + sx;
+                xsrc[a] = ok ? (const char*)(base + pix * ld + cc + ((fslot ^ ((row >> 1) & 7)) << 3)) : zero_page;
+                xadv[a] = ok ? 128 : 0;
+            }
+        }
+    };
+    const unsigned lds0 = lds_addr_of(smem);
+    // unit u: 0 = UX, 1 + q = UW_q.  K tiles past the end of the slice come from the zero page (see the 256 x 256 kernel).
+    auto issue_unit = [&](const int u, const unsigned bo) {
+        if (u == 0) {
+            if (x_left <= 0) {
+                if (x_left == 0) {
+#pragma unroll
+                    for (int a = 0; a < 2; ++a) { xsrc[a] = zero_page; xadv[a] = 0; }
+                    if (LORA) { lsrc = zero_page; ladv = 0; }
+                }
+            } else if (i_first || i_c0 == 0 || i_c0 == p.ca0) {
+                rebase_x();
+            }
+            i_first = false;
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                glds16_hidden(xsrc[a], lds0 + bo + (xrow0 + a * 64) * 128);
+                xsrc[a] += xadv[a];
+            }
+            if (LORA) {
+                glds16_hidden(lsrc, lds0 + bo + XB + WB + (wave & 3) * 1024);
+                lsrc += ladv;
+            }
+            i_c0 += BK;
+            if (MODE == 1 && i_c0 == cin) { i_c0 = 0; ++i_tap; }
+            --x_left;
+        } else {
+            const int q = u - 1;
+            if (q == 0 && w_left == 0) {
+#pragma unroll
+                for (int j = 0; j < NI; ++j) wsrc[j] = zero_page;
+                wkbytes = 0;
+            }
+#pragma unroll
+            for (int j = BP * q; j < BP * q + BP && j < NI; ++j) {
+                glds16_hidden(wsrc[j], lds0 + bo + XB + (wrow0 + j * 32) * 128);
+                wsrc[j] += wkbytes;
+            }
+            if (q == NP - 1) --w_left;
+        }
+    };
+
+    float ln_mean[MI], ln_rstd[MI];
+    const bool ln_on = MODE == 0 && !LORA && p.ln_in != nullptr;
+    {
+        f32x2 ln_pairs[MI][LN_MAXC];
+        if (MODE == 0 && ln_on) {
+            gemm_ln_request<MI>(p, m0 + wm * 32, lrow, ln_pairs);
+            gemm_ln_finish<MI>(p, m0 + wm * 32, lrow, tile_n == 0 && wn == 0 && lhi == 0, ln_pairs, ln_mean, ln_rstd);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+    // ---- prologue: tile 0 complete + the phase-0 units of tile 1 in flight; the phase-0 units of tile 0 landed -----------------
+    issue_unit(0, 0);
+#pragma unroll
+    for (int q = 0; q < NP; ++q) issue_unit(1 + q, 0);
+    issue_unit(0, BUF);
+    issue_unit(1, BUF);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G) : "memory");
+
+    f32x16 acc[MI][NI];
+#pragma unroll
+    for (int j = 0; j < NI; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[0][j][r] = 0.f;
+    f32x16 accl[MI];
+    if (LORA) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) accl[0][r] = 0.f;
+    }
+
+    const char* xbase = smem + (wm * 32) * 128;
+    const char* wbase = smem + XB + (wn * 32 * NI) * 128;
+    bf16x8 xf[4], wf[BP][4], lf[2];
+    auto read_x = [&](const unsigned bo) {
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) xf[ks] = *(const bf16x8*)(xbase + bo + lds_off(lrow, ks * 2 + lhi));
+        if (LORA) {      // this wave's k-steps of the adapter tile: ks = wn and wn + 2
+#pragma unroll
+            for (int h = 0; h < 2; ++h) lf[h] = *(const bf16x8*)(smem + bo + XB + WB + lds_off(lrow, (wn + 2 * h) * 2 + lhi));
+        }
+    };
+    auto read_w = [&](const unsigned bo, const int q) {
+#pragma unroll
+        for (int jj = 0; jj < BP; ++jj)
+            if (BP * q + jj < NI) {
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) wf[jj][ks] = *(const bf16x8*)(wbase + bo + (BP * q + jj) * 4096 + lds_off(lrow, ks * 2 + lhi));
+            }
+    };
+    auto mfmas = [&](const int q) {
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int jj = 0; jj < BP; ++jj)
+                if (BP * q + jj < NI)
+                    acc[0][BP * q + jj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[jj][ks], xf[ks], acc[0][BP * q + jj], 0, 0, 0);
+        if (LORA && q == NP - 1) {
+            // xf[wn], xf[wn + 2] with a compile-time register index: both candidates are named, the scalar wn selects
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const bf16x8 xs = wn ? xf[2 * h + 1] : xf[2 * h];
+                accl[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lf[h], xs, accl[0], 0, 0, 0);
+            }
+        }
+        __builtin_amdgcn_s_setprio(0);
+    };
+
+    __builtin_amdgcn_s_barrier();
+    if (grp == 1) __builtin_amdgcn_s_barrier();   // group 1 runs one barrier behind group 0 from here on
+
+    unsigned bo = 0;
+    for (int s = 0; s < nk; ++s) {
+        const unsigned nb = bo ^ BUF;
+#pragma unroll
+        for (int q = 0; q < NP; ++q) {
+            // phase q: the unit needed NP + 1 phases from now = the unit of phase (q + 1) % NP, in tile s + 1 (its buffer nb) or,
+            // when q is the last phase, the phase-0 units of tile s + 2 (this buffer, whose X / block 0-1 rows phase 0 gave up)
+            if (q == 0) read_x(bo);
+            read_w(bo, q);
+            __builtin_amdgcn_sched_barrier(0);
+            if (q + 1 < NP) {
+                issue_unit(1 + q + 1, nb);
+            } else {
+                issue_unit(0, bo);
+                issue_unit(1, bo);
+            }
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G) : "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_s_waitcnt(0xC07F);   // lgkmcnt(0)
+            __builtin_amdgcn_sched_barrier(0);
+            mfmas(q);
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        bo = nb;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (grp == 0) __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_s_barrier();
+
+    gemm_epilogue<MI, NI, MODE, LORA, NW, WN>(p, smem, acc, accl, ln_mean, ln_rstd, ln_on, tile_m, tile_n, ks_id, wave, wm, wn);
+}
+
 }  // namespace
 
 namespace slh_gemm_detail {
 
-int launch_gemm8p(const GemmArgs& a, int mode, hipStream_t s) {
+int launch_gemm8p(const GemmArgs& a, int mode, int ni_b, hipStream_t s) {
     const int grid = a.tiles_m * a.tiles_n * (a.splitk > 1 ? a.splitk : 1);
-    if (mode == 0)
-        hipLaunchKernelGGL((gemm8p_kernel<0, false>), dim3(grid), dim3(512), 0, s, a);
-    else
-        hipLaunchKernelGGL((gemm8p_kernel<1, false>), dim3(grid), dim3(512), 0, s, a);
-    SLH_LAUNCH_CHECK("slh_gemm (256 x 256)");
+#define SLH_LAUNCH_B(NI_)                                                                                        \
+    if (a.lora_down) {                                                                                           \
+        if (mode == 0) hipLaunchKernelGGL((gemm8pb_kernel<NI_, 0, true>), dim3(grid), dim3(512), 0, s, a);       \
+        else hipLaunchKernelGGL((gemm8pb_kernel<NI_, 1, true>), dim3(grid), dim3(512), 0, s, a);                 \
+    } else if (mode == 0) hipLaunchKernelGGL((gemm8pb_kernel<NI_, 0, false>), dim3(grid), dim3(512), 0, s, a);   \
+    else hipLaunchKernelGGL((gemm8pb_kernel<NI_, 1, false>), dim3(grid), dim3(512), 0, s, a)
+    if (ni_b == 0) {
+        if (mode == 0) hipLaunchKernelGGL((gemm8p_kernel<0, false>), dim3(grid), dim3(512), 0, s, a);
+        else hipLaunchKernelGGL((gemm8p_kernel<1, false>), dim3(grid), dim3(512), 0, s, a);
+    } else if (ni_b == 3) { SLH_LAUNCH_B(3); }
+    else if (ni_b == 4) { SLH_LAUNCH_B(4); }
+    else { SLH_LAUNCH_B(5); }
+#undef SLH_LAUNCH_B
+    SLH_LAUNCH_CHECK("slh_gemm (ping-pong K loop)");
     return 0;
 }
 

@@ -261,7 +261,12 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, char* smem, f32
     // four values in one round trip, behind the patches of the store staging.  A row bias qualifies when the tile's rows belong
     // to one sample (rows_per_sample a multiple of the tile height); otherwise it stays a per-row load below.
     constexpr int S = 4 * NI;                  // 16-byte slots per staged row
-    constexpr int LOG2S = NI == 2 ? 3 : 2;
+    // swizzle of the store staging patch: physical 16-byte slot of (row, logical slot), and whether the row's 8-byte halves are swapped;
+    // XOR forms for power-of-two S (NI = 1, 2, 4), a rotation for the others (NI = 5: S = 20)
+    constexpr bool SPOW2 = (S & (S - 1)) == 0;
+    constexpr int LOG2S = S == 4 ? 2 : (S == 8 ? 3 : (S == 16 ? 4 : 0));
+    auto patch_slot = [](const int row, const int slot) { return SPOW2 ? (slot ^ (row & (S - 1))) : (slot + row) % S; };
+    auto patch_hb = [](const int row) { return SPOW2 ? ((row >> LOG2S) & 1) : ((row / S) & 1); };
     float* sCol = (float*)(smem + NW * (32 * S * 16) + (LORA ? NW * MI * 2048 : 0));     // [4][BN]
     const bool rb_tile = p.rowbias != nullptr && p.rows_per_sample % BM == 0;
     {
@@ -312,6 +317,50 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, char* smem, f32
                     __bf16* po = p.c + (long)m * p.ldc + (n >> 5) * 64 + (n & 31);
                     *(bf16x4*)po = dh;
                     *(bf16x4*)(po + 32) = dg;
+                }
+            }
+        }
+        return;
+    }
+    if (p.geglu == 3) {
+        // GEGLU, 32-row weight blocks [16 value rows | 16 gate rows] (slh_gemm_desc.geglu = 3; any NI): inside one 32 x 32
+        // accumulator block the quads q = 0, 1 are values and q = 2, 3 the gates of the same 16 output columns, in the same lane.
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            const int m = m0 + wm * (32 * MI) + i * 32 + lrow;
+            if (m >= p.M) continue;
+#pragma unroll
+            for (int j = 0; j < NI; ++j) {
+                const int nb = n0 + wn * (32 * NI) + j * 32;               // first weight row of the block
+                if (nb >= p.N) continue;                                    // N % 32 == 0: blocks are whole
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const int cl = nb - n0 + q * 8 + lhi * 4;               // tile column of the value quad (gate: + 16)
+                    float a[4], g[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { a[e] = acc[i][j][q * 4 + e]; g[e] = acc[i][j][(q + 2) * 4 + e]; }
+                    if (MODE == 0 && ln_on) {
+                        const f32x4 sa = *(const f32x4*)(sCol + 2 * BN + cl), sg = *(const f32x4*)(sCol + 2 * BN + cl + 16);
+                        const f32x4 ba = *(const f32x4*)(sCol + 3 * BN + cl), bg = *(const f32x4*)(sCol + 3 * BN + cl + 16);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            a[e] = ln_rstd[i] * (a[e] - ln_mean[i] * sa[e]) + ba[e];
+                            g[e] = ln_rstd[i] * (g[e] - ln_mean[i] * sg[e]) + bg[e];
+                        }
+                    }
+                    if (p.bias) {
+                        const f32x4 ba = *(const f32x4*)(sCol + cl), bg = *(const f32x4*)(sCol + cl + 16);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { a[e] += ba[e]; g[e] += bg[e]; }
+                    }
+                    bf16x4 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float av = round_bf16(a[e]), gv = round_bf16(g[e]);   // the reference rounds proj(x) to bf16 before chunk / gelu
+                        o[e] = (__bf16)(av * round_bf16(gelu_erf_f(gv)));
+                    }
+                    *(bf16x4*)(p.c + (long)m * p.ldc + (nb >> 1) + q * 8 + lhi * 4) = o;
                 }
             }
         }
@@ -456,7 +505,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, char* smem, f32
         }
         // a row bias whose tile spans samples stays a per-row load
         const __bf16* rb = (p.rowbias && !rb_tile && mok) ? p.rowbias + (long)(m / p.rows_per_sample) * p.ld_rowbias : nullptr;
-        const int hb = (lrow >> LOG2S) & 1;
+        const int hb = patch_hb(lrow);
         bf16x4 okeep[NI][4];          // vt_also_c: the rounded quads, for the row-major store behind the transposed one
         // the residual quads of the whole 32-row block are requested together (one round trip instead of one per quad)
         bf16x4 res4[NI][4];
@@ -549,7 +598,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, char* smem, f32
                 }
                 // logical 16-byte slot j*4+q, 8-byte half lhi of row lrow; slot ^ row and half ^ row-bit keep both
                 // the 8-byte writes and the 16-byte row reads off each other's banks
-                const int slot = (j * 4 + q) ^ (lrow & (S - 1));
+                const int slot = patch_slot(lrow, j * 4 + q);
                 *(bf16x4*)(sE + lrow * (S * 16) + slot * 16 + ((lhi ^ hb) << 3)) = o;
             }
         }
@@ -589,7 +638,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, char* smem, f32
             for (int j = 0; j < NI; ++j)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const int slot = (j * 4 + q) ^ (lrow & (S - 1));
+                    const int slot = patch_slot(lrow, j * 4 + q);
                     *(bf16x4*)(sE + lrow * (S * 16) + slot * 16 + ((lhi ^ hb) << 3)) = okeep[j][q];
                 }
             __builtin_amdgcn_wave_barrier();
@@ -598,8 +647,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, char* smem, f32
         for (int it = 0; it < S / 2; ++it) {
             const int idx = it * 64 + lane;
             const int row = idx / S, slot = idx % S;
-            bf16x8 t8 = *(const bf16x8*)(sE + row * (S * 16) + ((slot ^ (row & (S - 1))) << 4));
-            if ((row >> LOG2S) & 1) t8 = __builtin_shufflevector(t8, t8, 4, 5, 6, 7, 0, 1, 2, 3);
+            bf16x8 t8 = *(const bf16x8*)(sE + row * (S * 16) + (patch_slot(row, slot) << 4));
+            if (patch_hb(row)) t8 = __builtin_shufflevector(t8, t8, 4, 5, 6, 7, 0, 1, 2, 3);
             const int m2 = mbase + row, n2 = ncol0 + slot * 8;
             if (m2 < p.M && n2 < p.N) {
                 __bf16* dst = p.c + (long)m2 * p.ldc + n2;
@@ -620,6 +669,6 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, char* smem, f32
 }
 
 // gemm8p.hip: the 256 x 256 ping-pong K loop (slh_gemm_desc.tile code 0x8xxx)
-int launch_gemm8p(const GemmArgs& a, int mode, hipStream_t s);
+int launch_gemm8p(const GemmArgs& a, int mode, int ni_b, hipStream_t s);   // ni_b: 0 = 256 x 256, else 128 x 64*ni_b
 
 }  // namespace slh_gemm_detail

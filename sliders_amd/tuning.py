@@ -26,6 +26,34 @@ def gemm_key(d, with_lora: bool = False) -> str:
     return k
 
 
+def tile_ok(d, tile: int) -> bool:
+    """Can slh_gemm run descriptor d with this tile code?  (The constraints slh_gemm itself checks: used by the tuner to skip
+    candidates and by the planner to drop a table entry that no longer fits the launch it is looked up for.)"""
+    mi, ni, wm = (tile >> 4) & 15, tile & 15, (tile >> 12) & 15
+    if wm == 8 and (tile >> 16) & 15:             # split-K: the slabs of these tiles must fit the workspace contract
+        bm, bn = (256, 256) if mi == 4 else (128, 64 * ni)
+        r = lambda v, q: (v + q - 1) // q * q
+        if r(d.M, bm) * r(d.N, bn) > r(d.M, 256) * r(d.N, 128):
+            return False
+    if wm == 8:                                   # ping-pong K loops (csrc/gemm8p.hip)
+        if (mi, ni) == (4, 2):                    # 256 x 256: no fused adapter
+            return not d.lora_down and d.geglu in (0, 1, 2, 3)
+        if mi != 1 or ni < 3 or ni > 5:
+            return False
+        if d.geglu in (1, 2) or d.ln_out or d.vt_out:     # 32 | 32 GEGLU blocks, chunk statistics and the V^T store assume NI = 2
+            return False
+        return True
+    if not tile:
+        return True
+    if d.geglu in (1,) and ni != 2:
+        return False
+    if d.geglu == 3:
+        return True
+    if d.ln_out and ni != 2:
+        return False
+    return True
+
+
 def table() -> Dict[str, int]:
     global _TABLE
     if _TABLE is None:
@@ -47,6 +75,8 @@ def tuned_tile(d) -> int:
     t = tb.get(full, tb.get(base, tb.get(gemm_key(d), 0)))
     if not t and d.lora_down:      # adapter fused in but only the plain product was measured (backward-data GEMMs): same tile
         t = tb.get(base[:-1] + "0", 0)
+    if t and not tile_ok(d, t):
+        t = 0
     force = os.environ.get("SLIDERS_FORCE_STAGES")     # experiment knob: 2 or 3 for every non-128x128 tile
     if force and t and (t & 0xFF) != 0x22:
         t = (t & 0xFF) | (int(force) << 8 if force == "3" else 0)

@@ -39,6 +39,16 @@ def _geglu_perm(w: torch.Tensor) -> torch.Tensor:
     return torch.stack([a.reshape(n // 32, 32, *rest), g.reshape(n // 32, 32, *rest)], dim=1).reshape(n2, *rest).contiguous()
 
 
+def _geglu_perm16(w: torch.Tensor) -> torch.Tensor:
+    """Row order of slh_gemm_desc.geglu = 3: 32-row blocks [16 value rows | 16 gate rows] (the ping-pong tiles, whose waves own a
+    number of 32-column blocks that need not be even)."""
+    n2 = w.shape[0]
+    n = n2 // 2
+    a, g = w[:n], w[n:]
+    rest = w.shape[1:]
+    return torch.stack([a.reshape(n // 16, 16, *rest), g.reshape(n // 16, 16, *rest)], dim=1).reshape(n2, *rest).contiguous()
+
+
 def pack_gemm_w(w: torch.Tensor) -> torch.Tensor:
     """[N][K] (K % 64 == 0) -> flat tile-packed layout of slh_gemm_desc.w_layout = 1 (include/sliders_hip.h):
     block (n>>6, k>>6) is 64 rows x 8 slots x 8 elements, slot s of row r stored at physical slot s ^ ((r>>1)&7);

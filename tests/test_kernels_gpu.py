@@ -41,7 +41,7 @@ def _pack_conv(w):
 
 
 @pytest.mark.parametrize("tile", [0x22, 0x21, 0x12, 0x11, 0x321, 0x312, 0x311, 0x4022, 0x4322, 0x4012, 0x4312, 0x4011,
-                                  0x322, 0x422, 0x421, 0x412, 0x411, 0x4422, 0x4412, 0x4411, 0x8042])
+                                  0x322, 0x422, 0x421, 0x412, 0x411, 0x4422, 0x4412, 0x4411, 0x8042, 0x8013, 0x8014, 0x8015])
 @pytest.mark.parametrize("M,N,K", [(256, 128, 64), (300, 320, 320), (1024, 640, 1280), (154, 256, 2048)])
 def test_gemm_dense(dev, M, N, K, tile):
     torch.manual_seed(M + N + K)
@@ -58,7 +58,7 @@ def test_gemm_dense(dev, M, N, K, tile):
     report(f"gemm_dense M{M} N{N} K{K} tile{tile:x}", c, ref, TOL)
 
 
-@pytest.mark.parametrize("tile", [0x22, 0x21, 0x12, 0x11, 0x311, 0x4022, 0x4012, 0x4011, 0x4312, 0x422, 0x412, 0x4412, 0x4322, 0x8042])
+@pytest.mark.parametrize("tile", [0x22, 0x21, 0x12, 0x11, 0x311, 0x4022, 0x4012, 0x4011, 0x4312, 0x422, 0x412, 0x4412, 0x4322, 0x8042, 0x8013, 0x8014, 0x8015])
 def test_gemm_packed_weights(dev, tile):
     """w_layout = 1: the frozen weights in the tile-packed, pre-swizzled order (sliders_amd.weights.pack_gemm_w)."""
     from sliders_amd.weights import pack_gemm_w
@@ -92,7 +92,7 @@ def test_gemm_packed_weights(dev, tile):
     report(f"conv_packed tile{tile:x}", c, _to_pix(ref_img), TOL)
 
 
-@pytest.mark.parametrize("tile", [0, 0x422, 0x4412, 0x4322, 0x312, 0x8042])
+@pytest.mark.parametrize("tile", [0, 0x422, 0x4412, 0x4322, 0x312, 0x8042, 0x8014, 0x8015])
 def test_gemm_two_source_rowbias_lora(dev, tile):
     torch.manual_seed(1)
     B, HW, C0, C1, N = 2, 160, 128, 64, 320
@@ -238,6 +238,44 @@ def test_gemm_geglu(dev):
     report("geglu_bwd", dpre, _perm_cols(pr.grad), 1.5e-2)
 
 
+@pytest.mark.parametrize("tile", [0x8015, 0x8014, 0x8013, 0x8042, 0x4412, 0x22])
+def test_gemm_geglu_16_blocks(dev, tile):
+    """slh_gemm_desc.geglu = 3: GEGLU with the weight rows in 32-row blocks [16 value | 16 gate] (weights._geglu_perm16) - the
+    pairing lives inside one 32 x 32 accumulator block, so tiles whose waves own an odd number of blocks can take it.  With the
+    LayerNorm fold on the consumer side (ff.net.0.proj as the pass runs it) and without."""
+    from sliders_amd.weights import _geglu_perm16, fold_layernorm
+    torch.manual_seed(23)
+    M, K, n_out = 300, 320, 448              # N = 896: 2.8 tiles of 320 columns, 3.5 of 256
+    N = 2 * n_out
+    x = bf(torch.randn(M, K, device=dev))
+    w = bf(torch.randn(N, K, device=dev) / math.sqrt(K))
+    b = bf(torch.randn(N, device=dev))
+    proj = bf(x.float() @ w.float().t() + b.float()).float()
+    ref = proj[:, :n_out] * bf(F.gelu(proj[:, n_out:])).float()
+    c = torch.zeros(M, n_out, device=dev, dtype=torch.bfloat16)
+    d = lib.GemmDesc(a0=p(x), w=p(_geglu_perm16(w)), bias=p(_geglu_perm16(b)), c=p(c), lda0=K, ca0=K, mode=0, stride=1, ldw=K, M=M, N=N,
+                     K=K, ldc=n_out, geglu=3, rows_per_sample=M, tile=tile)
+    lib.call(lib.OP_GEMM, d, stream())
+    torch.cuda.synchronize()
+    report(f"gemm_geglu16 tile{tile:x}", c, ref, TOL)
+    # folded LayerNorm in front (statistics from slh_layernorm's chunk form are produced by a plain product here)
+    gamma, beta = bf(torch.randn(K, device=dev) * 0.5 + 1.0), bf(torch.randn(K, device=dev) * 0.3)
+    hc = x.float().view(M, K // 64, 64).double()
+    mean_c = hc.mean(-1)
+    chunks = torch.stack([mean_c, ((hc - mean_c[..., None]) ** 2).sum(-1)], -1).permute(1, 0, 2).contiguous().float()   # [chunk][M][2]
+    ln = bf(F.layer_norm(x.float(), (K,), gamma.float(), beta.float(), 1e-5))
+    wf, sv, bp = fold_layernorm(w, b, gamma, beta)
+    wf, sv, bp = _geglu_perm16(wf), _geglu_perm16(sv).contiguous(), _geglu_perm16(bp).contiguous()
+    proj = bf(ln.float() @ w.float().t() + b.float()).float()
+    refg = proj[:, :n_out] * bf(F.gelu(proj[:, n_out:])).float()
+    c.zero_()
+    d = lib.GemmDesc(a0=p(x), w=p(wf), c=p(c), lda0=K, ca0=K, mode=0, stride=1, ldw=K, M=M, N=N, K=K, ldc=n_out, geglu=3,
+                     rows_per_sample=M, tile=tile, ln_in=p(chunks), ln_in_chunks=K // 64, ln_s=p(sv), ln_b=p(bp), ln_eps=1e-5)
+    lib.call(lib.OP_GEMM, d, stream())
+    torch.cuda.synchronize()
+    report(f"gemm_geglu16 + ln fold tile{tile:x}", c, refg, TOL)
+
+
 @pytest.mark.parametrize("tile", [0, 0x4412, 0x22, 0x11, 0x4322, 0x24412, 0x8042])
 def test_gemm_geglu_backward_form(dev, tile):
     """slh_gemm_desc.geglu = 2: the backward-data product of the Linear behind a GEGLU writes d(proj) itself - bit-identical to
@@ -311,7 +349,7 @@ def test_gemm_layernorm_folded(dev, C, offset):
         w = bf(torch.randn(N, C, device=dev) / math.sqrt(C))
         wf, sv, bp = fold_layernorm(w, None, gamma, beta)
         ref = ln.float() @ w.float().t()
-        for tile in (0x4412, 0x22, 0x11, 0x4322, 0x8042):
+        for tile in (0x4412, 0x22, 0x11, 0x4322, 0x8042, 0x8014, 0x8015):
             c = torch.zeros(M, N, device=dev, dtype=torch.bfloat16)
             mr = torch.full((M, 2), float("nan"), device=dev)
             d = lib.GemmDesc(a0=p(h), w=p(wf), c=p(c), lda0=C, ca0=C, mode=0, stride=1, ldw=C, M=M, N=N, K=C, ldc=N,
@@ -382,7 +420,7 @@ def _perm_cols(g):
 
 
 @pytest.mark.parametrize("stride,xform", [(1, 0), (2, 0), (1, 1), (1, 2)])
-@pytest.mark.parametrize("tile", [0x22, 0x11, 0x312, 0x311, 0x4022, 0x4312, 0x4011, 0x422, 0x411, 0x4412, 0x4322, 0x8042])
+@pytest.mark.parametrize("tile", [0x22, 0x11, 0x312, 0x311, 0x4022, 0x4312, 0x4011, 0x422, 0x411, 0x4412, 0x4322, 0x8042, 0x8013, 0x8014, 0x8015])
 def test_gemm_conv3x3(dev, stride, xform, tile):
     torch.manual_seed(3 + stride + xform)
     B, H, W, Ci, Co = 2, 12, 20, 128, 192
@@ -403,7 +441,7 @@ def test_gemm_conv3x3(dev, stride, xform, tile):
     report(f"gemm_conv s{stride} x{xform} tile{tile:x}", c, _to_pix(ref_img), TOL)
 
 
-@pytest.mark.parametrize("tile", [0, 0x422, 0x4412, 0x4322, 0x8042])
+@pytest.mark.parametrize("tile", [0, 0x422, 0x4412, 0x4322, 0x8042, 0x8015])
 def test_gemm_conv_two_source_and_skinny(dev, tile):
     torch.manual_seed(5)
     B, H, W, C0, C1, Co = 2, 16, 16, 128, 64, 128
@@ -897,7 +935,7 @@ def test_batched_wgrad_transposes_and_gather(dev):
     assert torch.equal(out, ref)
 
 
-@pytest.mark.parametrize("tile", [0x4412, 0x422, 0x22, 0x11, 0x4322])
+@pytest.mark.parametrize("tile", [0x4412, 0x422, 0x22, 0x11, 0x4322, 0x8015, 0x8014, 0x8013])
 def test_gemm_fused_lora_backward_data_form(dev, tile):
     """Backward-data product of an adapted Linear with the adapter fused in (slh_gemm_desc.lora_down + lora_up_rmajor):
     dX = dY . W + s * (dY . B) . A, the rank-4..12 intermediate U = dY . B computed from the k-major copy of the up matrices
@@ -941,7 +979,7 @@ def test_gemm_fused_lora_backward_data_form(dev, tile):
             assert int(tickets.abs().sum()) == 0
 
 
-@pytest.mark.parametrize("tile", [0x22, 0x21, 0x12, 0x11, 0x311, 0x4022, 0x4322, 0x4012, 0x4011, 0x422, 0x421, 0x4412, 0x4411])
+@pytest.mark.parametrize("tile", [0x22, 0x21, 0x12, 0x11, 0x311, 0x4022, 0x4322, 0x4012, 0x4011, 0x422, 0x421, 0x4412, 0x4411, 0x8015, 0x8014, 0x8013])
 def test_gemm_fused_lora_down(dev, tile):
     """LoRAModule.forward fused into one launch: y = x W^T + b + s (x A^T) B^T, T = x A^T written for backward."""
     torch.manual_seed(31)
@@ -990,7 +1028,7 @@ def test_gemm_fused_lora_down(dev, tile):
     report(f"conv_fused_lora T tile{tile:x}", Tout, _to_pix(t_img), 1e-5)
 
 
-@pytest.mark.parametrize("tile", [0x20412, 0x40421, 0x80422, 0x44412, 0x30011, 0x20022, 0xf0412])
+@pytest.mark.parametrize("tile", [0x20412, 0x40421, 0x80422, 0x44412, 0x30011, 0x20022, 0xf0412, 0x28015, 0x38014])
 def test_gemm_splitk(dev, tile):
     """Split-K (slh_gemm_desc.tile bits 16-19): every K slice publishes its partial tile in its own fp32 slab (whatever the
     workspace held), the slice of a tile that arrives last adds the slabs in slice order and runs the ordinary epilogue -
@@ -1056,6 +1094,12 @@ def test_gemm_splitk(dev, tile):
     d = lib.GemmDesc(a0=p(x0), a1=p(x1), w=p(_pack_conv(w4)), c=p(cc), lda0=C0, lda1=C1, ca0=C0, ca1=C1, mode=1, batch=B, hs=H,
                      ws=W, stride=1, ho=H, wo=W, ldw=9 * (C0 + C1), M=Mc, N=Co, K=9 * (C0 + C1), ldc=Co, rows_per_sample=H * W,
                      tile=tile, splitk_c32=p(wsc), splitk_slabs=S, splitk_ticket=p(tickets))
+    if (tile >> 12) & 15 == 8:
+        # a 128 x 256 / 128 x 320 tile over N = 128 would need slabs beyond the workspace contract (roundup(M, 256) x roundup(N, 128)
+        # floats per slice): refused, not overrun
+        with pytest.raises(lib.SlidersHipError, match="workspace contract"):
+            lib.call(lib.OP_GEMM, d, stream())
+        return
     lib.call(lib.OP_GEMM, d, stream())
     torch.cuda.synchronize()
     report(f"splitk conv 2src tile{tile:x}", cc, ref, TOL)
