@@ -1094,9 +1094,9 @@ def test_gemm_splitk(dev, tile):
     d = lib.GemmDesc(a0=p(x0), a1=p(x1), w=p(_pack_conv(w4)), c=p(cc), lda0=C0, lda1=C1, ca0=C0, ca1=C1, mode=1, batch=B, hs=H,
                      ws=W, stride=1, ho=H, wo=W, ldw=9 * (C0 + C1), M=Mc, N=Co, K=9 * (C0 + C1), ldc=Co, rows_per_sample=H * W,
                      tile=tile, splitk_c32=p(wsc), splitk_slabs=S, splitk_ticket=p(tickets))
-    if (tile >> 12) & 15 == 8:
-        # a 128 x 256 / 128 x 320 tile over N = 128 would need slabs beyond the workspace contract (roundup(M, 256) x roundup(N, 128)
-        # floats per slice): refused, not overrun
+    if (tile >> 12) & 15 == 8 and 128 * 64 * (tile & 15) > 256 * 128:
+        # a 128 x 320 tile over M = N = 128 would need slabs beyond the workspace contract (roundup(M, 256) x roundup(N, 128) floats
+        # per slice): refused, not overrun
         with pytest.raises(lib.SlidersHipError, match="workspace contract"):
             lib.call(lib.OP_GEMM, d, stream())
         return
