@@ -522,7 +522,7 @@ static void pick_tile(const slh_gemm_desc* d, int& MI, int& NI, int& WM) {
         MI = (d->tile >> 4) & 15; NI = d->tile & 15;
         const int wcode = (d->tile >> 12) & 15;
         WM = wcode == 4 ? 4 : 2;
-        if (wcode == 8) WM = 8;      // ping-pong K loops (gemm8p.hip): MI = 4, NI = 2 -> 256 x 256; MI = 1, NI = 3..5 -> 128 x 64*NI
+        if (wcode == 8) WM = 8;      // ping-pong K loops (gemm8p.hip): MI = 4, NI = 2 -> 256 x 256; MI = 1, NI = 3..5 -> 128 x 64*NI; MI = 2, NI = 5 -> 256 x 320
         if (MI) return;
         MI = 2; NI = 2; WM = 2;
     }
@@ -626,8 +626,12 @@ extern "C" int slh_gemm(const slh_gemm_desc* d, slh_stream_t stream) {
     int MI = 2, NI = 2, WM = 2;
     pick_tile(d, MI, NI, WM);
     if (WM == 8) {
-        SLH_CHECK((MI == 4 && NI == 2) || (MI == 1 && NI >= 3 && NI <= 5), "slh_gemm: ping-pong tiles are 256 x 256 (0x8042) or 128 x 64*NI (0x801<NI>, NI = 3..5)");
-        SLH_CHECK(!d->lora_down || MI == 1, "slh_gemm: the 256 x 256 tile does not take a fused adapter (lora_down)");
+        SLH_CHECK((MI == 4 && NI == 2) || (MI == 1 && NI >= 3 && NI <= 5) || (MI == 2 && NI == 5),
+                  "slh_gemm: ping-pong tiles are 256 x 256 (0x8042), 128 x 64*NI (0x801<NI>, NI = 3..5) or 256 x 320 (0x8025)");
+        SLH_CHECK(!d->lora_down || MI == 1, "slh_gemm: the 256-row ping-pong tiles do not take a fused adapter (lora_down)");
+        if (MI == 2)
+            SLH_CHECK(d->mode == 0 && d->M % 256 == 0 && d->w_layout == 1,
+                      "slh_gemm: the 256 x 320 tile (0x8025) runs dense products with M %% 256 == 0 and tile-packed weights");
     } else {
         SLH_CHECK((MI == 1 || MI == 2) && (NI == 1 || NI == 2), "slh_gemm: bad tile");
         SLH_CHECK(WM == 2 || NI == 2 || MI == 1, "slh_gemm: 8-wave tiles are 128x64, 128x128 or 256x128");
@@ -714,7 +718,7 @@ extern "C" int slh_gemm(const slh_gemm_desc* d, slh_stream_t stream) {
     }
     a.store16 = (d->ldc % 8 == 0) && (((uintptr_t)d->c & 15) == 0);
     if (WM == 8) {
-        const int bm = MI == 4 ? 256 : 128, bn = 64 * NI * (MI == 4 ? 2 : 1);
+        const int bm = MI == 1 ? 128 : 256, bn = 64 * NI * (MI == 4 ? 2 : 1);
         a.tiles_m = (d->M + bm - 1) / bm;
         a.tiles_n = (d->N + bn - 1) / bn;
         // the slab workspace is sized by contract (include/sliders_hip.h: roundup(M, 256) x roundup(N, 128) floats per slice)
@@ -722,7 +726,7 @@ extern "C" int slh_gemm(const slh_gemm_desc* d, slh_stream_t stream) {
             SLH_CHECK((long)a.tiles_m * bm * a.tiles_n * bn <= ((d->M + 255) / 256 * 256L) * ((d->N + 127) / 128 * 128L),
                       "slh_gemm: split-K slabs of %d x %d tiles exceed the workspace contract for M=%d N=%d", bm, bn, d->M, d->N);
         a.group_m = pick_group_m(d, a.tiles_m);
-        return launch_gemm8p(a, d->mode, MI == 4 ? 0 : NI, (hipStream_t)stream);
+        return launch_gemm8p(a, d->mode, MI == 4 ? 0 : (MI == 2 ? 20 + NI : NI), (hipStream_t)stream);
     }
     a.tiles_m = (d->M + 32 * MI * WM - 1) / (32 * MI * WM);
     a.tiles_n = (d->N + 64 * NI - 1) / (64 * NI);

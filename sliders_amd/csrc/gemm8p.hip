@@ -193,13 +193,13 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const GemmArgs p) {
     auto unit_end = [&](const int u) {
         if (u == 4) {
 #pragma unroll
-            for (int a = 0; a < 4; ++a) xsrc[a] += xadv[a];
+            for (int a = 0; a < 4; ++a) xsrc[a] += (SLH8P_ABL & 32) ? 0 : xadv[a];     // ABL 32: every K tile re-reads the first one (L2-hit rate of the DMA path)
             i_c0 += BK;
             if (MODE == 1 && i_c0 == cin) { i_c0 = 0; ++i_tap; }
             --x_left;
         } else if (u == 3) {
 #pragma unroll
-            for (int a = 0; a < 4; ++a) wsrc[a] += wkbytes;
+            for (int a = 0; a < 4; ++a) wsrc[a] += (SLH8P_ABL & 32) ? 0 : wkbytes;
             --w_left;
         }
     };
@@ -368,22 +368,30 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const GemmArgs p) {
 // = 1 piece per wave and block).  A unit needed in phase f is issued NP + 1 phases ahead (into the rows its buffer's previous
 // tile gave up NP + 1 - 2*NP + ... >= 2 phases earlier) and waited for in phase f - 1 with vmcnt(G), G = NI + 2 = the pieces of
 // one K tile per wave: exactly one K tile of LDS-DMA stays in flight across every barrier.
-template <int NI, int MODE, bool LORA>
+template <int MI, int NI, int MODE, bool LORA>
 __global__ __launch_bounds__(512, 2) void gemm8pb_kernel(const GemmArgs p) {
-    constexpr int MI = 1, NW = 8, WN = 2;
-    constexpr int BM = 128, BN = 64 * NI;
+    constexpr int NW = 8, WN = 2;
+    constexpr int BM = 128 * MI, BN = 64 * NI;
+    constexpr int XG = 2 * MI;                        // 8-row X groups per wave
     constexpr int XB = BM * 128, WB = BN * 128, LB = LORA ? 32 * 128 : 0, BUF = XB + WB + LB;
-    constexpr int BP = NI >= 5 ? 2 : 1;              // column blocks per phase
+    constexpr int BP = (NI >= 5 && MI == 1) ? 2 : 1;  // column blocks per phase (MI = 2: one block = 8 MFMAs, and 16 fragment registers less)
     constexpr int NP = (NI + BP - 1) / BP;           // phases per K tile; re-staging a region NP + 1 phases ahead of its next read
                                                      // leaves NP - 1 >= 2 phases behind its last one (see the 256 x 256 kernel)
-    constexpr int G = NI + 2 + (LORA ? 1 : 0);       // LDS-DMA pieces per wave and K tile
+    constexpr int G = NI + XG + (LORA ? 1 : 0);      // LDS-DMA pieces per wave and K tile
     // LORA: the rank-r down matrix (lora_down [r][K], r <= 12, zero-padded to 32 rows) rides along as a third operand tile, as in
     // gemm.hip: its piece travels with the X unit, the two waves that share 32 rows split its k-steps (wn = 0 the even ones), their
     // MFMAs go into the last - shortest - phase, and the shared epilogue's exchange (wave ^ 1) joins the halves.
-    static_assert(NI >= 3 && NI <= 5 && NP >= 3, "128 x 192 ... 128 x 320");
+    static_assert(NI >= 3 && NI <= 5 && NP >= 3 && (MI == 1 || (MI == 2 && !LORA)), "128 x 192 ... 128 x 320, 256 x 320 without the adapter");
     static_assert(gemm_epilogue_lds(MI, NI, NW, WN, LORA) <= 2 * BUF, "epilogue staging must fit the operand buffers");
-    static_assert(2 * BUF <= 160 * 1024, "LDS");
-    __shared__ __attribute__((aligned(16))) char smem[2 * BUF];
+    // LEAN (the 256-row tile, whose 160 accumulator registers leave ~90 for everything else): ONE running pointer per operand
+    // + wave-uniform byte offsets to the wave's other 8-row groups instead of one 64-bit pointer per group (needs M % 256 == 0:
+    // no row clamp, dense single- or two-source A, tile-packed W whose 64-row blocks are zero-padded), and the folded LayerNorm's
+    // per-row (mean, rstd) wait in the 2 KB of LDS behind the operand buffers instead of in registers.
+    constexpr bool LEAN = MI == 2;
+    static_assert(!LEAN || MODE == 0, "the 256-row tile: dense products only");
+    constexpr int LNB = LEAN ? BM * 8 : 0;
+    static_assert(2 * BUF + LNB <= 160 * 1024, "LDS");
+    __shared__ __attribute__((aligned(16))) char smem[2 * BUF + LNB];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -404,16 +412,16 @@ __global__ __launch_bounds__(512, 2) void gemm8pb_kernel(const GemmArgs p) {
     }
 
     // ---- staging geometry ---------------------------------------------------------------------------------------------------------
-    // X: 16 groups of 8 rows, wave w copies groups w and w + 8 (rows w*8, 64 + w*8).
+    // X: 16*MI groups of 8 rows, wave w copies groups w + 8a (rows w*8 + 64a).
     // W block j (both wave columns: 64 rows = 8 groups): wave w copies group w = (wn' = w >> 2, r8 = w & 3): row wn'*32*NI + j*32 + r8*8
     const int frow = lane >> 3, fslot = lane & 7;
     const int cin = p.ca0 + p.ca1;
     const int xrow0 = wave * 8;                                      // + {0, 64}
     const int wrow0 = (wave >> 2) * (32 * NI) + (wave & 3) * 8;      // + j*32
-    int xb[2], xoy[2], xox[2];
+    int xb[XG], xoy[XG], xox[XG];
     if (MODE == 1) {
 #pragma unroll
-        for (int a = 0; a < 2; ++a) {
+        for (int a = 0; a < XG; ++a) {
             int m = m0 + xrow0 + a * 64 + frow;
             m = m < p.M ? m : p.M - 1;
             const int hw = p.ho * p.wo;
@@ -424,21 +432,40 @@ __global__ __launch_bounds__(512, 2) void gemm8pb_kernel(const GemmArgs p) {
         }
     }
     const int wkstep = p.w_packed ? 4096 : BK;
-    const char* wsrc[NI];
+    const char* wsrc[LEAN ? 1 : NI];
+    int woff[LEAN ? NI : 1];        // LEAN: byte offset of block j's 8-row group from block 0's (wave-uniform)
+    if (LEAN) {
+        // tile-packed W: row n lives in block n >> 6 at (n & 63) * 128 B; the wave's group of block j starts at row
+        // nb_j = n0 + wrow0 + j*32 (a multiple of 8, so the group never straddles a 64-row block); whole blocks past
+        // ceil64(N) do not exist: their groups re-read block 0's (the columns are never stored)
+        const int nb0 = n0 + wrow0;
+        const int nlim = (p.N + 63) & ~63;
+        const int n0c = nb0 < nlim ? nb0 : 0;
+        const long base0 = ((long)(n0c >> 6) * (p.K >> 6)) * 8192 + (n0c & 63) * 128;
+        wsrc[0] = (const char*)p.w + base0 + frow * 128 + fslot * 16 + (long)kt_begin * 8192;
 #pragma unroll
-    for (int j = 0; j < NI; ++j) {
-        const int row = wrow0 + j * 32 + frow;
-        int n = n0 + row;
-        n = n < p.N ? n : p.N - 1;
-        const __bf16* wp = p.w_packed ? p.w + ((long)(n >> 6) * (p.K >> 6)) * 4096 + ((n & 63) << 6) + (fslot << 3)
-                                      : p.w + (long)n * p.ldw + ((fslot ^ ((row >> 1) & 7)) << 3);
-        wsrc[j] = (const char*)(wp + (long)kt_begin * wkstep);
+        for (int j = 0; j < NI; ++j) {
+            const int nb = nb0 + j * 32;
+            const int nc = nb < nlim ? nb : n0c;
+            woff[j] = (int)(((long)(nc >> 6) * (p.K >> 6)) * 8192 + (nc & 63) * 128 - base0);
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            const int row = wrow0 + j * 32 + frow;
+            int n = n0 + row;
+            n = n < p.N ? n : p.N - 1;
+            const __bf16* wp = p.w_packed ? p.w + ((long)(n >> 6) * (p.K >> 6)) * 4096 + ((n & 63) << 6) + (fslot << 3)
+                                          : p.w + (long)n * p.ldw + ((fslot ^ ((row >> 1) & 7)) << 3);
+            wsrc[j] = (const char*)(wp + (long)kt_begin * wkstep);
+        }
     }
     int wkbytes = wkstep * 2;
     const char* lsrc = nullptr;
     int ladv = 0;
-    const char* xsrc[2];
-    int xadv[2];
+    const char* xsrc[LEAN ? 1 : XG];
+    int xadv[LEAN ? 1 : XG];
+    long xgoff = 0;                 // LEAN: bytes between the wave's consecutive X groups (64 rows), wave-uniform
     const char* zero_page = (const char*)slh_zero_page;
     asm volatile("" : "+s"(zero_page));
     int i_c0 = kt_begin * BK, i_tap = 0;
@@ -455,9 +482,15 @@ __global__ __launch_bounds__(512, 2) void gemm8pb_kernel(const GemmArgs p) {
         const bool s1 = i_c0 >= p.ca0;
         const __bf16* base = s1 ? p.a1 : p.a0;
         const int cc = s1 ? i_c0 - p.ca0 : i_c0;
-        if (MODE == 0) {
+        if (LEAN) {
+            const int row = xrow0 + frow;            // rows of the groups a > 0: + 64 a (same swizzle: 64 is a multiple of 16)
+            const int ld = s1 ? p.lda1 : p.lda0;
+            xsrc[0] = (const char*)(base + (long)(m0 + row) * ld + cc + ((fslot ^ ((row >> 1) & 7)) << 3));
+            xadv[0] = 128;
+            xgoff = 128L * ld;
+        } else if (MODE == 0) {
 #pragma unroll
-            for (int a = 0; a < 2; ++a) {
+            for (int a = 0; a < XG; ++a) {
                 const int row = xrow0 + a * 64 + frow;
                 int m = m0 + row;
                 m = m < p.M ? m : p.M - 1;
@@ -470,7 +503,7 @@ __global__ __launch_bounds__(512, 2) void gemm8pb_kernel(const GemmArgs p) {
             const int sh = p.src_xform ? 1 : 0;
             const int HL = p.hs << sh, WL = p.ws << sh;
 #pragma unroll
-            for (int a = 0; a < 2; ++a) {
+            for (int a = 0; a < XG; ++a) {
                 const int row = xrow0 + a * 64 + frow;
                 const int iy = xoy[a] * p.stride + ky - 1;
                 const int ix = xox[a] * p.stride + kx - 1;
@@ -490,17 +523,24 @@ __global__ __launch_bounds__(512, 2) void gemm8pb_kernel(const GemmArgs p) {
             if (x_left <= 0) {
                 if (x_left == 0) {
 #pragma unroll
-                    for (int a = 0; a < 2; ++a) { xsrc[a] = zero_page; xadv[a] = 0; }
+                    for (int a = 0; a < (LEAN ? 1 : XG); ++a) { xsrc[a] = zero_page; xadv[a] = 0; }
+                    xgoff = 0;
                     if (LORA) { lsrc = zero_page; ladv = 0; }
                 }
             } else if (i_first || i_c0 == 0 || i_c0 == p.ca0) {
                 rebase_x();
             }
             i_first = false;
+            if (LEAN) {
 #pragma unroll
-            for (int a = 0; a < 2; ++a) {
-                glds16_hidden(xsrc[a], lds0 + bo + (xrow0 + a * 64) * 128);
-                xsrc[a] += xadv[a];
+                for (int a = 0; a < XG; ++a) glds16_hidden(xsrc[0] + a * xgoff, lds0 + bo + (xrow0 + a * 64) * 128);
+                xsrc[0] += xadv[0];
+            } else {
+#pragma unroll
+                for (int a = 0; a < XG; ++a) {
+                    glds16_hidden(xsrc[a], lds0 + bo + (xrow0 + a * 64) * 128);
+                    xsrc[a] += xadv[a];
+                }
             }
             if (LORA) {
                 glds16_hidden(lsrc, lds0 + bo + XB + WB + (wave & 3) * 1024);
@@ -513,15 +553,26 @@ __global__ __launch_bounds__(512, 2) void gemm8pb_kernel(const GemmArgs p) {
             const int q = u - 1;
             if (q == 0 && w_left == 0) {
 #pragma unroll
-                for (int j = 0; j < NI; ++j) wsrc[j] = zero_page;
+                for (int j = 0; j < (LEAN ? 1 : NI); ++j) wsrc[j] = zero_page;
+                if (LEAN) {
+#pragma unroll
+                    for (int j = 0; j < NI; ++j) woff[j] = 0;
+                }
                 wkbytes = 0;
             }
 #pragma unroll
             for (int j = BP * q; j < BP * q + BP && j < NI; ++j) {
-                glds16_hidden(wsrc[j], lds0 + bo + XB + (wrow0 + j * 32) * 128);
-                wsrc[j] += wkbytes;
+                if (LEAN) {
+                    glds16_hidden(wsrc[0] + woff[j], lds0 + bo + XB + (wrow0 + j * 32) * 128);
+                } else {
+                    glds16_hidden(wsrc[j], lds0 + bo + XB + (wrow0 + j * 32) * 128);
+                    wsrc[j] += wkbytes;
+                }
             }
-            if (q == NP - 1) --w_left;
+            if (q == NP - 1) {
+                if (LEAN) wsrc[0] += wkbytes;
+                --w_left;
+            }
         }
     };
 
@@ -530,8 +581,13 @@ __global__ __launch_bounds__(512, 2) void gemm8pb_kernel(const GemmArgs p) {
     {
         f32x2 ln_pairs[MI][LN_MAXC];
         if (MODE == 0 && ln_on) {
-            gemm_ln_request<MI>(p, m0 + wm * 32, lrow, ln_pairs);
-            gemm_ln_finish<MI>(p, m0 + wm * 32, lrow, tile_n == 0 && wn == 0 && lhi == 0, ln_pairs, ln_mean, ln_rstd);
+            gemm_ln_request<MI>(p, m0 + wm * (32 * MI), lrow, ln_pairs);
+            gemm_ln_finish<MI>(p, m0 + wm * (32 * MI), lrow, tile_n == 0 && wn == 0 && lhi == 0, ln_pairs, ln_mean, ln_rstd);
+            if (LEAN) {          // parked in LDS over the K loop (every lane that holds row (i, lrow) writes the same pair)
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+                    *(f32x2*)(smem + 2 * BUF + (wm * (32 * MI) + i * 32 + lrow) * 8) = f32x2{ln_mean[i], ln_rstd[i]};
+            }
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -546,21 +602,25 @@ __global__ __launch_bounds__(512, 2) void gemm8pb_kernel(const GemmArgs p) {
 
     f32x16 acc[MI][NI];
 #pragma unroll
-    for (int j = 0; j < NI; ++j)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[0][j][r] = 0.f;
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     f32x16 accl[MI];
     if (LORA) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) accl[0][r] = 0.f;
     }
 
-    const char* xbase = smem + (wm * 32) * 128;
+    const char* xbase = smem + (wm * 32 * MI) * 128;
     const char* wbase = smem + XB + (wn * 32 * NI) * 128;
-    bf16x8 xf[4], wf[BP][4], lf[2];
+    bf16x8 xf[MI][4], wf[BP][4], lf[2];
     auto read_x = [&](const unsigned bo) {
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) xf[ks] = *(const bf16x8*)(xbase + bo + lds_off(lrow, ks * 2 + lhi));
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) xf[i][ks] = *(const bf16x8*)(xbase + bo + i * 4096 + lds_off(lrow, ks * 2 + lhi));
         if (LORA) {      // this wave's k-steps of the adapter tile: ks = wn and wn + 2
 #pragma unroll
             for (int h = 0; h < 2; ++h) lf[h] = *(const bf16x8*)(smem + bo + XB + WB + lds_off(lrow, (wn + 2 * h) * 2 + lhi));
@@ -580,13 +640,16 @@ __global__ __launch_bounds__(512, 2) void gemm8pb_kernel(const GemmArgs p) {
         for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
             for (int jj = 0; jj < BP; ++jj)
-                if (BP * q + jj < NI)
-                    acc[0][BP * q + jj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[jj][ks], xf[ks], acc[0][BP * q + jj], 0, 0, 0);
+                if (BP * q + jj < NI) {
+#pragma unroll
+                    for (int i = 0; i < MI; ++i)
+                        acc[i][BP * q + jj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[jj][ks], xf[i][ks], acc[i][BP * q + jj], 0, 0, 0);
+                }
         if (LORA && q == NP - 1) {
             // xf[wn], xf[wn + 2] with a compile-time register index: both candidates are named, the scalar wn selects
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
-                const bf16x8 xs = wn ? xf[2 * h + 1] : xf[2 * h];
+                const bf16x8 xs = wn ? xf[0][2 * h + 1] : xf[0][2 * h];
                 accl[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lf[h], xs, accl[0], 0, 0, 0);
             }
         }
@@ -628,6 +691,13 @@ __global__ __launch_bounds__(512, 2) void gemm8pb_kernel(const GemmArgs p) {
     if (grp == 0) __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_s_barrier();
 
+    if (LEAN && MODE == 0 && ln_on) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            const f32x2 mr = *(const f32x2*)(smem + 2 * BUF + (wm * (32 * MI) + i * 32 + lrow) * 8);
+            ln_mean[i] = mr[0]; ln_rstd[i] = mr[1];
+        }
+    }
     gemm_epilogue<MI, NI, MODE, LORA, NW, WN>(p, smem, acc, accl, ln_mean, ln_rstd, ln_on, tile_m, tile_n, ks_id, wave, wm, wn);
 }
 
@@ -637,15 +707,17 @@ namespace slh_gemm_detail {
 
 int launch_gemm8p(const GemmArgs& a, int mode, int ni_b, hipStream_t s) {
     const int grid = a.tiles_m * a.tiles_n * (a.splitk > 1 ? a.splitk : 1);
-#define SLH_LAUNCH_B(NI_)                                                                                        \
-    if (a.lora_down) {                                                                                           \
-        if (mode == 0) hipLaunchKernelGGL((gemm8pb_kernel<NI_, 0, true>), dim3(grid), dim3(512), 0, s, a);       \
-        else hipLaunchKernelGGL((gemm8pb_kernel<NI_, 1, true>), dim3(grid), dim3(512), 0, s, a);                 \
-    } else if (mode == 0) hipLaunchKernelGGL((gemm8pb_kernel<NI_, 0, false>), dim3(grid), dim3(512), 0, s, a);   \
-    else hipLaunchKernelGGL((gemm8pb_kernel<NI_, 1, false>), dim3(grid), dim3(512), 0, s, a)
+#define SLH_LAUNCH_B(NI_)                                                                                           \
+    if (a.lora_down) {                                                                                              \
+        if (mode == 0) hipLaunchKernelGGL((gemm8pb_kernel<1, NI_, 0, true>), dim3(grid), dim3(512), 0, s, a);       \
+        else hipLaunchKernelGGL((gemm8pb_kernel<1, NI_, 1, true>), dim3(grid), dim3(512), 0, s, a);                 \
+    } else if (mode == 0) hipLaunchKernelGGL((gemm8pb_kernel<1, NI_, 0, false>), dim3(grid), dim3(512), 0, s, a);   \
+    else hipLaunchKernelGGL((gemm8pb_kernel<1, NI_, 1, false>), dim3(grid), dim3(512), 0, s, a)
     if (ni_b == 0) {
         if (mode == 0) hipLaunchKernelGGL((gemm8p_kernel<0, false>), dim3(grid), dim3(512), 0, s, a);
         else hipLaunchKernelGGL((gemm8p_kernel<1, false>), dim3(grid), dim3(512), 0, s, a);
+    } else if (ni_b == 25) {           // 256 x 320 (dense, M % 256 == 0, packed W: checked by slh_gemm)
+        hipLaunchKernelGGL((gemm8pb_kernel<2, 5, 0, false>), dim3(grid), dim3(512), 0, s, a);
     } else if (ni_b == 3) { SLH_LAUNCH_B(3); }
     else if (ni_b == 4) { SLH_LAUNCH_B(4); }
     else { SLH_LAUNCH_B(5); }

@@ -669,6 +669,6 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, char* smem, f32
 }
 
 // gemm8p.hip: the 256 x 256 ping-pong K loop (slh_gemm_desc.tile code 0x8xxx)
-int launch_gemm8p(const GemmArgs& a, int mode, int ni_b, hipStream_t s);   // ni_b: 0 = 256 x 256, else 128 x 64*ni_b
+int launch_gemm8p(const GemmArgs& a, int mode, int ni_b, hipStream_t s);   // ni_b: 0 = 256 x 256, 3..5 = 128 x 64*ni_b, 25 = 256 x 320
 
 }  // namespace slh_gemm_detail

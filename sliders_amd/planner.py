@@ -240,7 +240,7 @@ class UNetPlan:
              lora_paths: Optional[List[str]] = None, geglu: bool = False, out: Optional[Act] = None,
              w_ptr: Optional[int] = None, bias_ptr: Optional[int] = None, vt_heads: Optional[int] = None,
              ln_stats: bool = False, ln_fold: Optional[Act] = None, geglu_pre: Optional[Act] = None,
-             ln_mr: Optional[Buf] = None, tape_x: Optional[Act] = None) -> Optional[Act]:
+             ln_mr: Optional[Buf] = None, tape_x: Optional[Act] = None, geglu16: bool = False) -> Optional[Act]:
         """y = x . W^T (+bias)(+rowbias per sample)(+LoRA)(+residual).  conv: {'stride','xform'} for 3x3.
         vt_heads: the product is a fused q|k|v projection of that many heads; where the kernel supports it (no-grad
         passes, head_dim % 64 == 0) its V third is written head-transposed for slh_attn_fwd straight from the epilogue
@@ -277,9 +277,11 @@ class UNetPlan:
                 T = self.f32((M, R), name + ".T") if self.train else None
             else:
                 T = self.skinny(x, self.lora.down_ptr(grp[0]), R, K, conv, M, Ho, Wo, name + ".lora_down")
+        sfx = "16" if geglu16 else ""      # GEGLU.proj in the 16 | 16 block order (slh_gemm_desc.geglu = 3)
+        assert not geglu16 or (geglu and geglu_pre is None and not lora_paths)
         d = lib.GemmDesc(a0=x0.ptr, a1=x1.ptr if x1 else 0,
-                         w=w_ptr if w_ptr is not None else self.w.ptr(wname + ".w"),
-                         bias=(bias_ptr if bias_ptr is not None else (self.w.ptr(wname + ".b") if bias else 0)),
+                         w=w_ptr if w_ptr is not None else self.w.ptr(wname + ".w" + sfx),
+                         bias=(bias_ptr if bias_ptr is not None else (self.w.ptr(wname + ".b" + sfx) if bias else 0)),
                          rowbias=rowbias[0] if rowbias else 0,
                          lora_t=T.ptr if (T and not fused) else 0, lora_up=self.lora.up_ptr(grp[0]) if grp else 0,
                          lora_down=self.lora.down_ptr(grp[0]) if fused else 0,
@@ -291,19 +293,28 @@ class UNetPlan:
                          mode=0, stride=1, ldw=K, M=M, N=N, K=K,
                          ld_rowbias=rowbias[1] if rowbias else 0, rows_per_sample=Ho * Wo,
                          ld_t=(4 * len(grp)) if grp else 0, lora_groups=len(grp) if grp else 0,
-                         ld_res=residual.ld if residual else 0, ldc=out.ld, geglu=1 if geglu else 0, tile=0,
+                         ld_res=residual.ld if residual else 0, ldc=out.ld, geglu=(3 if geglu16 else 1) if geglu else 0, tile=0,
                          w_layout=1 if (w_ptr is None and self.w.packed) else 0)
         if conv is not None:
             self._conv_fields(d, x0, conv, Ho, Wo)
+        # the tuned table keys the two sides of a folded LayerNorm apart (",ni" consumer, ",no" producer: the producer needs a
+        # 128-column tile): the descriptor carries the fold BEFORE the lookup (the producer's pointer is a placeholder until the
+        # tile that will run is known to support it)
+        train_fold = self.train and os.environ.get("SLIDERS_TRAIN_NO_LN_FOLD") is None
+        want_ln_out = bool(ln_stats and (not self.train or train_fold) and not geglu and N % 64 == 0)
+        if ln_fold is not None:
+            d.w, d.bias = self.w.ptr(wname + ".lnw" + sfx), 0
+            d.ln_in, d.ln_in_chunks, d.ln_eps = ln_fold.ln[0].ptr, ln_fold.ln[1], 1e-5
+            d.ln_s, d.ln_b = self.w.ptr(wname + ".lns" + sfx), self.w.ptr(wname + ".lnb" + sfx)
+        if want_ln_out:
+            d.ln_out = 8
         d.tile = tuned_tile(d)
+        d.ln_out = 0
         if not d.tile and M <= 192 and N >= 4096:
             d.tile = 0x12        # few rows, very wide: 64-row tiles waste the least of the short M
         if ln_fold is not None:
             if ((d.tile >> 16) & 15) > 1 or (not d.tile and splitk_wanted(d)):
                 return None
-            d.w, d.bias = self.w.ptr(wname + ".lnw"), 0
-            d.ln_in, d.ln_in_chunks, d.ln_eps = ln_fold.ln[0].ptr, ln_fold.ln[1], 1e-5
-            d.ln_s, d.ln_b = self.w.ptr(wname + ".lns"), self.w.ptr(wname + ".lnb")
             if ln_mr is not None:
                 d.ln_mr_out = ln_mr.ptr
         else:
@@ -311,9 +322,8 @@ class UNetPlan:
         if geglu_pre is not None:
             assert geglu and geglu_pre.C == N
             d.geglu_pre, d.ld_pre = geglu_pre.ptr, geglu_pre.ld
-        train_fold = self.train and os.environ.get("SLIDERS_TRAIN_NO_LN_FOLD") is None
-        if ln_stats and (not self.train or train_fold) and not geglu and N % 64 == 0 and not d.splitk_c32 and \
-                (lib.gemm_variant(d) >> 4) & 15 == 2:
+        if want_ln_out and not d.splitk_c32 and (lib.gemm_variant(d) >> 4) & 15 == 2 and \
+                ((d.tile >> 12) & 15 != 8 or (d.tile >> 4) & 15 == 4):
             st = self.f32((N // 64, M, 2), name + ".ln_chunks")
             d.ln_out = st.ptr
             out.ln = (st, N // 64)
@@ -369,14 +379,15 @@ class UNetPlan:
         return y
 
     def ln_gemm(self, h: Act, norm: str, wname: str, N: int, bias: bool = True, lora_paths: Optional[List[str]] = None,
-                geglu: bool = False, vt_heads: Optional[int] = None, geglu_pre: Optional[Act] = None) -> Act:
+                geglu: bool = False, vt_heads: Optional[int] = None, geglu_pre: Optional[Act] = None, geglu16: bool = False) -> Act:
         """Linear(LayerNorm(h)): folded into one product when h's producer left row statistics, the consumer carries no adapter
         and the pass keeps no tape; the LayerNorm launch + the plain product otherwise."""
         grp = self._lora_group(lora_paths) if lora_paths else None
         if grp is None and h.ln is not None and getattr(self.w, "ln_fold", False) and \
                 self.w.has(wname + ".lnw") and h.C % 64 == 0 and h.C <= 1280 and h.ld == h.C:
             if not self.train:
-                y = self.gemm(h, wname, N, wname, bias=False, geglu=geglu, vt_heads=vt_heads, ln_fold=h)
+                y = self.gemm(h, wname, N, wname, bias=False, geglu=geglu, vt_heads=vt_heads, ln_fold=h,
+                              geglu16=geglu16 and self.w.has(wname + ".lnw16"))
                 if y is not None:
                     return y
             elif os.environ.get("SLIDERS_TRAIN_NO_LN_FOLD") is None:
@@ -393,7 +404,7 @@ class UNetPlan:
                 del self.tape[mark:]
         n = self.layernorm(h, norm, norm)
         return self.gemm(n, wname, N, wname, bias=bias, lora_paths=lora_paths, geglu=geglu, vt_heads=vt_heads,
-                         geglu_pre=geglu_pre)
+                         geglu_pre=geglu_pre, geglu16=geglu16 and geglu_pre is None and self.w.has(wname + ".w16"))
 
     def attention(self, q: Act, k: Act, v: Act, Tk: int, heads: int, name: str, vt_pre=None) -> Act:
         """q [B*Tq][C] view, k/v [B*Tk][C] views (any ld); returns [B*Tq][C].  vt_pre = (pointer to this layer's first
@@ -547,7 +558,7 @@ class UNetPlan:
             grp = self._lora_group([path + ".ff.net.0.proj"])
             if grp is not None:
                 raise NotImplementedError("LoRA on GEGLU.proj is not a reference target")
-            ff = self.ln_gemm(h2, path + ".norm3", path + ".ff1", 8 * C, geglu=True)
+            ff = self.ln_gemm(h2, path + ".norm3", path + ".ff1", 8 * C, geglu=True, geglu16=getattr(self.w, "geglu16", False))
         return self.gemm(ff, path + ".ff2", C, path + ".ff2", residual=h2, lora_paths=[path + ".ff.net.2"], ln_stats=True)
 
     def _transformer(self, x: Act, path: str, layers: int, heads: int) -> Act:

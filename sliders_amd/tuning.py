@@ -31,14 +31,15 @@ def tile_ok(d, tile: int) -> bool:
     candidates and by the planner to drop a table entry that no longer fits the launch it is looked up for.)"""
     mi, ni, wm = (tile >> 4) & 15, tile & 15, (tile >> 12) & 15
     if wm == 8 and (tile >> 16) & 15:             # split-K: the slabs of these tiles must fit the workspace contract
-        bm, bn = (256, 256) if mi == 4 else (128, 64 * ni)
+        bm, bn = (256, 256) if mi == 4 else (128 * mi, 64 * ni)
         r = lambda v, q: (v + q - 1) // q * q
         if r(d.M, bm) * r(d.N, bn) > r(d.M, 256) * r(d.N, 128):
             return False
     if wm == 8:                                   # ping-pong K loops (csrc/gemm8p.hip)
         if (mi, ni) == (4, 2):                    # 256 x 256: no fused adapter
             return not d.lora_down and d.geglu in (0, 1, 2, 3)
-        if mi != 1 or ni < 3 or ni > 5:
+        if not ((mi == 1 and 3 <= ni <= 5) or
+                (mi == 2 and ni == 5 and not d.lora_down and d.mode == 0 and d.M % 256 == 0 and d.w_layout == 1)):
             return False
         if d.geglu in (1, 2) or d.ln_out or d.vt_out:     # 32 | 32 GEGLU blocks, chunk statistics and the V^T store assume NI = 2
             return False

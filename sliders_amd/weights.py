@@ -103,6 +103,10 @@ class WeightStore:
         # LayerNorm folded into its consumer GEMMs in the no-grad passes (one more copy of the q|k|v, attn2.to_q and GEGLU
         # projection matrices, pre-scaled by the LayerNorm weight); SLIDERS_NO_LN_FOLD=1 keeps the LayerNorm launches
         self.ln_fold = os.environ.get("SLIDERS_NO_LN_FOLD") is None
+        # GEGLU.proj also in the 16 | 16 block order (geglu = 3) for the no-grad passes: opens the 128 x 320 / 256 x 320 tiles to
+        # ff.net.0.proj.  Measured equal to the 32 | 32 form on the tiles that win today (profiles/r04_gemm_pingpong.md), so the
+        # second copy of the weights (+3.6 GB for SDXL) is opt-in: SLIDERS_GEGLU16=1
+        self.geglu16 = os.environ.get("SLIDERS_GEGLU16", "0") == "1"
         self.temb_offsets: Dict[str, int] = {}
         self.resnet_paths: List[str] = []
         self._pack()
@@ -118,7 +122,7 @@ class WeightStore:
         self.gemm_shape[name] = tuple(t.shape)
         self.t[name] = pack_gemm_w(t) if self.packed else t.contiguous()
 
-    def _put_ln_folded(self, wname: str, w: torch.Tensor, bias, gamma: torch.Tensor, beta: torch.Tensor, perm=None):
+    def _put_ln_folded(self, wname: str, w: torch.Tensor, bias, gamma: torch.Tensor, beta: torch.Tensor, perm=None, suffix: str = ""):
         """LayerNorm folded into the Linear that consumes it (slh_gemm_desc.ln_in; no-grad passes):
             Linear(LN(x)) = rstd * (x . W'^T - mean * s) + b',   W' = bf16(W * gamma),  s = row sums of W' (fp32, of the ROUNDED
             matrix the kernel multiplies with),  b' = bias + W . beta (fp32).
@@ -126,10 +130,10 @@ class WeightStore:
         wf, s, bp = fold_layernorm(w, bias, gamma, beta, self.dtype, self.device)
         if perm is not None:
             wf, s, bp = perm(wf), perm(s), perm(bp)
-        self.gemm_shape[wname + ".lnw"] = tuple(wf.shape)
-        self.t[wname + ".lnw"] = pack_gemm_w(wf) if self.packed else wf.contiguous()
-        self.t[wname + ".lns"] = s.contiguous()
-        self.t[wname + ".lnb"] = bp.contiguous()
+        self.gemm_shape[wname + ".lnw" + suffix] = tuple(wf.shape)
+        self.t[wname + ".lnw" + suffix] = pack_gemm_w(wf) if self.packed else wf.contiguous()
+        self.t[wname + ".lns" + suffix] = s.contiguous()
+        self.t[wname + ".lnb" + suffix] = bp.contiguous()
 
     def gemm_matrix(self, name: str) -> torch.Tensor:
         """Row-major [N][K] view of a tile-packed matrix (copy)."""
@@ -202,6 +206,12 @@ class WeightStore:
                 self._put(f"{a2}.out.b", sd[f"{a2}.to_out.0.bias"])
                 self._put_gemm(f"{name}.ff1.w", _geglu_perm(sd[f"{name}.ff.net.0.proj.weight"]))
                 self._put(f"{name}.ff1.b", _geglu_perm(sd[f"{name}.ff.net.0.proj.bias"]))
+                if self.geglu16:
+                    # second copy in the 16 | 16 block order of slh_gemm_desc.geglu = 3 (the no-grad passes: lets the tuner give
+                    # GEGLU.proj tiles whose waves own an odd number of 32-column blocks, e.g. 256 x 320); the training forward
+                    # keeps the 32 | 32 copy - its backward reads geglu_pre in that order
+                    self._put_gemm(f"{name}.ff1.w16", _geglu_perm16(sd[f"{name}.ff.net.0.proj.weight"]))
+                    self._put(f"{name}.ff1.b16", _geglu_perm16(sd[f"{name}.ff.net.0.proj.bias"]))
                 self._put_gemm(f"{name}.ff2.w", sd[f"{name}.ff.net.2.weight"])
                 self._put(f"{name}.ff2.b", sd[f"{name}.ff.net.2.bias"])
                 if self.ln_fold:
@@ -211,6 +221,9 @@ class WeightStore:
                     self._put_ln_folded(f"{a2}.q", sd[f"{a2}.to_q.weight"], None, *n2)
                     self._put_ln_folded(f"{name}.ff1", sd[f"{name}.ff.net.0.proj.weight"], sd[f"{name}.ff.net.0.proj.bias"], *n3,
                                         perm=_geglu_perm)
+                    if self.geglu16:
+                        self._put_ln_folded(f"{name}.ff1", sd[f"{name}.ff.net.0.proj.weight"], sd[f"{name}.ff.net.0.proj.bias"], *n3,
+                                            perm=_geglu_perm16, suffix="16")
         # all cross-attention K/V projections read the SAME text embeddings: one [sum(C) K rows | sum(C) V rows][Dctx]
         # matrix lets a UNet pass compute them in one full-chip launch instead of one 120-workgroup launch per
         # transformer block, and transposes every V with one more (tile-packed blocks are row-block major, so packed
