@@ -60,7 +60,10 @@ def table() -> Dict[str, int]:
     if _TABLE is None:
         _TABLE = {}
         here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tuning")
-        for path in sorted(glob.glob(os.path.join(here, "*.json"))):
+        paths = sorted(glob.glob(os.path.join(here, "*.json")))
+        if os.environ.get("SLIDERS_TUNING_OVERRIDE"):          # same-box A/B of table variants: entries of this file win
+            paths.append(os.environ["SLIDERS_TUNING_OVERRIDE"])
+        for path in paths:
             with open(path) as f:
                 _TABLE.update({k: int(v) for k, v in json.load(f).items()})
     return _TABLE
