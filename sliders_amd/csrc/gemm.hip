@@ -18,6 +18,7 @@
 // trainscripts/textsliders/lora.py:108-112.
 #include "gemm_common.h"
 #include <cstdlib>
+#include <cstring>
 
 using namespace slh_gemm_detail;
 
@@ -206,10 +207,8 @@ __global__ __launch_bounds__(128 * WM, gemm_waves_per_simd(MI, NI, STAGES, LORA,
     }
     int kt_begin = 0, nk = p.K / BK;
     if (p.splitk > 1) {
-        const int per = (nk + p.splitk - 1) / p.splitk;
-        kt_begin = ks_id * per;
-        nk = min(nk, kt_begin + per) - kt_begin;
-        if (nk <= 0) return;       // uniform over the workgroup
+        kt_begin = ks_id * p.kper;          // K tiles per slice: computed once, by slh_gemm, which also makes every slice non-empty
+        nk = min(nk, kt_begin + p.kper) - kt_begin;
     }
     const int lrow = lane & 31, lhi = lane >> 5;
 
@@ -697,11 +696,24 @@ extern "C" int slh_gemm(const slh_gemm_desc* d, slh_stream_t stream) {
         SLH_CHECK(d->geglu_pre && d->N % 32 == 0 && d->ldc >= 2 * d->N && d->ldc % 4 == 0 && !d->bias && !d->rowbias && !d->residual &&
                       !d->lora_t && !d->lora_down && !d->vt_out && !d->ln_in && !d->ln_out,
                   "slh_gemm: geglu = 2 (backward form) needs geglu_pre, N %% 32 == 0, ldc >= 2N and a bare product");
+    // same-XCD slab reads (gemm_common.h, split-K epilogue): gfx950 only, SLIDERS_SPLITK_LOCAL=0 turns them off
+    static const int splitk_local_ok = [] {
+        const char* e = getenv("SLIDERS_SPLITK_LOCAL");
+        if (e && atoi(e) == 0) return 0;
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
+        return strncmp(prop.gcnArchName, "gfx950", 6) == 0 ? 1 : 0;
+    }();
+    a.splitk_local = splitk_local_ok;
+    a.kper = d->K / 64;
     if (a.splitk > 1) {
         // every slice must be non-empty: each publishes its whole partial tile, the last one to arrive reads them all
         const int nk = d->K / 64;
         const int per = (nk + a.splitk - 1) / a.splitk;
         a.splitk = (nk + per - 1) / per;
+        a.kper = per;
+        SLH_CHECK((a.splitk - 1) * per < nk, "slh_gemm: internal: empty K slice (%d slices of %d over %d K tiles)", a.splitk, per, nk);
     }
     if (a.splitk > 1) {
         SLH_CHECK(d->splitk_c32, "slh_gemm: split-K needs the fp32 slab workspace splitk_c32");

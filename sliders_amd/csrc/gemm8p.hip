@@ -68,10 +68,8 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const GemmArgs p) {
 
     int kt_begin = 0, nk = p.K / BK;
     if (p.splitk > 1) {
-        const int per = (nk + p.splitk - 1) / p.splitk;
-        kt_begin = ks_id * per;
-        nk = min(nk, kt_begin + per) - kt_begin;
-        if (nk <= 0) return;       // uniform over the workgroup (the host makes every slice non-empty)
+        kt_begin = ks_id * p.kper;          // K tiles per slice: computed once, by slh_gemm, which also makes every slice non-empty
+        nk = min(nk, kt_begin + p.kper) - kt_begin;
     }
 
     // ---- staging geometry: every unit is 16 groups of 8 rows; wave w copies groups w and w + 8 -------------------------------
@@ -405,10 +403,8 @@ __global__ __launch_bounds__(512, 2) void gemm8pb_kernel(const GemmArgs p) {
 
     int kt_begin = 0, nk = p.K / BK;
     if (p.splitk > 1) {
-        const int per = (nk + p.splitk - 1) / p.splitk;
-        kt_begin = ks_id * per;
-        nk = min(nk, kt_begin + per) - kt_begin;
-        if (nk <= 0) return;
+        kt_begin = ks_id * p.kper;          // K tiles per slice: computed once, by slh_gemm, which also makes every slice non-empty
+        nk = min(nk, kt_begin + p.kper) - kt_begin;
     }
 
     // ---- staging geometry ---------------------------------------------------------------------------------------------------------

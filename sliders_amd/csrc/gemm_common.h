@@ -21,6 +21,8 @@ struct GemmArgs {
     int tiles_m, tiles_n, group_m;
     float* c32; float* t32;   // split-K: fp32 partial sums (zeroed by the caller), see slh_gemm_desc.splitk_c32
     int splitk;
+    int kper;                     // split-K: K tiles per slice (the last slice may be shorter, never empty)
+    int splitk_local;             // split-K: the last slice may read same-XCD partials through this XCD's L2 (see the epilogue)
     unsigned long long* ticket;   // split-K arrival tickets, one per output tile (slh_gemm_desc.splitk_ticket)
     __bf16* vt; int vt_col0, vt_D, vt_heads, vt_tokens, vt_ld;   // head-transposed store of the V columns (slh_gemm_desc.vt_out)
     int store16;  // c and ldc allow 16-byte row stores
@@ -201,7 +203,11 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, char* smem, f32
         __syncthreads();
         const unsigned long long seen = arrival;
         if ((int)(seen & 255) != p.splitk) return;
-        const bool local = (int)((seen >> (8 + 7 * xcc)) & 127) == p.splitk;     // uniform over the workgroup
+        // (The L2-local read is a measured shortcut of THIS chip, outside the memory model's guarantees: it relies on the slab
+        // lines never being resident in the reader's L1 - L1 is invalidated per dispatch and every slab line is read once - and on
+        // HW_REG_XCC_ID naming the L2 a workgroup's write-through stores passed.  slh_gemm enables it on gfx950 only;
+        // SLIDERS_SPLITK_LOCAL=0 switches to the agent-scope loads everywhere; tests/test_kernels_gpu.py stresses both.)
+        const bool local = p.splitk_local && (int)((seen >> (8 + 7 * xcc)) & 127) == p.splitk;     // uniform over the workgroup
         // slice 0 is loaded straight into the accumulators (their contents are in the slabs now), every further slice as
         // batches of independent 16-byte loads (one 32-row block): the serial part is one round trip per slice and block
         auto reduce = [&](auto kLocal) {

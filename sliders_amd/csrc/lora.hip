@@ -69,7 +69,7 @@ __global__ __launch_bounds__(256) void skinny_kernel(AddrArgs A, const __bf16* _
     // chain of dependent global round trips otherwise (a row's K / (8 LPR) chunks one after the other).
     if (A.mode == 0) {
         auto src_of = [&](int k) {
-            const int kc = k < K ? k : sub * 8;
+            const int kc = k < K ? k : 0;          // column 0 always exists (sub * 8 may lie past K when LPR * 8 > K); never accumulated
             return kc < A.ca0 ? A.a0 + (long)mm * A.lda0 + kc : A.a1 + (long)mm * A.lda1 + (kc - A.ca0);
         };
         bf16x8 cur = *(const bf16x8*)src_of(sub * 8);
@@ -93,7 +93,7 @@ __global__ __launch_bounds__(256) void skinny_kernel(AddrArgs A, const __bf16* _
             if (!ok) continue;
             const long pix = ((long)b * A.hs + (iy >> sh)) * A.ws + (ix >> sh);
             auto src_of = [&](int c) {
-                const int cc = c < cin ? c : sub * 8;
+                const int cc = c < cin ? c : 0;
                 return cc < A.ca0 ? A.a0 + pix * A.lda0 + cc : A.a1 + pix * A.lda1 + (cc - A.ca0);
             };
             bf16x8 cur = *(const bf16x8*)src_of(sub * 8);

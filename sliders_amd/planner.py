@@ -202,6 +202,12 @@ class UNetPlan:
         buf = self.arena.alloc((B * H * W, C), torch.bfloat16, name)
         return Act(buf.ptr, B, H, W, C, C, buf, name)
 
+    def key_act(self, B, H, W, C, name="") -> Act:
+        """An activation that is never written or read - a tape KEY for the gradient chain (the backward keys gradient buffers on
+        the forward buffer's address): one aligned granule of the arena instead of a B*H*W x C tensor."""
+        buf = self.arena.alloc((128,), torch.bfloat16, name)
+        return Act(buf.ptr, B, H, W, C, C, buf, name)
+
     def f32(self, shape, name="", zero=False) -> Buf:
         return (self.zarena if zero else self.arena).alloc(shape, torch.float32, name)
 
@@ -386,22 +392,28 @@ class UNetPlan:
         if grp is None and h.ln is not None and getattr(self.w, "ln_fold", False) and \
                 self.w.has(wname + ".lnw") and h.C % 64 == 0 and h.C <= 1280 and h.ld == h.C:
             if not self.train:
+                amark, nallocs = self.arena.mark(), len(self.arena.allocs)
                 y = self.gemm(h, wname, N, wname, bias=False, geglu=geglu, vt_heads=vt_heads, ln_fold=h,
                               geglu16=geglu16 and self.w.has(wname + ".lnw16"))
                 if y is not None:
                     return y
+                self.arena.reset(amark)           # fold refused: the output it had reserved goes back
+                del self.arena.allocs[nallocs:]
             elif os.environ.get("SLIDERS_TRAIN_NO_LN_FOLD") is None:
                 # training pass: the same fold; the product also leaves (mean, rstd) per row for the LayerNorm backward, and the
                 # tape keeps the LayerNorm and the product as two records around a stand-in for the normalised tensor
+                amark, nallocs = self.arena.mark(), len(self.arena.allocs)
                 mr = self.f32((h.M, 2), norm + ".mean_rstd")
-                stand_in = self.act(h.B, h.H, h.W, h.C, norm + ".unwritten")
+                stand_in = self.key_act(h.B, h.H, h.W, h.C, norm + ".unwritten")
                 mark = len(self.tape)
                 self.tape.append(dict(op="ln", x=h, out=stand_in, wname=norm, mr=mr, name=norm))
                 y = self.gemm(h, wname, N, wname, bias=False, geglu=geglu, ln_fold=h, ln_mr=mr, tape_x=stand_in,
                               geglu_pre=geglu_pre)
                 if y is not None:
                     return y
-                del self.tape[mark:]
+                del self.tape[mark:]              # fold refused (split-K tile): nothing was emitted - give the arena back too
+                self.arena.reset(amark)
+                del self.arena.allocs[nallocs:]
         n = self.layernorm(h, norm, norm)
         return self.gemm(n, wname, N, wname, bias=bias, lora_paths=lora_paths, geglu=geglu, vt_heads=vt_heads,
                          geglu_pre=geglu_pre, geglu16=geglu16 and geglu_pre is None and self.w.has(wname + ".w16"))

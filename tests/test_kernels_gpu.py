@@ -7,6 +7,7 @@ plus accumulation-order noise).  Elementwise kernels whose rounding points are r
 loss gradient, AdamW) must be BIT-EXACT against the torch bf16 ops.
 """
 import math
+import os
 
 import pytest
 import torch
@@ -1097,6 +1098,50 @@ def test_gemm_fused_lora_down(dev, tile):
     torch.cuda.synchronize()
     report(f"conv_fused_lora tile{tile:x}", c, ref, TOL)
     report(f"conv_fused_lora T tile{tile:x}", Tout, _to_pix(t_img), 1e-5)
+
+
+@pytest.mark.parametrize("local", ["1", "0"])
+def test_gemm_splitk_stress_same_slabs(dev, local):
+    """Back-to-back split-K launches that recycle ONE slab workspace and ONE ticket array (as consecutive products of a pass
+    do), different operands every launch, replayed as a hipGraph: every launch must reduce ITS slices' partials - a slab line
+    left in an L1 / L2 by an earlier launch, or a slice's store that the last arriver reads too early, would show as a wrong
+    tile.  Both read paths of the last arriver: the same-XCD shortcut (default on gfx950) and the agent-scope loads
+    (SLIDERS_SPLITK_LOCAL=0), each in a fresh process state of the library's cached switch (subprocess)."""
+    import subprocess, sys, textwrap
+    code = textwrap.dedent("""
+        import math, torch
+        from sliders_amd import lib
+        dev = torch.device("cuda:0")
+        torch.manual_seed(5)
+        M, N, K, S, L = 512, 640, 2560, 4, 72
+        xs = [(torch.randn(M, K, device=dev)).bfloat16() for _ in range(3)]
+        ws = [(torch.randn(N, K, device=dev) / math.sqrt(K)).bfloat16() for _ in range(3)]
+        outs = [torch.zeros(M, N, device=dev, dtype=torch.bfloat16) for _ in range(L)]
+        slabs = torch.full((S, 512, 640), float("nan"), device=dev)
+        tickets = torch.zeros(((M + 63) // 64) * ((N + 63) // 64), device=dev, dtype=torch.int64)
+        prog = lib.Program()
+        for i in range(L):
+            tile = (0x40412, 0x44412, 0x28015, 0x20022)[i % 4]
+            d = lib.GemmDesc(a0=xs[i % 3].data_ptr(), w=ws[(i // 3) % 3].data_ptr(), c=outs[i].data_ptr(), lda0=K, ca0=K, mode=0,
+                             stride=1, ldw=K, M=M, N=N, K=K, ldc=N, rows_per_sample=M, tile=tile, splitk_c32=slabs.data_ptr(),
+                             splitk_slabs=S, splitk_ticket=tickets.data_ptr())
+            prog.add(lib.OP_GEMM, d, f"g{i}")
+        s = torch.cuda.current_stream().cuda_stream
+        for rep in range(6):                     # the later replays run as one captured graph
+            for o in outs:
+                o.fill_(7.0)
+            prog.run(s)
+            torch.cuda.synchronize()
+            for i in range(L):
+                ref = xs[i % 3].float() @ ws[(i // 3) % 3].float().t()
+                err = ((outs[i].float() - ref).norm() / ref.norm()).item()
+                assert err < 4e-3, (rep, i, err)
+            assert int(tickets.abs().sum()) == 0
+        print("stress ok")
+    """)
+    env = dict(os.environ, SLIDERS_SPLITK_LOCAL=local, PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "stress ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
 @pytest.mark.parametrize("tile", [0x20412, 0x40421, 0x80422, 0x44412, 0x30011, 0x20022, 0xf0412, 0x28015, 0x38014])
