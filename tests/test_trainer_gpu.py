@@ -108,8 +108,10 @@ def test_iteration_matches_reference_loop_on_oracle(dev, name, action, pred):
 
 def test_dedup_frozen_equals_three_cfg_pairs(dev):
     """Same engine, same denoised latents, same timestep: the one-pass [uncond, positive, neutral] evaluation
-    against the reference's three CFG-pair passes.  Not bit-identical run to run (GroupNorm statistics are
-    summed with fp32 atomics, a 1-ulp bf16 flip then propagates), so the bound is the bf16 noise floor."""
+    against the reference's three CFG-pair passes.  Every reduction of the pass runs in a fixed order (round 3), rows of different
+    samples never meet in one accumulator, and on these nets both batch sizes resolve to the same tiles - so the three predictions
+    are EQUAL, bit for bit.  (On shapes where the tuned table picks another split-K factor for M = 3 HW than for 2 HW the K sum is
+    re-associated and the results differ in the last fp32 bits of a product: allowed here up to the value measured on MI355X, 0.)"""
     name, k, hw = "tiny_sdxl", 2, 16
     cfg, store, emb, pool, noise = _setup(dev)
     eng = UNetEngine(cfg, build_unet(name, seed=0).state_dict(), dev)
@@ -129,4 +131,4 @@ def test_dedup_frozen_equals_three_cfg_pairs(dev):
         b = b.float().cpu()
         r = rel_err(a, b)
         print(f"[parity] dedup {nm}: rel_l2 {r:.3e} max abs diff {(a - b).abs().max().item():.3e}")
-        assert r < 1e-2
+        assert torch.equal(a, b), f"dedup {nm}: the B=3 pass and the CFG-pair pass must agree bit for bit on this net (rel_l2 {r:.3e})"
