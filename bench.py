@@ -88,6 +88,10 @@ def measure_roofline(eng, plan):
         stage_bytes = (32 * mi * wm + 64 * ni + (32 if d.lora_down else 0)) * 128
         while stages > 2 and stages * stage_bytes > 160 * 1024:      # the launcher falls back to the deepest ring that fits
             stages -= 1
+        if wm == 8:                              # ping-pong K loops (csrc/gemm8p.hip)
+            if mi == 4:
+                return f"gemm8p_kernel<{v & 15}, false>"
+            return f"gemm8pb_kernel<{mi}, {ni}, {v & 15}, {'true' if d.lora_down else 'false'}>"
         return f"gemm_kernel<{mi}, {ni}, {v & 15}, {stages}, {'true' if d.lora_down else 'false'}, {wm}>"
 
     for _ in range(2):
@@ -151,10 +155,17 @@ def measure_roofline(eng, plan):
             pmj = json.load(f)
             pm = pmj["kernels"].get(kname.replace(", ", "; "))
             thead = pmj.get("tree_head")
-        if pm:
+        from sliders_amd.srchash import kernel_source_hash
+        here_hash, there_hash = kernel_source_hash(), pmj.get("kernel_source_hash")
+        if pm and there_hash == here_hash:
             traffic = pm["fetch_bytes_per_launch"] + pm["write_bytes_per_launch"]
             tsrc = (f"profiles/{os.path.basename(tpath)} (FETCH_SIZE x2 + WRITE_SIZE per launch, LoRA-on forward pass; counter passes "
-                    f"taken on tree {thead or 'unrecorded'})")
+                    f"taken on tree {thead or 'unrecorded'}, kernel sources + tile tables hash {there_hash} = this tree's)")
+        else:
+            # a counter file of OTHER kernels is not evidence about these: say so instead of pairing the numbers silently
+            tsrc = (f"none: profiles/{os.path.basename(tpath)} was taken on kernel sources / tile tables hash {there_hash or 'unrecorded'}, "
+                    f"this tree hashes {here_hash}" + ("" if pm else f"; it has no row for {kname}") +
+                    " - re-run scripts/measure_round4.sh")
     # MFMA utilisation from the newest committed counter pass: SQ_VALU_MFMA_BUSY_CYCLES (32 per 32x32x16 MFMA, summed over
     # the SIMDs) / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs)
     def mfma_util(kernel_prefix):
@@ -201,6 +212,75 @@ def measure_roofline(eng, plan):
         "dominant_rule": "largest share of the pass; instantiations within 5 % of it are ranked by algorithmic FLOPs",
         "all_gemm_variants": table, "paths": paths,
     }
+
+
+def cpu_baseline_config0(budget_s=75.0):
+    """BASELINE.json configs[0] as SURVEY.md 8(d) defines its CPU line: SD-1.4 architecture, 'age'-style text slider, rank 4
+    alpha 1, `noxattn`, batch 1, fp32, ONE training iteration of the reference loop (train_lora.py:155-321) with timesteps_to =
+    k = 5 on the host cores through the oracle: k denoise steps with the adapters on + three frozen predictions + the target
+    prediction (k + 4 = 9 UNet forwards on a CFG pair) + loss.backward() into the 150 adapters + AdamW.  512 x 512 when one
+    forward fits the budget / 11, else 256 x 256 with the rate scaled by latent area (flagged in `sample`)."""
+    import torch.nn.functional as F
+    from oracle.ddim_oracle import DDIMScheduler
+    from oracle.lora_oracle import LoRANetworkOracle
+    from oracle.unet_oracle import build_unet
+    from sliders_amd.config import CONFIGS
+    ncpu = _usable_cpus()
+    torch.set_num_threads(ncpu)
+    cfg = CONFIGS["sd1"]()
+    net = build_unet("sd1", seed=0)
+    net.requires_grad_(False)
+    nw = LoRANetworkOracle(net, rank=4, multiplier=1.0, alpha=1.0, train_method="noxattn")
+    g = torch.Generator().manual_seed(3)
+    for m in nw.unet_loras:                       # non-zero up matrices: the denoise chain depends on the adapters
+        m.lora_up.weight.data.copy_(torch.randn(m.lora_up.weight.shape, generator=g) * 0.02)
+    for p_ in nw.parameters():
+        p_.requires_grad_(True)
+    opt = torch.optim.AdamW(nw.parameters(), lr=2e-4)
+    emb = {n: torch.randn(1, 77, cfg.cross_attention_dim, generator=g) for n in ("target", "positive", "neutral", "uncond")}
+    k = 5
+
+    def predict(x, which, t, gs):
+        e = net(torch.cat([x] * 2), t, torch.cat([emb["uncond"], emb[which]]), None).sample
+        u, c = e.chunk(2)
+        return u + gs * (c - u)
+
+    def iteration(hw):
+        sch = DDIMScheduler()
+        t0 = time.time()
+        opt.zero_grad()
+        with torch.no_grad():
+            sch.set_timesteps(50)
+            x = torch.randn(1, 4, hw, hw, generator=g)
+            with nw:
+                for t in sch.timesteps[0:k]:
+                    x = sch.step(predict(x, "target", t, 3), t, x).prev_sample
+            sch.set_timesteps(1000)
+            t_cur = sch.timesteps[int(k * 1000 / 50)]
+            pos, neu, unc = (predict(x, w, t_cur, 1) for w in ("positive", "neutral", "uncond"))
+        t_fwd = time.time()
+        with nw:
+            tgt = predict(x, "target", t_cur, 1)
+        loss = F.mse_loss(tgt, neu + 4.0 * (pos - unc))
+        loss.backward()
+        opt.step()
+        return time.time() - t0, time.time() - t_fwd, float(loss.detach())
+
+    with torch.no_grad():                          # probe: one forward at 256 x 256 (also creates the oneDNN primitives)
+        predict(torch.randn(1, 4, 32, 32, generator=g), "target", torch.tensor(500), 1)
+        t0 = time.time()
+        predict(torch.randn(1, 4, 32, 32, generator=g), "target", torch.tensor(500), 1)
+        f256 = time.time() - t0
+    hw = 64 if 4.0 * f256 * 12 < budget_s else 32
+    wall, t_train, loss = iteration(hw)
+    scale = (64 * 64) / float(hw * hw)
+    return {"value": round((k + 4) / (wall * scale), 4), "unit": "UNet denoise steps/s (SD-1.4 512x512 bs 1, rank-4 text slider, fp32)",
+            "cores": ncpu, "kind": "port", "iterations_per_s": round(1.0 / (wall * scale), 5),
+            "iteration_s": round(wall * scale, 2), "train_forward_backward_adamw_s": round(t_train * scale, 2),
+            "sample": (f"one training iteration of the reference loop at k = {k} ({k + 4} forwards on a CFG pair + backward + AdamW) through the "
+                       f"CPU oracle, timed at {hw * 8}x{hw * 8}" + ("" if hw == 64 else ", scaled by latent area to 512x512 (extrapolated)") +
+                       f"; loss {loss:.4e}"),
+            "config": "BASELINE.json configs[0] / SURVEY.md 8(d)"}
 
 
 def measure_vae_roofline(vae, vae_sd, image, res_px):
@@ -533,6 +613,10 @@ def run_config(a, dev, world, rank, main_line):
     if rank == 0 and world == 1:
         if not a.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(a.model, hw)
+            try:
+                res["cpu_baseline_config0"] = cpu_baseline_config0()
+            except Exception as ex:                          # a reported side figure must never cost the bench line
+                res["cpu_baseline_config0"] = {"value": None, "error": repr(ex)[:200]}
     return res
 
 

@@ -4,7 +4,11 @@ MI355X_MICROARCH.md section HBM), WRITE_SIZE is taken as reported (uncalibrated)
 usage: make_pmc_traffic.py fetch_summary.csv write_summary.csv out.json"""
 import csv
 import json
+import os
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from sliders_amd.srchash import kernel_source_hash
 
 
 def rows(path):
@@ -25,7 +29,7 @@ for r in rows(write):
     k["write_bytes_per_launch"] = int(1024 * float(r["WRITE_SIZE"]) / n)
     hit, miss = float(r["TCC_HIT_sum"]), float(r["TCC_MISS_sum"])
     k["l2_hit_rate"] = round(hit / (hit + miss), 3) if hit + miss > 0 else None
-res = {"tree_head": tree_head, "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum (separate passes, --kernel-trace only) over "
+res = {"tree_head": tree_head, "kernel_source_hash": kernel_source_hash(), "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum (separate passes, --kernel-trace only) over "
                  "LoRA-on SDXL 1024x1024 B=2 UNet passes (scripts/bench_forward.py --lora --warm 0 --iters 1: the first call "
                  "plus one replay); FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports 64 B per 128-B request); "
                  "WRITE_SIZE uncalibrated; KB -> bytes",
