@@ -373,8 +373,14 @@ typedef struct slh_wgrad_desc {
     int32_t M, R, ldv, ldo;
     int32_t out_rmajor;      /* 1: out is [R][ldo] (down-weight layout), 0: [C][ldo] (up-weight layout) */
     int32_t vgroup_cols;     /* >0: channel c uses V columns 4*(c/vgroup_cols).. (fused q/k/v up grads) */
+    float* slabs;            /* fixed-order reduction over the M splits (bit-reproducible gradients): slh_lora_wgrad_single_blocks(d)
+                                slabs of 256 * R floats (contents irrelevant) ... */
+    void* tickets;           /* ... and as many uint32 arrival tickets, zeroed once (the last arriver re-arms them).  Both NULL:
+                                fp32 atomics (commit in arrival order).  Inside a batch: any non-NULL slabs selects the slab
+                                geometry for slh_lora_wgrad_blocks; the workspace itself is the batch's */
 } slh_wgrad_desc;
 int slh_lora_wgrad(const slh_wgrad_desc* d, slh_stream_t stream);
+int slh_lora_wgrad_single_blocks(const slh_wgrad_desc* d);
 
 /* Batched launches: n independent problems of one kind in ONE launch (the backward of a UNet pass has ~380 rank-4
  * weight-gradient reductions and ~210 head transposes of forward activations, each far too small to fill the chip).
@@ -386,6 +392,9 @@ typedef struct slh_batch_desc {
     int32_t n, total;
     int32_t arg;             /* slh_lora_wgrad_batch: R (4 or 12), the same for every problem of the batch */
     int32_t pad_;
+    void* slabs;             /* slh_lora_wgrad_batch: `total` slabs of 256 * R floats + ... */
+    void* tickets;           /* ... `total` uint32 tickets (zeroed once): fixed-order reduction, every problem's descriptor built
+                                with a non-NULL slabs; both NULL: fp32 atomics */
 } slh_batch_desc;
 int slh_lora_wgrad_blocks(const slh_wgrad_desc* d);
 int slh_lora_wgrad_batch(const slh_batch_desc* d, slh_stream_t stream);

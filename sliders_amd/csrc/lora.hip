@@ -198,11 +198,19 @@ struct WgradArgs {
     AddrArgs A;
     const float* v; float* out; const float* scale;
     int M, R, ldv, ldo, rows_per_block, rmajor, vgroup_cols;
+    // fixed-order reduction over the M splits (ws != null): every workgroup publishes its 32 x 8R partial sums in its own slab,
+    // the split of a column block that arrives last adds the slabs in split order and does the one `out +=` of that block -
+    // bit-reproducible gradients.  ws == null: fp32 atomics (commit in arrival order).
+    float* ws; unsigned* ticket;
 };
 
+// slab_id: index of this workgroup's slab, slab_step: slabs between consecutive splits of one column block, ticket_id: the
+// column block's arrival ticket, splits: M splits of the block
 template <int R>
-__device__ __forceinline__ void wgrad_body(const WgradArgs& p, const int bx, const int by, const int bz) {
+__device__ __forceinline__ void wgrad_body(const WgradArgs& p, const int bx, const int by, const int bz, const long slab_id = 0,
+                                           const int slab_step = 0, const long ticket_id = 0, const int splits = 1) {
     __shared__ float red[4][32][8 * R + 1];
+    __shared__ int last_flag;
     const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;
     const int C = p.A.ca0 + p.A.ca1;
     const int c = (bx * 32 + cx) * 8;
@@ -259,6 +267,52 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& p, const int bx, con
     __syncthreads();
     // 256 threads reduce 32 chunks x (8R) values over the 8 row-lanes
     const float s = *p.scale;
+    if (p.ws != nullptr) {
+        constexpr int PER = 32 * 8 * R;                                   // floats per slab: 4 consecutive ones per thread and pass
+        const __amdgpu_buffer_rsrc_t slabs = __builtin_amdgcn_make_buffer_rsrc(p.ws + slab_id * PER - (long)by * slab_step * PER, 0,
+                                                                              (int)((long)splits * slab_step * PER * 4), 0x00020000);
+#pragma unroll
+        for (int q = 0; q < PER / 1024; ++q) {
+            const int idx = (q * 256 + threadIdx.x) * 4;
+            f32x4 t4;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int ccx = (idx + u) / (8 * R), er = (idx + u) - ccx * (8 * R);
+                float t = 0.f;
+#pragma unroll
+                for (int y = 0; y < 4; ++y) t += red[y][ccx][er];
+                t4[u] = t;
+            }
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, t4), slabs, (by * slab_step * PER + idx) * 4, 0, 16 /* sc1 */);
+        }
+        if (!last_arriver(p.ticket + ticket_id, (unsigned)splits, &last_flag)) return;
+#pragma unroll
+        for (int q = 0; q < PER / 1024; ++q) {
+            const int idx = (q * 256 + threadIdx.x) * 4;
+            f32x4 tot = {0.f, 0.f, 0.f, 0.f};
+            for (int k0 = 0; k0 < splits; k0 += 8) {                      // 8 independent loads in flight, added in split order
+                f32x4 v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    v[u] = k0 + u < splits ? __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                                                 slabs, ((k0 + u) * slab_step * PER + idx) * 4, 0, 16 /* sc1 */))
+                                           : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int u = 0; u < 8; ++u) tot += v[u];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int ccx = (idx + u) / (8 * R), er = (idx + u) - ccx * (8 * R);
+                const int e = er / R, r = er - e * R;
+                const int cc = (bx * 32 + ccx) * 8 + e;
+                if (cc >= C) continue;
+                const long col = (p.A.mode == 0 ? 0 : (long)tap * C) + cc;
+                float* o = p.rmajor ? p.out + (long)r * p.ldo + col : p.out + col * p.ldo + r;
+                *o += s * tot[u];                                         // the only writer of this element in this launch
+            }
+        }
+        return;
+    }
     for (int idx = threadIdx.x; idx < 32 * 8 * R; idx += 256) {
         const int ccx = idx / (8 * R);
         const int er = idx - ccx * (8 * R);
@@ -276,20 +330,25 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& p, const int bx, con
 
 template <int R>
 __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p) {
-    wgrad_body<R>(p, blockIdx.x, blockIdx.y, blockIdx.z);
+    // slab of workgroup (bx, by, bz): ((bz * splits + by) * gx + bx); ticket of its column block: bz * gx + bx
+    wgrad_body<R>(p, blockIdx.x, blockIdx.y, blockIdx.z, ((long)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x,
+                  (int)gridDim.x, (long)blockIdx.z * gridDim.x + blockIdx.x, (int)gridDim.y);
 }
 
-// launch geometry of one weight-gradient problem (host and device agree by construction)
+// launch geometry of one weight-gradient problem (host and device agree by construction).  kind: 0 = one launch per problem,
+// partial sums meet in fp32 atomics (~768 workgroups, 3 per CU); 1 = one launch per problem, slab reduction (~256 workgroups:
+// every split costs a slab round trip); 2 = a problem inside a batched launch, slab reduction: the batch supplies the
+// parallelism, a split is worth it only from ~512 rows on
 struct WgradGeom { int gx, splits, taps, rows_per_block; };
-__host__ __device__ inline WgradGeom wgrad_geom(int C, int M, int mode) {
+__host__ __device__ inline WgradGeom wgrad_geom(int C, int M, int mode, int kind) {
     WgradGeom g;
     g.gx = (C / 8 + 31) / 32;
     g.taps = mode == 1 ? 9 : 1;
-    // a rank-4 gradient is a reduction over M with only C/256 (x9 taps) independent column blocks: split M until the
-    // launch has ~768 workgroups (3 per CU), at least 64 rows each; partial sums meet in the fp32 atomics of wgrad_body
+    // a rank-4 gradient is a reduction over M with only C/256 (x9 taps) independent column blocks: split M, at least 64 rows each
     const int blocks_xz = g.gx * g.taps;
-    int splits = (768 + blocks_xz - 1) / blocks_xz;
-    const int max_splits = (M + 63) / 64, min_splits = (M + 1023) / 1024;
+    const int target = kind == 0 ? 768 : 256;
+    int splits = kind == 2 ? (M + 511) / 512 : (target + blocks_xz - 1) / blocks_xz;
+    const int max_splits = (M + 63) / 64, min_splits = kind == 2 ? 1 : (M + 1023) / 1024;
     if (splits > max_splits) splits = max_splits;
     if (splits < min_splits) splits = min_splits;
     if (splits < 1) splits = 1;
@@ -306,7 +365,8 @@ __host__ __device__ inline void wgrad_args(WgradArgs& p, const slh_wgrad_desc& d
     p.M = d.M; p.R = d.R; p.ldv = d.ldv; p.ldo = d.ldo;
     p.rmajor = d.out_rmajor;
     p.vgroup_cols = d.vgroup_cols;
-    p.rows_per_block = wgrad_geom(d.c0 + d.c1, d.M, d.mode).rows_per_block;
+    p.ws = d.slabs; p.ticket = (unsigned*)d.tickets;
+    p.rows_per_block = wgrad_geom(d.c0 + d.c1, d.M, d.mode, d.slabs ? 1 : 0).rows_per_block;
 }
 
 // problem of workgroup `bid`: the last index with prefix[index] <= bid (prefix[0] = 0, prefix[n] = total > bid)
@@ -319,17 +379,22 @@ __device__ __forceinline__ int batch_find(const int* prefix, int n, int bid) {
     return lo;
 }
 
+// ws / ticket: the batch's workspace (one slab per workgroup, one ticket per workgroup id - a column block uses the ticket at
+// the id of its first split) or null (atomics, the legacy geometry)
 template <int R>
-__global__ __launch_bounds__(256) void wgrad_batch_kernel(const slh_wgrad_desc* table, const int* prefix, int n) {
+__global__ __launch_bounds__(256) void wgrad_batch_kernel(const slh_wgrad_desc* table, const int* prefix, int n, float* ws, unsigned* ticket) {
     const int bid = blockIdx.x;
     const int pi = __builtin_amdgcn_readfirstlane(batch_find(prefix, n, bid));
     const slh_wgrad_desc d = table[pi];
     WgradArgs p;
     wgrad_args(p, d);
-    const WgradGeom g = wgrad_geom(d.c0 + d.c1, d.M, d.mode);
+    p.ws = ws; p.ticket = ticket;
+    const WgradGeom g = wgrad_geom(d.c0 + d.c1, d.M, d.mode, ws ? 2 : 0);
+    p.rows_per_block = g.rows_per_block;
     const int local = bid - prefix[pi];
     const int bx = local % g.gx, rest = local / g.gx;
-    wgrad_body<R>(p, bx, rest % g.splits, rest / g.splits);
+    const int by = rest % g.splits, bz = rest / g.splits;
+    wgrad_body<R>(p, bx, by, bz, bid, g.gx, (long)prefix[pi] + (long)bz * g.splits * g.gx + bx, g.splits);
 }
 
 }  // namespace
@@ -392,11 +457,14 @@ extern "C" int slh_gemv(const slh_gemv_desc* d, slh_stream_t stream) {
     return 0;
 }
 
-static int wgrad_check(const slh_wgrad_desc* d) {
-    SLH_CHECK(d && d->z0 && d->v && d->out && d->scale, "slh_lora_wgrad: null pointer");
+// ptrs: also the operand pointers (launch time); the geometry queries of plan time (slh_lora_wgrad_*blocks: also called by
+// dry-run planning, which has shapes but no memory yet) check the shape fields only
+static int wgrad_check(const slh_wgrad_desc* d, bool ptrs = true) {
+    SLH_CHECK(d, "slh_lora_wgrad: null descriptor");
+    if (ptrs) SLH_CHECK(d->z0 && d->v && d->out && d->scale, "slh_lora_wgrad: null pointer");
     SLH_CHECK(d->R == 4 || d->R == 12, "slh_lora_wgrad: R must be 4 or 12");
     SLH_CHECK(d->c0 % 8 == 0 && d->c1 % 8 == 0 && d->ldz0 % 8 == 0 && d->ldz1 % 8 == 0, "slh_lora_wgrad: alignment");
-    SLH_CHECK((d->z1 != nullptr) == (d->c1 > 0), "slh_lora_wgrad: z1/c1 mismatch");
+    if (ptrs) SLH_CHECK((d->z1 != nullptr) == (d->c1 > 0), "slh_lora_wgrad: z1/c1 mismatch");
     SLH_CHECK(d->M > 0 && d->c0 + d->c1 > 0, "slh_lora_wgrad: empty problem");
     if (d->mode == 1) SLH_CHECK(d->M == d->batch * d->ho * d->wo, "slh_lora_wgrad: conv M mismatch");
     return 0;
@@ -406,7 +474,8 @@ extern "C" int slh_lora_wgrad(const slh_wgrad_desc* d, slh_stream_t stream) {
     if (wgrad_check(d)) return -1;
     WgradArgs p;
     wgrad_args(p, *d);
-    const WgradGeom g = wgrad_geom(d->c0 + d->c1, d->M, d->mode);
+    SLH_CHECK((d->slabs != nullptr) == (d->tickets != nullptr), "slh_lora_wgrad: slabs and tickets come together");
+    const WgradGeom g = wgrad_geom(d->c0 + d->c1, d->M, d->mode, d->slabs ? 1 : 0);
     dim3 grid(g.gx, g.splits, g.taps);
     hipStream_t s = (hipStream_t)stream;
     if (d->R == 4) hipLaunchKernelGGL(wgrad_kernel<4>, grid, dim3(256), 0, s, p);
@@ -416,19 +485,28 @@ extern "C" int slh_lora_wgrad(const slh_wgrad_desc* d, slh_stream_t stream) {
 }
 
 extern "C" int slh_lora_wgrad_blocks(const slh_wgrad_desc* d) {
-    if (wgrad_check(d)) return -1;
-    const WgradGeom g = wgrad_geom(d->c0 + d->c1, d->M, d->mode);
+    if (wgrad_check(d, false)) return -1;
+    const WgradGeom g = wgrad_geom(d->c0 + d->c1, d->M, d->mode, d->slabs ? 2 : 0);
+    return g.gx * g.splits * g.taps;
+}
+
+extern "C" int slh_lora_wgrad_single_blocks(const slh_wgrad_desc* d) {
+    if (wgrad_check(d, false)) return -1;
+    const WgradGeom g = wgrad_geom(d->c0 + d->c1, d->M, d->mode, 1);
     return g.gx * g.splits * g.taps;
 }
 
 extern "C" int slh_lora_wgrad_batch(const slh_batch_desc* d, slh_stream_t stream) {
     SLH_CHECK(d && d->table && d->prefix && d->n > 0 && d->total > 0, "slh_lora_wgrad_batch: empty batch / null pointer");
     SLH_CHECK(d->arg == 4 || d->arg == 12, "slh_lora_wgrad_batch: arg must be the common R (4 or 12)");
+    SLH_CHECK((d->slabs != nullptr) == (d->tickets != nullptr), "slh_lora_wgrad_batch: slabs and tickets come together");
     hipStream_t s = (hipStream_t)stream;
     if (d->arg == 4)
-        hipLaunchKernelGGL(wgrad_batch_kernel<4>, dim3(d->total), dim3(256), 0, s, (const slh_wgrad_desc*)d->table, d->prefix, d->n);
+        hipLaunchKernelGGL(wgrad_batch_kernel<4>, dim3(d->total), dim3(256), 0, s, (const slh_wgrad_desc*)d->table, d->prefix, d->n,
+                           (float*)d->slabs, (unsigned*)d->tickets);
     else
-        hipLaunchKernelGGL(wgrad_batch_kernel<12>, dim3(d->total), dim3(256), 0, s, (const slh_wgrad_desc*)d->table, d->prefix, d->n);
+        hipLaunchKernelGGL(wgrad_batch_kernel<12>, dim3(d->total), dim3(256), 0, s, (const slh_wgrad_desc*)d->table, d->prefix, d->n,
+                           (float*)d->slabs, (unsigned*)d->tickets);
     SLH_LAUNCH_CHECK("slh_lora_wgrad_batch");
     return 0;
 }

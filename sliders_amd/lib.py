@@ -72,7 +72,7 @@ LossDesc = _struct("LossDesc", _ptrs("target", "positive", "neutral", "uncond", 
                    + _ints("n") + [("guidance", c_f32)] + _ints("erase", "hw", "nch"))
 WgradDesc = _struct("WgradDesc", _ptrs("z0", "z1", "v", "out", "scale")
                     + _ints("ldz0", "ldz1", "c0", "c1", "mode", "batch", "hs", "ws", "src_xform", "stride", "ho",
-                            "wo", "M", "R", "ldv", "ldo", "out_rmajor", "vgroup_cols"))
+                            "wo", "M", "R", "ldv", "ldo", "out_rmajor", "vgroup_cols") + _ptrs("slabs", "tickets"))
 AdamwDesc = _struct("AdamwDesc", _ptrs("param", "exp_avg", "exp_avg_sq", "grad") + [("n", c_i64)]
                     + [(n, c_f64) for n in ("lr", "beta1", "beta2", "eps", "weight_decay")]
                     + _ints("step") + [("grad_scale", c_f32)])
@@ -91,7 +91,7 @@ Gn32Desc = _struct("Gn32Desc", _ptrs("x", "gamma", "beta", "stats", "y") + _ints
 Softmax32Desc = _struct("Softmax32Desc", _ptrs("x") + [("ld", c_i64)] + _ints("rows", "cols"))
 VaeConvDesc = _struct("VaeConvDesc", _ptrs("x", "w", "bias", "qw", "qb", "y") + _ints("batch", "h", "wd", "cin", "cout")
                       + [("inv_scaling", c_f32)])
-BatchDesc = _struct("BatchDesc", _ptrs("table", "prefix") + _ints("n", "total", "arg", "pad_"))
+BatchDesc = _struct("BatchDesc", _ptrs("table", "prefix") + _ints("n", "total", "arg", "pad_") + _ptrs("slabs", "tickets"))
 Gather16Desc = _struct("Gather16Desc", _ptrs("src", "idx", "out") + [("n", c_i64)])
 VaeSampleDesc = _struct("VaeSampleDesc", _ptrs("moments", "post_noise", "noise", "latent_f32", "noisy_f32", "noisy_bf16")
                         + _ints("batch", "hw") + [("scaling", c_f32), ("sqrt_alpha", c_f32), ("sqrt_one_minus_alpha", c_f32)]
@@ -136,7 +136,7 @@ _ENTRY = {
 
 EXPORTS = ["slh_version", "slh_last_error", "slh_run_program", "slh_desc_sizes", "slh_graph_capture", "slh_graph_launch",
            "slh_graph_destroy", "slh_gemm_variant", "slh_gn_row_blocks", "slh_gn_clusters", "slh_gn32_row_blocks",
-           "slh_lora_wgrad_blocks", "slh_transpose_heads_blocks", "slh_gn_fused_ok"] + [v[0] for v in _ENTRY.values()]
+           "slh_lora_wgrad_blocks", "slh_lora_wgrad_single_blocks", "slh_transpose_heads_blocks", "slh_gn_fused_ok"] + [v[0] for v in _ENTRY.values()]
 
 
 class SlidersHipError(RuntimeError):
@@ -233,7 +233,7 @@ def batch_table(opcode: int, descs, device, arg: int = 0):
     prefix = [0]
     for d in descs:
         assert isinstance(d, dtype)
-        nb = fn(C.byref(d)) if device is not None else 1
+        nb = fn(C.byref(d))         # host-side geometry only: also in dry-run planning (the arena is sized from it)
         if nb <= 0:
             raise SlidersHipError(f"{fn_name}: {last_error()}")
         prefix.append(prefix[-1] + nb)
@@ -243,6 +243,17 @@ def batch_table(opcode: int, descs, device, arg: int = 0):
     table = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(device)
     pre = torch.tensor(prefix, dtype=torch.int32, device=device)
     return BatchDesc(table=table.data_ptr(), prefix=pre.data_ptr(), n=len(descs), total=prefix[-1], arg=arg), (table, pre)
+
+
+def wgrad_single_blocks(desc) -> int:
+    """Workgroups (= slabs = tickets) of a stand-alone slh_lora_wgrad launch with the fixed-order reduction."""
+    lib = load()
+    lib.slh_lora_wgrad_single_blocks.argtypes = [C.POINTER(WgradDesc)]
+    lib.slh_lora_wgrad_single_blocks.restype = c_i32
+    nb = lib.slh_lora_wgrad_single_blocks(C.byref(desc))
+    if nb <= 0:
+        raise SlidersHipError(f"slh_lora_wgrad_single_blocks: {last_error()}")
+    return nb
 
 
 def gemm_variant(desc) -> int:

@@ -703,13 +703,23 @@ class BackwardPlan:
         self._wg_batch: Dict[int, List] = {4: [], 12: []}
         self._keep: List = []            # device tables of the batched launches
         self.batched = os.environ.get("SLIDERS_BWD_UNBATCHED") is None
+        # weight gradients reduced over their M splits in a fixed order (slabs + tickets) instead of fp32 atomics: the LoRA
+        # gradient buffer is bit-reproducible.  SLIDERS_WGRAD_ATOMIC=1: the old form (A/B)
+        self.wgrad_fixed_order = os.environ.get("SLIDERS_WGRAD_ATOMIC") is None
         self.fuse_u = os.environ.get("SLIDERS_BWD_UNFUSED_U") is None
         self._uses_up_t = False
         self._walk()
         dev = None if self.arena.virtual else fwd.lora.params.device
         for R, descs in self._wg_batch.items():
             if descs:
+                if self.wgrad_fixed_order:
+                    for d in descs:
+                        d.slabs = 8                 # marker: slab geometry (the workspace is the batch's)
                 bd, keep = lib.batch_table(lib.OP_WGRAD_BATCH, descs, dev, arg=R)
+                if self.wgrad_fixed_order:
+                    # one slab of 256 R floats and one ticket per workgroup: the M splits of a column block meet in a fixed order
+                    bd.slabs = self.arena.alloc((bd.total, 256 * R), torch.float32, f"bwd.wgrad_slabs_R{R}").ptr
+                    bd.tickets = self.zarena.alloc((bd.total,), torch.int32, f"bwd.wgrad_tickets_R{R}").ptr
                 self._keep.append(keep)
                 self.prog.add(lib.OP_WGRAD_BATCH, bd, f"bwd.wgrad_batch_R{R}")
         zend = self.zarena.mark()
@@ -888,6 +898,10 @@ class BackwardPlan:
         if defer and self.batched:
             self._wg_batch[d.R].append(d)
         else:
+            if self.wgrad_fixed_order:
+                nb = lib.wgrad_single_blocks(d)
+                d.slabs = self.arena.alloc((nb, 256 * d.R), torch.float32, name + ".slabs").ptr
+                d.tickets = self.zarena.alloc((nb,), torch.int32, name + ".tickets").ptr
             self.prog.add(lib.OP_WGRAD, d, name)
 
     def _b_gemm(self, rec):

@@ -936,6 +936,63 @@ def test_lora_wgrad(dev):
     report("wgrad_conv", out, 0.25 * wd.grad.permute(0, 2, 3, 1).reshape(4, -1), 1e-4)
 
 
+def test_lora_wgrad_fixed_order_is_bit_reproducible(dev):
+    """slh_wgrad_desc.slabs / tickets (and slh_batch_desc.slabs / tickets): the M splits of a column block publish their partial
+    sums in slabs, the split that arrives last adds them in split order and does the block's one `out +=` - the same bits every
+    time, whatever order the workgroups ran in; same numbers as the atomic form up to fp32 re-association; tickets left zero;
+    += semantics kept."""
+    torch.manual_seed(41)
+    scale = torch.tensor([0.5], device=dev)
+    cases = []
+    for M, C, R, rmajor in ((4096, 1280, 4, 1), (1500, 320, 4, 0), (2048, 640, 12, 1), (64, 64, 4, 0)):
+        z = bf(torch.randn(M, C, device=dev))
+        v = torch.randn(M, 12, device=dev)
+        cases.append((M, C, R, rmajor, z, v))
+
+    def desc(case, out, slabs=None, tickets=None):
+        M, C, R, rmajor, z, v = case
+        return lib.WgradDesc(z0=p(z), v=p(v), out=p(out), scale=p(scale), ldz0=C, c0=C, mode=0, stride=1, M=M, R=R, ldv=12,
+                             ldo=C if rmajor else R, out_rmajor=rmajor, vgroup_cols=0, slabs=p(slabs) if slabs is not None else 0,
+                             tickets=p(tickets) if tickets is not None else 0)
+
+    shape = lambda c: (c[2], c[1]) if c[3] else (c[1], c[2])
+    # single launches
+    for case in cases:
+        probe = desc(case, torch.zeros(shape(case), device=dev), torch.zeros(1, device=dev), torch.zeros(1, device=dev))
+        nb = lib.wgrad_single_blocks(probe)
+        outs = []
+        for rep in range(3):
+            out = torch.full(shape(case), 0.25, device=dev)                   # += : starts non-zero
+            slabs = torch.full((nb, 256 * case[2]), float("nan"), device=dev)
+            tickets = torch.zeros(nb, device=dev, dtype=torch.int32)
+            for _ in range(2):                                                  # twice into the same buffer, recycling the workspace
+                lib.call(lib.OP_WGRAD, desc(case, out, slabs, tickets), stream())
+            torch.cuda.synchronize()
+            assert int(tickets.abs().sum()) == 0
+            outs.append(out)
+        assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2]), "fixed-order weight gradients must be bit-reproducible"
+        ref = 0.25 + 2 * 0.5 * (case[5][:, :case[2]].t() @ case[4].float() if case[3] else case[4].float().t() @ case[5][:, :case[2]])
+        report(f"wgrad fixed order M{case[0]} C{case[1]} R{case[2]}", outs[0], ref, 1e-4)
+    # one batched launch (R = 4 problems), slab geometry
+    r4 = [c for c in cases if c[2] == 4]
+    runs = []
+    for rep in range(3):
+        outs = [torch.full(shape(c), -0.5, device=dev) for c in r4]
+        descs = [desc(c, o, torch.zeros(1, device=dev), torch.zeros(1, device=dev)) for c, o in zip(r4, outs)]    # non-NULL slabs: slab geometry
+        bd, keep = lib.batch_table(lib.OP_WGRAD_BATCH, descs, dev, arg=4)
+        slabs = torch.full((bd.total, 1024), float("nan"), device=dev)
+        tickets = torch.zeros(bd.total, device=dev, dtype=torch.int32)
+        bd.slabs, bd.tickets = p(slabs), p(tickets)
+        lib.call(lib.OP_WGRAD_BATCH, bd, stream())
+        torch.cuda.synchronize()
+        assert int(tickets.abs().sum()) == 0
+        runs.append(outs)
+    for i, c in enumerate(r4):
+        assert torch.equal(runs[0][i], runs[1][i]) and torch.equal(runs[0][i], runs[2][i])
+        ref = -0.5 + 0.5 * (c[5][:, :4].t() @ c[4].float() if c[3] else c[4].float().t() @ c[5][:, :4])
+        report(f"wgrad batch fixed order problem {i}", runs[0][i], ref, 1e-4)
+
+
 def test_batched_wgrad_transposes_and_gather(dev):
     """slh_batch_desc: n weight-gradient reductions / head transposes of different shapes in ONE launch give what the n
     single launches give (the table and the prefix sums of workgroups live in device memory; a workgroup finds its problem

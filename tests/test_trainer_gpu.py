@@ -106,6 +106,29 @@ def test_iteration_matches_reference_loop_on_oracle(dev, name, action, pred):
     assert delta.max().item() < 5e-4 and delta.max().item() > 0
 
 
+@pytest.mark.parametrize("name", ["tiny_sdxl", "tiny_sd1"])
+def test_iteration_is_bit_reproducible_including_gradients(dev, name):
+    """Two fresh engines + trainers, the same inputs: loss, LoRA gradient buffer and updated parameters are EQUAL bit for bit.
+    The forward pass has been since round 3 (fixed-order GroupNorm / split-K reductions); round 4 removed the last fp32
+    atomics of the path, the M-split sums of the weight gradients (slh_wgrad_desc.slabs / tickets), so `loss.backward()`
+    (train_lora_xl.py:345) is reproducible too - and data-parallel replicas can be compared by equality, not cosine."""
+    k, hw = 3, 16
+    runs = []
+    for rep in range(2):
+        cfg, store, emb, pool, noise = _setup(dev, name)
+        eng = UNetEngine(cfg, build_unet(name, seed=0).state_dict(), dev)
+        tr = SliderTrainer(eng, store, hw, hw, lr=2e-4)
+        losses = [tr.iteration(_pair(emb, pool, dev, "enhance"), k, noise.to(dev)).item() for _ in range(2)]   # two optimizer steps
+        torch.cuda.synchronize()
+        runs.append((losses, store.grads.clone(), store.params.clone(), tr.e_tgt.clone()))
+    (l0, g0, p0, e0), (l1, g1, p1, e1) = runs
+    assert l0 == l1
+    assert torch.equal(e0, e1)
+    ndiff = int((g0 != g1).sum())
+    assert torch.equal(g0, g1), f"{ndiff} of {g0.numel()} gradient elements differ between two identical runs"
+    assert torch.equal(p0, p1)
+
+
 def test_dedup_frozen_equals_three_cfg_pairs(dev):
     """Same engine, same denoised latents, same timestep: the one-pass [uncond, positive, neutral] evaluation
     against the reference's three CFG-pair passes.  Every reduction of the pass runs in a fixed order (round 3), rows of different
