@@ -224,20 +224,8 @@ def train(config: config_util.RootConfig, prompts, device: int, xl: bool, synthe
         s, pair = pairs[pi]
         # per-pair resolution / dynamic_resolution / batch_size / dynamic_crops (train_lora_xl.py:179-203); the draws
         # come from the rank-shared stream so that every rank does the same amount of work in a step
-        height = width = s.resolution
-        gshared = samp.shared
-        if s.dynamic_resolution:
-            st = torch.random.get_rng_state()
-            torch.manual_seed(int(torch.randint(0, 2 ** 31 - 1, (1,), generator=gshared).item()))
-            height, width = get_random_resolution_in_bucket(s.resolution)
-            torch.random.set_rng_state(st)
-        time_ids = None
-        if eng.cfg.is_xl and s.dynamic_crops:
-            st = torch.random.get_rng_state()
-            torch.manual_seed(int(torch.randint(0, 2 ** 31 - 1, (1,), generator=gshared).item()))
-            ids = get_add_time_ids(height, width, dynamic_crops=True, dtype=torch.bfloat16)   # bf16 like the reference (quirk D.8)
-            torch.random.set_rng_state(st)
-            time_ids = ids.float().repeat(2 * s.batch_size, 1)
+        height, width = samp.resolution(s)
+        time_ids = samp.time_ids(s, height, width, eng.cfg.is_xl)
         # get_initial_latents (train_util.py:55): unit noise times the scheduler's init_noise_sigma
         noise = samp.noise((s.batch_size, 4, height // 8, width // 8)).to(dev) * tr.sched.init_noise_sigma
         lr = sched.current()

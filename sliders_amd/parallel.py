@@ -39,12 +39,40 @@ class StepSampler:
 
     def next(self):
         """-> (k, pair_index).  k is identical on all ranks; pair indices of one step are distinct whenever
-        world <= n_pairs."""
+        world <= n_pairs.  Every call consumes the SAME number of draws of the shared stream on every rank (k, the base
+        pair, and the two seeds of this step's resolution / crop draws - used or not), so ranks whose prompt pairs have
+        different settings (one with dynamic_resolution, one without) cannot drift apart."""
         k = int(torch.randint(1, self.max_steps, (1,), generator=self.shared).item())
         base = int(torch.randint(0, self.n_pairs, (1,), generator=self.shared).item())
+        self.res_seed = int(torch.randint(0, 2 ** 31 - 1, (1,), generator=self.shared).item())
+        self.crop_seed = int(torch.randint(0, 2 ** 31 - 1, (1,), generator=self.shared).item())
         pair = (base + self.rank) % self.n_pairs
         self.step += 1
         return k, pair
+
+    def resolution(self, settings):
+        """(height, width) of this step for a prompt pair's settings (train_lora_xl.py:179-186): the bucket draw of
+        get_random_resolution_in_bucket under this step's rank-shared seed, so every rank whose pair asks for the same
+        bucket denoises the same latent size (equal work per step)."""
+        from .train_util import get_random_resolution_in_bucket
+        height = width = settings.resolution
+        if settings.dynamic_resolution:
+            st = torch.random.get_rng_state()
+            torch.manual_seed(self.res_seed)
+            height, width = get_random_resolution_in_bucket(settings.resolution)
+            torch.random.set_rng_state(st)
+        return height, width
+
+    def time_ids(self, settings, height, width, is_xl):
+        """SDXL micro-conditioning with dynamic_crops (train_lora_xl.py:188-203) under this step's rank-shared seed, or None."""
+        if not (is_xl and settings.dynamic_crops):
+            return None
+        from .train_util import get_add_time_ids
+        st = torch.random.get_rng_state()
+        torch.manual_seed(self.crop_seed)
+        ids = get_add_time_ids(height, width, dynamic_crops=True, dtype=torch.bfloat16)   # bf16 like the reference (quirk D.8)
+        torch.random.set_rng_state(st)
+        return ids.float().repeat(2 * settings.batch_size, 1)
 
     def noise(self, shape) -> torch.Tensor:
         """Latent noise, drawn on the CPU like the reference (train_util.py:20-32)."""

@@ -116,3 +116,44 @@ def test_single_process_is_identity():
     s = StepSampler(seed=1, rank=0, world=1, n_pairs=2)
     k, p = s.next()
     assert 1 <= k <= 49 and p in (0, 1)
+
+
+def test_step_sampler_ranks_stay_in_step_with_mixed_prompt_settings():
+    """Ranks whose prompt pairs have DIFFERENT settings (dynamic_resolution / dynamic_crops on one pair, off on another) must keep
+    drawing the same k - and the same (height, width) whenever their pairs ask for the same bucket - at every step: the shared
+    stream is consumed identically by every rank whatever its pair needs (sliders_amd/parallel.py StepSampler.next).  A rank
+    that consumed one draw more would run a different denoise length from the next step on (up to 49x the work)."""
+    from types import SimpleNamespace as S
+    settings = [S(resolution=1024, dynamic_resolution=True, dynamic_crops=True, batch_size=1),
+                S(resolution=1024, dynamic_resolution=False, dynamic_crops=False, batch_size=1),
+                S(resolution=1024, dynamic_resolution=True, dynamic_crops=False, batch_size=1),
+                S(resolution=512, dynamic_resolution=True, dynamic_crops=True, batch_size=2)]
+    world = 4
+    samps = [StepSampler(seed=11, rank=r, world=world, n_pairs=len(settings)) for r in range(world)]
+    seen_dynamic = set()
+    for step in range(64):
+        draws = []
+        for smp in samps:
+            k, pi = smp.next()
+            s = settings[pi]
+            h, w = smp.resolution(s)
+            ids = smp.time_ids(s, h, w, is_xl=True)
+            draws.append((k, pi, h, w, None if ids is None else tuple(ids.flatten().tolist()), s))
+        assert len({d[0] for d in draws}) == 1, f"step {step}: k differs across ranks: {[d[0] for d in draws]}"
+        assert len({d[1] for d in draws}) == world, "pair indices of one step are distinct while world <= n_pairs"
+        # the ranks whose pairs draw from the same bucket get the same resolution (equal work), fixed-resolution pairs their own
+        dyn1024 = {(d[2], d[3]) for d in draws if d[5].dynamic_resolution and d[5].resolution == 1024}
+        assert len(dyn1024) == 1
+        seen_dynamic |= dyn1024
+        for d in draws:
+            if not d[5].dynamic_resolution:
+                assert (d[2], d[3]) == (d[5].resolution, d[5].resolution)
+            assert (d[4] is not None) == d[5].dynamic_crops
+            assert 0 < d[2] <= d[5].resolution and d[2] % 64 == 0
+    assert len(seen_dynamic) > 4, "the bucket draw varies from step to step"
+    # the global torch RNG (the reference's own stream, e.g. for dropout-free init) is left untouched by the shared draws
+    torch.manual_seed(123)
+    a = torch.rand(3)
+    torch.manual_seed(123)
+    samps[0].next(); samps[0].resolution(settings[0]); samps[0].time_ids(settings[0], 512, 512, True)
+    assert torch.equal(a, torch.rand(3))
