@@ -78,8 +78,7 @@ typedef struct slh_gemm_desc {
                                 workgroup, block tile (32*MI*WM) x (64*NI); stages 0|2: double buffer, 3|4: deep LDS ring;
                                 S: split-K factor (0|1 none), needs splitk_c32.
                                 WM = 8: ping-pong K loops, one 8-wave workgroup per CU (csrc/gemm8p.hip): 0x8042 = 256 x 256
-                                (no fused adapter), 0x801<NI> = 128 x 64*NI, NI = 3..5, 0x8025 = 256 x 320 (no fused adapter); 0x801x / 0x8025: geglu 0 | 3
-                                only, no ln_out / vt_out */
+                                (no fused adapter), 0x801<NI> = 128 x 64*NI, NI = 3..5 (geglu 0 | 3 only, no ln_out / vt_out) */
     int32_t lora_rank;       /* 0 = 4.  With lora_up_rmajor: total rank 4 | 8 | 12 (T has that many columns) */
     int32_t lora_up_rmajor;  /* 1: lora_up is [rank][N] (= lora_down as stored): backward-data LoRA term */
     int32_t w_layout;        /* 0: w is [N][ldw].  1: frozen weights repacked once at load time into the order the kernel

@@ -26,7 +26,7 @@ ap.add_argument("--hw", type=int, default=128)
 ap.add_argument("--out", default=None)
 ap.add_argument("--reps", type=int, default=2)
 ap.add_argument("--tiles", default="11,12,21,22,4011,4012,4022,322,422,412,421,4412,4322,4411,"
-                "20412,40412,80412,20421,40421,80421,20422,40422,24412,44412,40411,80411,f0412,8015,8014,8013,8042,28015,28014,8025")
+                "20412,40412,80412,20421,40421,80421,20422,40422,24412,44412,40411,80411,f0412,8015,8014,8013,8042,28015,28014")
 ap.add_argument("--fwd-only", action="store_true")
 ap.add_argument("--incremental", action="store_true",
                 help="baseline = the committed table; a candidate replaces an entry only when it is > 2 %% faster")

@@ -521,7 +521,7 @@ static void pick_tile(const slh_gemm_desc* d, int& MI, int& NI, int& WM) {
         MI = (d->tile >> 4) & 15; NI = d->tile & 15;
         const int wcode = (d->tile >> 12) & 15;
         WM = wcode == 4 ? 4 : 2;
-        if (wcode == 8) WM = 8;      // ping-pong K loops (gemm8p.hip): MI = 4, NI = 2 -> 256 x 256; MI = 1, NI = 3..5 -> 128 x 64*NI; MI = 2, NI = 5 -> 256 x 320
+        if (wcode == 8) WM = 8;      // ping-pong K loops (gemm8p.hip): MI = 4, NI = 2 -> 256 x 256; MI = 1, NI = 3..5 -> 128 x 64*NI
         if (MI) return;
         MI = 2; NI = 2; WM = 2;
     }
@@ -625,12 +625,9 @@ extern "C" int slh_gemm(const slh_gemm_desc* d, slh_stream_t stream) {
     int MI = 2, NI = 2, WM = 2;
     pick_tile(d, MI, NI, WM);
     if (WM == 8) {
-        SLH_CHECK((MI == 4 && NI == 2) || (MI == 1 && NI >= 3 && NI <= 5) || (MI == 2 && NI == 5),
-                  "slh_gemm: ping-pong tiles are 256 x 256 (0x8042), 128 x 64*NI (0x801<NI>, NI = 3..5) or 256 x 320 (0x8025)");
-        SLH_CHECK(!d->lora_down || MI == 1, "slh_gemm: the 256-row ping-pong tiles do not take a fused adapter (lora_down)");
-        if (MI == 2)
-            SLH_CHECK(d->mode == 0 && d->M % 256 == 0 && d->w_layout == 1,
-                      "slh_gemm: the 256 x 320 tile (0x8025) runs dense products with M %% 256 == 0 and tile-packed weights");
+        SLH_CHECK((MI == 4 && NI == 2) || (MI == 1 && NI >= 3 && NI <= 5),
+                  "slh_gemm: ping-pong tiles are 256 x 256 (0x8042) or 128 x 64*NI (0x801<NI>, NI = 3..5)");
+        SLH_CHECK(!d->lora_down || MI == 1, "slh_gemm: the 256 x 256 tile does not take a fused adapter (lora_down)");
     } else {
         SLH_CHECK((MI == 1 || MI == 2) && (NI == 1 || NI == 2), "slh_gemm: bad tile");
         SLH_CHECK(WM == 2 || NI == 2 || MI == 1, "slh_gemm: 8-wave tiles are 128x64, 128x128 or 256x128");
@@ -738,7 +735,7 @@ extern "C" int slh_gemm(const slh_gemm_desc* d, slh_stream_t stream) {
             SLH_CHECK((long)a.tiles_m * bm * a.tiles_n * bn <= ((d->M + 255) / 256 * 256L) * ((d->N + 127) / 128 * 128L),
                       "slh_gemm: split-K slabs of %d x %d tiles exceed the workspace contract for M=%d N=%d", bm, bn, d->M, d->N);
         a.group_m = pick_group_m(d, a.tiles_m);
-        return launch_gemm8p(a, d->mode, MI == 4 ? 0 : (MI == 2 ? 20 + NI : NI), (hipStream_t)stream);
+        return launch_gemm8p(a, d->mode, MI == 4 ? 0 : NI, (hipStream_t)stream);
     }
     a.tiles_m = (d->M + 32 * MI * WM - 1) / (32 * MI * WM);
     a.tiles_n = (d->N + 64 * NI - 1) / (64 * NI);

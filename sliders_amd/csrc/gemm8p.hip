@@ -82,19 +82,7 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const GemmArgs p) {
     constexpr int XOFF[4] = {0, 128, 64, 192};
     constexpr int WOFF[4] = {0, 128, 32, 160};
 
-    int xb[4], xoy[4], xox[4];           // conv: sample / output pixel of the row
-    if (MODE == 1) {
-#pragma unroll
-        for (int a = 0; a < 4; ++a) {
-            int m = m0 + xrow0 + XOFF[a] + frow;
-            m = m < p.M ? m : p.M - 1;
-            const int hw = p.ho * p.wo;
-            const int b = m / hw;
-            const int rem = m - b * hw;
-            const int oy = rem / p.wo;
-            xb[a] = b; xoy[a] = oy; xox[a] = rem - oy * p.wo;
-        }
-    }
+
     const int wkstep = p.w_packed ? 4096 : BK;   // elements between consecutive K tiles of one W row group
     const char* wsrc[4];
 #pragma unroll
@@ -112,7 +100,7 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const GemmArgs p) {
     // the second concat source (same scheme as the ring loop of gemm.hip).  The schedule keeps issuing units for two K tiles past
     // the end of the slice: those come from the zero page (pointer parked, no advance) and land in rows nobody reads again.
     const char* xsrc[4];
-    int xadv[4];
+    unsigned xmove = 15;                   // bit a: group a's pointer advances with K (conv: 0 for a tap outside the image - the zero page)
     const char* zero_page = (const char*)slh_zero_page;
     asm volatile("" : "+s"(zero_page));    // formed once (a GOT load), not re-materialised inside the K loop
     int i_c0 = kt_begin * BK, i_tap = 0;
@@ -130,8 +118,8 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const GemmArgs p) {
                 int m = m0 + row;
                 m = m < p.M ? m : p.M - 1;
                 xsrc[a] = (const char*)(base + (long)m * (s1 ? p.lda1 : p.lda0) + cc + (((SLH8P_VAR & 4) ? fslot : (fslot ^ ((row >> 1) & 7))) << 3));
-                xadv[a] = 128;
             }
+            xmove = 15;
         } else {
             const int ld = s1 ? p.lda1 : p.lda0;
             const int ky = i_tap / 3, kx = i_tap - ky * 3;
@@ -140,14 +128,22 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const GemmArgs p) {
 #pragma unroll
             for (int a = 0; a < 4; ++a) {
                 const int row = xrow0 + XOFF[a] + frow;
-                const int iy = xoy[a] * p.stride + ky - 1;
-                const int ix = xox[a] * p.stride + kx - 1;
+                // sample / output pixel of the row: recomputed here (9 x sources times per K slice) rather than carried in 12
+                // registers through the K loop
+                int m = m0 + row;
+                m = m < p.M ? m : p.M - 1;
+                const int hw = p.ho * p.wo;
+                const int xb_a = m / hw;
+                const int rem = m - xb_a * hw;
+                const int xoy_a = rem / p.wo, xox_a = rem - xoy_a * p.wo;
+                const int iy = xoy_a * p.stride + ky - 1;
+                const int ix = xox_a * p.stride + kx - 1;
                 bool ok = (iy >= 0) & (iy < HL) & (ix >= 0) & (ix < WL);
                 if (p.src_xform == 2) ok = ok & (((iy | ix) & 1) == 0);
                 const int sy = iy >> sh, sx = ix >> sh;
-                const long pix = ((long)xb[a] * p.hs + sy) * p.ws + sx;
+                const long pix = ((long)xb_a * p.hs + sy) * p.ws + sx;
                 xsrc[a] = ok ? (const char*)(base + pix * ld + cc + ((fslot ^ ((row >> 1) & 7)) << 3)) : zero_page;
-                xadv[a] = ok ? 128 : 0;
+                xmove = ok ? (xmove | (1u << a)) : (xmove & ~(1u << a));
             }
         }
     };
@@ -168,7 +164,8 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const GemmArgs p) {
             if (x_left <= 0) {
                 if (x_left == 0) {
 #pragma unroll
-                    for (int a = 0; a < 4; ++a) { xsrc[a] = zero_page; xadv[a] = 0; }
+                    for (int a = 0; a < 4; ++a) xsrc[a] = zero_page;
+                    xmove = 0;
                 }
             } else if (i_first || i_c0 == 0 || i_c0 == p.ca0) {
                 rebase_x();
@@ -191,7 +188,7 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(const GemmArgs p) {
     auto unit_end = [&](const int u) {
         if (u == 4) {
 #pragma unroll
-            for (int a = 0; a < 4; ++a) xsrc[a] += (SLH8P_ABL & 32) ? 0 : xadv[a];     // ABL 32: every K tile re-reads the first one (L2-hit rate of the DMA path)
+            for (int a = 0; a < 4; ++a) xsrc[a] += (SLH8P_ABL & 32) ? 0 : (int)((xmove >> a) & 1) << 7;     // ABL 32: every K tile re-reads the first one (L2-hit rate of the DMA path)
             i_c0 += BK;
             if (MODE == 1 && i_c0 == cin) { i_c0 = 0; ++i_tap; }
             --x_left;
@@ -379,17 +376,10 @@ __global__ __launch_bounds__(512, 2) void gemm8pb_kernel(const GemmArgs p) {
     // LORA: the rank-r down matrix (lora_down [r][K], r <= 12, zero-padded to 32 rows) rides along as a third operand tile, as in
     // gemm.hip: its piece travels with the X unit, the two waves that share 32 rows split its k-steps (wn = 0 the even ones), their
     // MFMAs go into the last - shortest - phase, and the shared epilogue's exchange (wave ^ 1) joins the halves.
-    static_assert(NI >= 3 && NI <= 5 && NP >= 3 && (MI == 1 || (MI == 2 && !LORA)), "128 x 192 ... 128 x 320, 256 x 320 without the adapter");
+    static_assert(NI >= 3 && NI <= 5 && NP >= 3 && MI == 1, "128 x 192 ... 128 x 320 (a 256 x 320 tile, MI = 2, was built and measured: 160 accumulator registers leave no room, and one round of 256 big tiles loses to two of 512 - docs/ROUND_NOTES.md)");
     static_assert(gemm_epilogue_lds(MI, NI, NW, WN, LORA) <= 2 * BUF, "epilogue staging must fit the operand buffers");
-    // LEAN (the 256-row tile, whose 160 accumulator registers leave ~90 for everything else): ONE running pointer per operand
-    // + wave-uniform byte offsets to the wave's other 8-row groups instead of one 64-bit pointer per group (needs M % 256 == 0:
-    // no row clamp, dense single- or two-source A, tile-packed W whose 64-row blocks are zero-padded), and the folded LayerNorm's
-    // per-row (mean, rstd) wait in the 2 KB of LDS behind the operand buffers instead of in registers.
-    constexpr bool LEAN = MI == 2;
-    static_assert(!LEAN || MODE == 0, "the 256-row tile: dense products only");
-    constexpr int LNB = LEAN ? BM * 8 : 0;
-    static_assert(2 * BUF + LNB <= 160 * 1024, "LDS");
-    __shared__ __attribute__((aligned(16))) char smem[2 * BUF + LNB];
+    static_assert(2 * BUF <= 160 * 1024, "LDS");
+    __shared__ __attribute__((aligned(16))) char smem[2 * BUF];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -428,40 +418,21 @@ __global__ __launch_bounds__(512, 2) void gemm8pb_kernel(const GemmArgs p) {
         }
     }
     const int wkstep = p.w_packed ? 4096 : BK;
-    const char* wsrc[LEAN ? 1 : NI];
-    int woff[LEAN ? NI : 1];        // LEAN: byte offset of block j's 8-row group from block 0's (wave-uniform)
-    if (LEAN) {
-        // tile-packed W: row n lives in block n >> 6 at (n & 63) * 128 B; the wave's group of block j starts at row
-        // nb_j = n0 + wrow0 + j*32 (a multiple of 8, so the group never straddles a 64-row block); whole blocks past
-        // ceil64(N) do not exist: their groups re-read block 0's (the columns are never stored)
-        const int nb0 = n0 + wrow0;
-        const int nlim = (p.N + 63) & ~63;
-        const int n0c = nb0 < nlim ? nb0 : 0;
-        const long base0 = ((long)(n0c >> 6) * (p.K >> 6)) * 8192 + (n0c & 63) * 128;
-        wsrc[0] = (const char*)p.w + base0 + frow * 128 + fslot * 16 + (long)kt_begin * 8192;
+    const char* wsrc[NI];
 #pragma unroll
-        for (int j = 0; j < NI; ++j) {
-            const int nb = nb0 + j * 32;
-            const int nc = nb < nlim ? nb : n0c;
-            woff[j] = (int)(((long)(nc >> 6) * (p.K >> 6)) * 8192 + (nc & 63) * 128 - base0);
-        }
-    } else {
-#pragma unroll
-        for (int j = 0; j < NI; ++j) {
-            const int row = wrow0 + j * 32 + frow;
-            int n = n0 + row;
-            n = n < p.N ? n : p.N - 1;
-            const __bf16* wp = p.w_packed ? p.w + ((long)(n >> 6) * (p.K >> 6)) * 4096 + ((n & 63) << 6) + (fslot << 3)
-                                          : p.w + (long)n * p.ldw + ((fslot ^ ((row >> 1) & 7)) << 3);
-            wsrc[j] = (const char*)(wp + (long)kt_begin * wkstep);
-        }
+    for (int j = 0; j < NI; ++j) {
+        const int row = wrow0 + j * 32 + frow;
+        int n = n0 + row;
+        n = n < p.N ? n : p.N - 1;
+        const __bf16* wp = p.w_packed ? p.w + ((long)(n >> 6) * (p.K >> 6)) * 4096 + ((n & 63) << 6) + (fslot << 3)
+                                      : p.w + (long)n * p.ldw + ((fslot ^ ((row >> 1) & 7)) << 3);
+        wsrc[j] = (const char*)(wp + (long)kt_begin * wkstep);
     }
     int wkbytes = wkstep * 2;
     const char* lsrc = nullptr;
     int ladv = 0;
-    const char* xsrc[LEAN ? 1 : XG];
-    int xadv[LEAN ? 1 : XG];
-    long xgoff = 0;                 // LEAN: bytes between the wave's consecutive X groups (64 rows), wave-uniform
+    const char* xsrc[XG];
+    int xadv[XG];
     const char* zero_page = (const char*)slh_zero_page;
     asm volatile("" : "+s"(zero_page));
     int i_c0 = kt_begin * BK, i_tap = 0;
@@ -478,13 +449,7 @@ __global__ __launch_bounds__(512, 2) void gemm8pb_kernel(const GemmArgs p) {
         const bool s1 = i_c0 >= p.ca0;
         const __bf16* base = s1 ? p.a1 : p.a0;
         const int cc = s1 ? i_c0 - p.ca0 : i_c0;
-        if (LEAN) {
-            const int row = xrow0 + frow;            // rows of the groups a > 0: + 64 a (same swizzle: 64 is a multiple of 16)
-            const int ld = s1 ? p.lda1 : p.lda0;
-            xsrc[0] = (const char*)(base + (long)(m0 + row) * ld + cc + ((fslot ^ ((row >> 1) & 7)) << 3));
-            xadv[0] = 128;
-            xgoff = 128L * ld;
-        } else if (MODE == 0) {
+        if (MODE == 0) {
 #pragma unroll
             for (int a = 0; a < XG; ++a) {
                 const int row = xrow0 + a * 64 + frow;
@@ -519,24 +484,17 @@ __global__ __launch_bounds__(512, 2) void gemm8pb_kernel(const GemmArgs p) {
             if (x_left <= 0) {
                 if (x_left == 0) {
 #pragma unroll
-                    for (int a = 0; a < (LEAN ? 1 : XG); ++a) { xsrc[a] = zero_page; xadv[a] = 0; }
-                    xgoff = 0;
+                    for (int a = 0; a < XG; ++a) { xsrc[a] = zero_page; xadv[a] = 0; }
                     if (LORA) { lsrc = zero_page; ladv = 0; }
                 }
             } else if (i_first || i_c0 == 0 || i_c0 == p.ca0) {
                 rebase_x();
             }
             i_first = false;
-            if (LEAN) {
 #pragma unroll
-                for (int a = 0; a < XG; ++a) glds16_hidden(xsrc[0] + a * xgoff, lds0 + bo + (xrow0 + a * 64) * 128);
-                xsrc[0] += xadv[0];
-            } else {
-#pragma unroll
-                for (int a = 0; a < XG; ++a) {
-                    glds16_hidden(xsrc[a], lds0 + bo + (xrow0 + a * 64) * 128);
-                    xsrc[a] += xadv[a];
-                }
+            for (int a = 0; a < XG; ++a) {
+                glds16_hidden(xsrc[a], lds0 + bo + (xrow0 + a * 64) * 128);
+                xsrc[a] += xadv[a];
             }
             if (LORA) {
                 glds16_hidden(lsrc, lds0 + bo + XB + WB + (wave & 3) * 1024);
@@ -549,26 +507,15 @@ __global__ __launch_bounds__(512, 2) void gemm8pb_kernel(const GemmArgs p) {
             const int q = u - 1;
             if (q == 0 && w_left == 0) {
 #pragma unroll
-                for (int j = 0; j < (LEAN ? 1 : NI); ++j) wsrc[j] = zero_page;
-                if (LEAN) {
-#pragma unroll
-                    for (int j = 0; j < NI; ++j) woff[j] = 0;
-                }
+                for (int j = 0; j < NI; ++j) wsrc[j] = zero_page;
                 wkbytes = 0;
             }
 #pragma unroll
             for (int j = BP * q; j < BP * q + BP && j < NI; ++j) {
-                if (LEAN) {
-                    glds16_hidden(wsrc[0] + woff[j], lds0 + bo + XB + (wrow0 + j * 32) * 128);
-                } else {
-                    glds16_hidden(wsrc[j], lds0 + bo + XB + (wrow0 + j * 32) * 128);
-                    wsrc[j] += wkbytes;
-                }
+                glds16_hidden(wsrc[j], lds0 + bo + XB + (wrow0 + j * 32) * 128);
+                wsrc[j] += wkbytes;
             }
-            if (q == NP - 1) {
-                if (LEAN) wsrc[0] += wkbytes;
-                --w_left;
-            }
+            if (q == NP - 1) --w_left;
         }
     };
 
@@ -579,11 +526,6 @@ __global__ __launch_bounds__(512, 2) void gemm8pb_kernel(const GemmArgs p) {
         if (MODE == 0 && ln_on) {
             gemm_ln_request<MI>(p, m0 + wm * (32 * MI), lrow, ln_pairs);
             gemm_ln_finish<MI>(p, m0 + wm * (32 * MI), lrow, tile_n == 0 && wn == 0 && lhi == 0, ln_pairs, ln_mean, ln_rstd);
-            if (LEAN) {          // parked in LDS over the K loop (every lane that holds row (i, lrow) writes the same pair)
-#pragma unroll
-                for (int i = 0; i < MI; ++i)
-                    *(f32x2*)(smem + 2 * BUF + (wm * (32 * MI) + i * 32 + lrow) * 8) = f32x2{ln_mean[i], ln_rstd[i]};
-            }
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -687,14 +629,7 @@ __global__ __launch_bounds__(512, 2) void gemm8pb_kernel(const GemmArgs p) {
     if (grp == 0) __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_s_barrier();
 
-    if (LEAN && MODE == 0 && ln_on) {
-#pragma unroll
-        for (int i = 0; i < MI; ++i) {
-            const f32x2 mr = *(const f32x2*)(smem + 2 * BUF + (wm * (32 * MI) + i * 32 + lrow) * 8);
-            ln_mean[i] = mr[0]; ln_rstd[i] = mr[1];
-        }
-    }
-    gemm_epilogue<MI, NI, MODE, LORA, NW, WN>(p, smem, acc, accl, ln_mean, ln_rstd, ln_on, tile_m, tile_n, ks_id, wave, wm, wn);
+    gemm_epilogue<MI, NI, MODE, LORA, NW, WN, 0>(p, smem, acc, accl, ln_mean, ln_rstd, ln_on, tile_m, tile_n, ks_id, wave, wm, wn);
 }
 
 }  // namespace
@@ -712,8 +647,6 @@ int launch_gemm8p(const GemmArgs& a, int mode, int ni_b, hipStream_t s) {
     if (ni_b == 0) {
         if (mode == 0) hipLaunchKernelGGL((gemm8p_kernel<0, false>), dim3(grid), dim3(512), 0, s, a);
         else hipLaunchKernelGGL((gemm8p_kernel<1, false>), dim3(grid), dim3(512), 0, s, a);
-    } else if (ni_b == 25) {           // 256 x 320 (dense, M % 256 == 0, packed W: checked by slh_gemm)
-        hipLaunchKernelGGL((gemm8pb_kernel<2, 5, 0, false>), dim3(grid), dim3(512), 0, s, a);
     } else if (ni_b == 3) { SLH_LAUNCH_B(3); }
     else if (ni_b == 4) { SLH_LAUNCH_B(4); }
     else { SLH_LAUNCH_B(5); }

@@ -131,7 +131,9 @@ constexpr int gemm_epilogue_lds(int MI, int NI, int NW, int WN, bool LORA) {
 //   acc[i][j][r] = C[m = m0 + wm*32*MI + i*32 + lrow][n = n0 + wn*32*NI + j*32 + (r&3) + 8*(r>>2) + 4*lhi]
 // (MFMA operand roles swapped: W rows feed the A operand, activation rows the B operand).  Must be entered by all waves of the
 // workgroup with the operand stages in `smem` no longer in use by the K loop's LDS-DMA (they are recycled as staging patches).
-template <int MI, int NI, int MODE, bool LORA, int NW, int WN>
+// FEAT: optional forms a K loop's tiles can take - 1 the head-transposed V store (vt_out), 2 the 32 | 32 GEGLU forms (geglu = 1, 2),
+// 4 the LayerNorm chunk statistics (ln_out); compiled out where slh_gemm never routes them (registers and code of the odd-NI tiles)
+template <int MI, int NI, int MODE, bool LORA, int NW, int WN, int FEAT = 7>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, char* smem, f32x16 (&acc)[MI][NI], f32x16 (&accl)[MI],
                                               const float (&ln_mean)[MI], const float (&ln_rstd)[MI], const bool ln_on,
                                               const int tile_m, const int tile_n, const int ks_id, const int wave, const int wm,
@@ -287,7 +289,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, char* smem, f32
         __syncthreads();                       // every wave is done reading the operand stages being reused below
         if (tid < BN) { sCol[tid] = c0; sCol[BN + tid] = c1; sCol[2 * BN + tid] = c2; sCol[3 * BN + tid] = c3; }
     }
-    if (p.geglu == 2) {
+    if ((FEAT & 2) && p.geglu == 2) {
         // Backward of GEGLU fused into the backward-data product of the Linear behind it (ff.net.2): the accumulators are
         // d(ff) - rounded to bf16 as the unfused path stores it - and leave as d(proj) in proj's blocked column order, computed
         // from the forward's pre-activation (slh_elementwise GEGLU_BWD arithmetic, one launch and one HBM round trip of
@@ -372,7 +374,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, char* smem, f32
         }
         return;
     }
-    if (p.geglu) {
+    if ((FEAT & 2) && p.geglu) {
         // GEGLU: W rows are stored in 64-row blocks [32 value rows | 32 gate rows]; NI is 2 here, so
         // sub-tile j=0 holds the values and j=1 the gates of the same 32 output columns.
         __syncthreads();
@@ -478,7 +480,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, char* smem, f32
     }
     const bool have_t = (LORA || p.lora_t != nullptr) && !mfma_up;      // the per-element forms below
     // wave-uniform: this wave's columns belong to the V block that slh_attn_fwd wants head-transposed
-    const bool to_vt = p.vt != nullptr && ncol0 >= p.vt_col0;
+    const bool to_vt = (FEAT & 1) && p.vt != nullptr && ncol0 >= p.vt_col0;
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
         const int mbase = m0 + wm * (32 * MI) + i * 32;
@@ -588,7 +590,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, char* smem, f32
                 bf16x4 o;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) o[e] = (__bf16)v[e];
-                if (p.ln_out) {                 // statistics of the stored (rounded) values, shifted by the lane's first one
+                if ((FEAT & 4) && p.ln_out) {   // statistics of the stored (rounded) values, shifted by the lane's first one
                     if (j == 0 && q == 0) { ln_k = (float)o[0]; ln_sum = 0.f; ln_sq = 0.f; }
 #pragma unroll
                     for (int e = 0; e < 4; ++e) { const float dlt = (float)o[e] - ln_k; ln_sum += dlt; ln_sq += dlt * dlt; }
@@ -608,7 +610,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, char* smem, f32
                 *(bf16x4*)(sE + lrow * (S * 16) + slot * 16 + ((lhi ^ hb) << 3)) = o;
             }
         }
-        if (NI == 2 && p.ln_out) {
+        if ((FEAT & 4) && NI == 2 && p.ln_out) {
             // LayerNorm statistics of this row's 64 columns (producer side of the folded LayerNorm): the lane holds 32 of
             // them, its partner lane^32 the other 32; (mean, M2) from sums shifted by a sample of the row (no cancellation), merged (Chan)
             const float dm = ln_sum * (1.f / (16 * NI));
@@ -675,6 +677,6 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, char* smem, f32
 }
 
 // gemm8p.hip: the 256 x 256 ping-pong K loop (slh_gemm_desc.tile code 0x8xxx)
-int launch_gemm8p(const GemmArgs& a, int mode, int ni_b, hipStream_t s);   // ni_b: 0 = 256 x 256, 3..5 = 128 x 64*ni_b, 25 = 256 x 320
+int launch_gemm8p(const GemmArgs& a, int mode, int ni_b, hipStream_t s);   // ni_b: 0 = 256 x 256, 3..5 = 128 x 64*ni_b
 
 }  // namespace slh_gemm_detail

@@ -38,8 +38,7 @@ def tile_ok(d, tile: int) -> bool:
     if wm == 8:                                   # ping-pong K loops (csrc/gemm8p.hip)
         if (mi, ni) == (4, 2):                    # 256 x 256: no fused adapter
             return not d.lora_down and d.geglu in (0, 1, 2, 3)
-        if not ((mi == 1 and 3 <= ni <= 5) or
-                (mi == 2 and ni == 5 and not d.lora_down and d.mode == 0 and d.M % 256 == 0 and d.w_layout == 1)):
+        if mi != 1 or ni < 3 or ni > 5:
             return False
         if d.geglu in (1, 2) or d.ln_out or d.vt_out:     # 32 | 32 GEGLU blocks, chunk statistics and the V^T store assume NI = 2
             return False

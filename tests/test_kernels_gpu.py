@@ -239,77 +239,6 @@ def test_gemm_geglu(dev):
     report("geglu_bwd", dpre, _perm_cols(pr.grad), 1.5e-2)
 
 
-def test_gemm_tile_256x320(dev):
-    """0x8025: the 256 x 320 ping-pong tile (one running pointer per operand + wave-uniform offsets, LayerNorm statistics parked in
-    LDS): dense products with M % 256 == 0 and tile-packed weights only - plain + bias + residual, two concatenated sources,
-    N not a multiple of the tile, K slices (split-K), GEGLU 16 | 16 with the LayerNorm fold; everything else is refused."""
-    from sliders_amd.weights import _geglu_perm16, fold_layernorm, pack_gemm_w
-    torch.manual_seed(77)
-    M, N, K = 512, 896, 640
-    x = bf(torch.randn(M, K, device=dev))
-    w = bf(torch.randn(N, K, device=dev) / math.sqrt(K))
-    b = bf(torch.randn(N, device=dev))
-    res = bf(torch.randn(M, N, device=dev))
-    c = torch.zeros(M, N, device=dev, dtype=torch.bfloat16)
-    d = lib.GemmDesc(a0=p(x), w=p(pack_gemm_w(w)), bias=p(b), residual=p(res), c=p(c), lda0=K, ca0=K, mode=0, stride=1, ldw=0, M=M,
-                     N=N, K=K, ld_res=N, ldc=N, rows_per_sample=M, tile=0x8025, w_layout=1)
-    lib.call(lib.OP_GEMM, d, stream())
-    torch.cuda.synchronize()
-    ref = x.float() @ w.float().t() + b.float() + res.float()
-    report("gemm 256x320 dense", c, ref, TOL)
-    # two sources (the second a column slice of a wider tensor)
-    x0, x1big = x[:, :384].contiguous(), bf(torch.randn(M, 512, device=dev))
-    x1 = x1big[:, 256:]
-    c.zero_()
-    d = lib.GemmDesc(a0=p(x0), a1=x1.data_ptr(), w=p(pack_gemm_w(w)), c=p(c), lda0=384, lda1=512, ca0=384, ca1=256, mode=0, stride=1,
-                     ldw=0, M=M, N=N, K=K, ldc=N, rows_per_sample=M, tile=0x8025, w_layout=1)
-    lib.call(lib.OP_GEMM, d, stream())
-    torch.cuda.synchronize()
-    report("gemm 256x320 two sources", c, torch.cat([x0.float(), x1.float()], 1) @ w.float().t(), TOL)
-    # split-K (slabs within the workspace contract: N = 1280 is 4 whole tiles)
-    N2 = 1280
-    w2 = bf(torch.randn(N2, K, device=dev) / math.sqrt(K))
-    c2 = torch.zeros(M, N2, device=dev, dtype=torch.bfloat16)
-    ws = torch.full((2, 512, 1280), float("nan"), device=dev)
-    tickets = torch.zeros(64, device=dev, dtype=torch.int64)
-    d = lib.GemmDesc(a0=p(x), w=p(pack_gemm_w(w2)), c=p(c2), lda0=K, ca0=K, mode=0, stride=1, ldw=0, M=M, N=N2, K=K, ldc=N2,
-                     rows_per_sample=M, tile=0x28025, w_layout=1, splitk_c32=p(ws), splitk_slabs=2, splitk_ticket=p(tickets))
-    lib.call(lib.OP_GEMM, d, stream())
-    torch.cuda.synchronize()
-    report("gemm 256x320 split-K", c2, x.float() @ w2.float().t(), TOL)
-    assert int(tickets.abs().sum()) == 0
-    # GEGLU 16 | 16 + folded LayerNorm (ff.net.0.proj of the no-grad passes)
-    n_out = N // 2
-    gamma, beta = bf(torch.randn(K, device=dev) * 0.5 + 1.0), bf(torch.randn(K, device=dev) * 0.3)
-    hc = x.float().view(M, K // 64, 64).double()
-    mean_c = hc.mean(-1)
-    chunks = torch.stack([mean_c, ((hc - mean_c[..., None]) ** 2).sum(-1)], -1).permute(1, 0, 2).contiguous().float()
-    ln = bf(F.layer_norm(x.float(), (K,), gamma.float(), beta.float(), 1e-5))
-    wf, sv, bp = fold_layernorm(w, b, gamma, beta)
-    wf, sv, bp = _geglu_perm16(wf), _geglu_perm16(sv).contiguous(), _geglu_perm16(bp).contiguous()
-    proj = bf(ln.float() @ w.float().t() + b.float()).float()
-    refg = proj[:, :n_out] * bf(F.gelu(proj[:, n_out:])).float()
-    cg = torch.zeros(M, n_out, device=dev, dtype=torch.bfloat16)
-    mr = torch.full((M, 2), float("nan"), device=dev)
-    d = lib.GemmDesc(a0=p(x), w=p(pack_gemm_w(wf)), c=p(cg), lda0=K, ca0=K, mode=0, stride=1, ldw=0, M=M, N=N, K=K, ldc=n_out, geglu=3,
-                     rows_per_sample=M, tile=0x8025, w_layout=1, ln_in=p(chunks), ln_in_chunks=K // 64, ln_s=p(sv), ln_b=p(bp),
-                     ln_eps=1e-5, ln_mr_out=p(mr))
-    lib.call(lib.OP_GEMM, d, stream())
-    torch.cuda.synchronize()
-    report("gemm 256x320 geglu16 + ln fold", cg, refg, TOL)
-    xd = x.double()
-    assert float((mr[:, 0].double() - xd.mean(-1)).abs().max()) < 1e-5
-    assert float((mr[:, 1].double() * torch.sqrt(xd.var(-1, unbiased=False) + 1e-5) - 1).abs().max()) < 1e-4
-    # refused: rows not a multiple of 256, row-major weights, a fused adapter
-    for kw, msg in ((dict(M=300), "256 x 320"), (dict(w_layout=0, ldw=K), "256 x 320")):
-        dd = lib.GemmDesc(a0=p(x), w=p(pack_gemm_w(w)), c=p(c), lda0=K, ca0=K, mode=0, stride=1, ldw=0, M=M, N=N, K=K, ldc=N,
-                          rows_per_sample=M, tile=0x8025, w_layout=1)
-        for k, v in kw.items():
-            setattr(dd, k, v)
-        with pytest.raises(lib.SlidersHipError, match=msg):
-            lib.call(lib.OP_GEMM, dd, stream())
-
-
 @pytest.mark.parametrize("tile", [0x8015, 0x8014, 0x8013, 0x8042, 0x4412, 0x22])
 def test_gemm_geglu_16_blocks(dev, tile):
     """slh_gemm_desc.geglu = 3: GEGLU with the weight rows in 32-row blocks [16 value | 16 gate] (weights._geglu_perm16) - the
