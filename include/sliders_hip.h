@@ -174,24 +174,25 @@ int slh_gemv(const slh_gemv_desc* d, slh_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * GroupNorm (+SiLU) on pixel-major images; x may be a two-source channel concat.
- * stats: per (sample, group) sum / sum-of-squares accumulated with atomics into stats[b][G][2] (fp32,
- * zeroed by the caller).  apply: y = act((x-mean)*rstd*gamma+beta).
+ * slh_gn_stats leaves (sum, sum of squares) pairs per cluster of row blocks; slh_gn_apply (same descriptor, next on the
+ * stream) adds a sample's cluster pairs in index order in every workgroup's prologue, writes stats[b][G] = (mean, rstd) and
+ * y = act((x-mean)*rstd*gamma+beta).  No fp32 atomics anywhere: bit-reproducible.
  * diffusers ResnetBlock2D.norm1/norm2 (+nonlinearity), Transformer2DModel.norm, conv_norm_out.
  * ---------------------------------------------------------------------------------------------- */
 typedef struct slh_gn_desc {
     const void* x0; const void* x1;
     const void* gamma; const void* beta; /* [C] bf16 */
-    float* stats;            /* [batch][groups][2] fp32: (mean, rstd), written by slh_gn_stats */
+    float* stats;            /* [batch][groups][2] fp32: (mean, rstd), written by slh_gn_apply (and slh_gn_fused) */
     void* y;                 /* [batch*hw][ldy] bf16 */
     int32_t ldx0, ldx1, c0, c1;
     int32_t batch, hw, groups, ldy;
     float eps;
     int32_t act;             /* 0 none, 1 SiLU */
-    /* slh_gn_stats only.  The reduction is done in a fixed order (bit-reproducible, no fp32 atomics): every workgroup
-     * publishes one (sum, sum of squares) pair per group and the last one to arrive combines them in index order. */
-    /* with R = slh_gn_row_blocks(c0+c1, hw, groups) workgroups per sample and L = slh_gn_clusters(R) clusters of them
-     * (two-level combine: the serial tail behind the last workgroup stays two round trips at any tensor size): */
-    float* partial;          /* [batch][R + L][groups][2] fp32 scratch, any contents */
+    /* The statistics are reduced in a fixed order: every workgroup of slh_gn_stats (one row block) writes one shifted (sum, sum of
+     * squares) pair per group; the LAST workgroup of a cluster of 16 row blocks to arrive (one ticket level) adds the cluster's
+     * pairs in row-block order and leaves the cluster pair; slh_gn_apply adds the cluster pairs (double accumulation).
+     * With R = slh_gn_row_blocks(c0+c1, hw, groups) and L = slh_gn_clusters(R): */
+    float* partial;          /* [batch][R + L][groups][2] fp32 scratch, any contents; must stay untouched between the two launches */
     uint32_t* ticket;        /* [batch][1 + L] arrival counters, ZERO before the launch (left zero by it) */
 } slh_gn_desc;
 int slh_gn_stats(const slh_gn_desc* d, slh_stream_t stream);
@@ -534,6 +535,8 @@ enum {
     SLH_OP_VAE_CONV_IN = 27, SLH_OP_VAE_MOMENTS = 28, SLH_OP_VAE_SAMPLE = 29, SLH_OP_VAE_POST_QUANT = 30, SLH_OP_LION = 31,
     SLH_OP_WGRAD_BATCH = 32, SLH_OP_TRANSPOSE_BATCH = 33, SLH_OP_GATHER16 = 34, SLH_OP_GN_FUSED = 35
 };
+/* SLH_OP_MEMSET: byte fill by a kernel of this library (not hipMemsetAsync: a captured memset node is a runtime blit whose
+ * replays were observed to go wrong on the legacy default stream - see the executor's comment) */
 typedef struct slh_memset_desc { void* ptr; int64_t nbytes; int32_t value; int32_t pad; } slh_memset_desc;
 int slh_run_program(const void* program, int64_t nbytes, slh_stream_t stream);
 /* hipGraph replay of a command buffer: capture records the launches slh_run_program would issue (on a private stream;

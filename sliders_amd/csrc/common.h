@@ -184,7 +184,7 @@ __device__ __forceinline__ void gn_combine_partials(const float* partial, int co
 //   part   : [row_blocks + nclusters][groups][2]   level-1 pairs, then level-2 pairs
 //   ticket : [1 + nclusters]                       ticket[0] = level 2, ticket[1 + c] = cluster c
 // Returns true in the threads t = g * lpg (g < groups) of the ONE workgroup that ends up with the sample's totals.
-constexpr int GN_CLUSTER = 128;
+constexpr int GN_CLUSTER = 16;
 __device__ __forceinline__ bool gn_two_level_reduce(float* part, unsigned* ticket, int row_blocks, int rb, int groups, int lpg,
                                                     bool owner, float S1, float Q1, int* lds_flag, double& S, double& Q) {
     const int tid = threadIdx.x;

@@ -32,6 +32,11 @@ static GnGeom gn_geom(int c0, int c1, int hw, int groups) {
     return g;
 }
 
+// Forward statistics: one-shot workgroups (all of a workgroup's rows in flight at once: the launch streams at full width) whose
+// pairs meet ONCE, inside clusters of GN_CLUSTER row blocks (the cluster's last arriver adds them in index order and leaves one
+// pair per group); the few cluster pairs of a sample (<= ~65) are added - again in index order - by every workgroup of
+// slh_gn_apply in its prologue, which also leaves (mean, rstd) in d.stats.  Round 3 combined the cluster pairs under a second
+// ticket level inside the statistics launch: that serial tail (publish - ticket - dependent loads) was ~1/3 of the launch.
 __device__ __forceinline__ const __bf16* gn_src(const slh_gn_desc& d, long row, int c) {
     return c < d.c0 ? (const __bf16*)d.x0 + row * d.ldx0 + c : (const __bf16*)d.x1 + row * d.ldx1 + (c - d.c0);
 }
@@ -79,22 +84,60 @@ __global__ void gn_stats_kernel(const slh_gn_desc d, int nchunk, int rpi, int ro
     }
     float S, Q;
     const bool owner = gn_block_reduce<8>(gn_lds, C, cg, d.groups, rpi, lpg, chunk, rl, s, q, S, Q);
+    // level 1 only: the cluster's last arriver leaves the cluster's pair at part[row_blocks + cluster] (plain store: the next
+    // kernel on the stream reads it)
     const int ncl = (row_blocks + GN_CLUSTER - 1) / GN_CLUSTER;
-    double Sd, Qd;
-    const bool fin = gn_two_level_reduce(d.partial + (long)b * (row_blocks + ncl) * d.groups * 2, d.ticket + (long)b * (1 + ncl),
-                                         row_blocks, blockIdx.x, d.groups, lpg, owner, S, Q, (int*)(gn_lds + 2 * rpi * C), Sd, Qd);
+    float* part = d.partial + (long)b * (row_blocks + ncl) * d.groups * 2;
     const int g = tid / lpg;
-    if (fin) {
-        const double n = (double)d.hw * (double)cg;
-        const double k = (double)(float)*gn_src(d, (long)b * d.hw, g * cg);
-        const double m = Sd / n;
-        const double var = fmax(Qd / n - m * m, 0.0);
-        d.stats[((long)b * d.groups + g) * 2] = (float)(k + m);
-        d.stats[((long)b * d.groups + g) * 2 + 1] = (float)(1.0 / sqrt(var + (double)d.eps));
-    }
+    const int rb = blockIdx.x, cl = rb / GN_CLUSTER;
+    if (owner) store_pair_sc1(part + ((long)rb * d.groups + g) * 2, S, Q);
+    const int first = cl * GN_CLUSTER;
+    const int members = min(GN_CLUSTER, row_blocks - first);
+    if (!last_arriver(d.ticket + (long)b * (1 + ncl) + 1 + cl, (unsigned)members, (int*)(gn_lds + 2 * rpi * C))) return;
+    double Sd, Qd;
+    gn_combine_partials(part + (long)first * d.groups * 2, members, d.groups, lpg, Sd, Qd);
+    if (g < d.groups && (tid & (lpg - 1)) == 0)
+        *(f32x2*)(part + ((long)(row_blocks + cl) * d.groups + g) * 2) = f32x2{(float)Sd, (float)Qd};
 }
 
-__global__ void gn_apply_kernel(const slh_gn_desc d, int nchunk, int rpi, int rows_per_block, int cg) {
+// (mean, rstd) of every group of sample b from the `srb` cluster pairs slh_gn_stats left at `part`, in index order (double
+// accumulation, `lpg` lanes per group each taking every lpg-th pair, then a fixed shuffle tree): identical in every workgroup.
+// Ends with the pairs in st[0 .. groups) (mean) and st[64 ..) (rstd) behind a __syncthreads().
+__device__ __forceinline__ void gn_stats_from_partials(const slh_gn_desc& d, int b, const float* part, int srb, int cg, int lpg, float* st) {
+    const int tid = threadIdx.x;
+    const int g = tid / lpg, j = tid & (lpg - 1);
+    double a = 0.0, q = 0.0;
+    if (g < d.groups) {
+        constexpr int U = 16;
+        for (int i0 = j; i0 < srb; i0 += U * lpg) {
+            f32x2 v[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int i = i0 + u * lpg;
+                v[u] = *(const f32x2*)(part + ((long)(i < srb ? i : 0) * d.groups + g) * 2);
+                if (i >= srb) v[u] = f32x2{0.f, 0.f};
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) { a += (double)v[u][0]; q += (double)v[u][1]; }
+        }
+    }
+    for (int o = lpg >> 1; o > 0; o >>= 1) {
+        a += __shfl_xor(a, o, 64);
+        q += __shfl_xor(q, o, 64);
+    }
+    if (g < d.groups && j == 0) {
+        const double n = (double)d.hw * (double)cg;
+        const double k = (double)(float)*gn_src(d, (long)b * d.hw, g * cg);
+        const double m = a / n;
+        const double var = fmax(q / n - m * m, 0.0);
+        st[g] = (float)(k + m);
+        st[64 + g] = (float)(1.0 / sqrt(var + (double)d.eps));
+    }
+    __syncthreads();
+}
+
+__global__ void gn_apply_kernel(const slh_gn_desc d, int nchunk, int rpi, int rows_per_block, int cg, int lpg, int row_blocks) {
+    __shared__ float st[128];
     const int tid = threadIdx.x;
     const int chunk = tid % nchunk, rl = tid / nchunk;
     const int c = chunk * 8;
@@ -104,19 +147,24 @@ __global__ void gn_apply_kernel(const slh_gn_desc d, int nchunk, int rpi, int ro
     float a[8], sft[8];
     const bf16x8 gm = *(const bf16x8*)((const __bf16*)d.gamma + c);
     const bf16x8 bt = *(const bf16x8*)((const __bf16*)d.beta + c);
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        const int g = (c + e) / cg;
-        const float mean = d.stats[((long)b * d.groups + g) * 2];
-        const float rstd = d.stats[((long)b * d.groups + g) * 2 + 1];
-        a[e] = rstd * (float)gm[e];
-        sft[e] = (float)bt[e] - mean * a[e];
-    }
+    // this workgroup's rows are requested before the statistics are combined (their latency hides the combine's)
     bf16x8 v[GN_ITERS];
 #pragma unroll
     for (int it = 0; it < GN_ITERS; ++it) {
         const int r = min(r0 + rl + it * rpi, d.hw - 1);       // unconditional (see gn_stats_kernel)
         v[it] = *(const bf16x8*)gn_src(d, (long)b * d.hw + r, c);
+    }
+    const int ncl = (row_blocks + GN_CLUSTER - 1) / GN_CLUSTER;
+    gn_stats_from_partials(d, b, d.partial + ((long)b * (row_blocks + ncl) + row_blocks) * d.groups * 2, ncl, cg, lpg, st);
+    if (blockIdx.x == 0 && tid < d.groups)                     // for the backward (slh_gn_bwd_*) and anyone else who reads d.stats
+        *(f32x2*)(d.stats + ((long)b * d.groups + tid) * 2) = f32x2{st[tid], st[64 + tid]};
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int g = (c + e) / cg;
+        const float mean = st[g];
+        const float rstd = st[64 + g];
+        a[e] = rstd * (float)gm[e];
+        sft[e] = (float)bt[e] - mean * a[e];
     }
 #pragma unroll
     for (int it = 0; it < GN_ITERS; ++it) {
@@ -510,11 +558,12 @@ extern "C" int slh_gn_fused(const slh_gn_desc* d, slh_stream_t stream) {
 
 extern "C" int slh_gn_apply(const slh_gn_desc* d, slh_stream_t stream) {
     SLH_CHECK(d && d->x0 && d->stats && d->y && d->gamma && d->beta, "slh_gn_apply: null pointer");
+    SLH_CHECK(d->partial, "slh_gn_apply: needs the partial sums slh_gn_stats left (same descriptor)");
     if (gn_check("slh_gn_apply", d->c0, d->c1, d->groups, d->ldx0, d->ldx1, d->x1)) return -1;
     SLH_CHECK(d->ldy % 8 == 0, "slh_gn_apply: ldy");
     const GnGeom g = gn_geom(d->c0, d->c1, d->hw, d->groups);
     hipLaunchKernelGGL(gn_apply_kernel, dim3(g.row_blocks, d->batch), dim3(g.threads), 0, (hipStream_t)stream, *d,
-                       g.nchunk, g.rpi, g.rows_per_block, g.cg);
+                       g.nchunk, g.rpi, g.rows_per_block, g.cg, g.lpg, g.row_blocks);
     SLH_LAUNCH_CHECK("slh_gn_apply");
     return 0;
 }

@@ -11,6 +11,29 @@
 void slh_set_error(const char* fmt, ...);
 
 namespace {
+// SLH_OP_MEMSET is a kernel of this library, not hipMemsetAsync: inside a captured hipGraph the runtime's memset node is a
+// blit whose arguments live in the launch stream's blit ring, and replays on the legacy default stream were observed to zero
+// the wrong bytes once other blits (torch fill_ / copies) had gone through that ring in between (round-4 notes).
+__global__ void fill_kernel(unsigned char* p, unsigned v4, long n, int head) {
+    // [0, head) bytes up to the first 16-byte boundary and the tail: thread 0's; the aligned middle: one uint4 per thread
+    const long i = head + ((long)blockIdx.x * blockDim.x + threadIdx.x) * 16;
+    if (i + 16 <= n) *(uint4*)(p + i) = uint4{v4, v4, v4, v4};
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        for (long j = 0; j < head; ++j) p[j] = (unsigned char)v4;
+        for (long j = head + ((n - head) & ~15L); j < n; ++j) p[j] = (unsigned char)v4;
+    }
+}
+inline int fill_bytes(void* ptr, int value, long n, hipStream_t s) {
+    if (n <= 0) return 0;
+    long head = (long)((16 - ((uintptr_t)ptr & 15)) & 15);
+    if (head > n) head = n;
+    const unsigned b = (unsigned)value & 0xffu, v4 = b * 0x01010101u;
+    const long threads = (n - head) / 16 + 1;
+    fill_kernel<<<dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s>>>((unsigned char*)ptr, v4, n, (int)head);
+    if (hipGetLastError() != hipSuccess) { slh_set_error("slh_run_program: memset launch failed"); return -2; }
+    return 0;
+}
+
 template <typename T>
 inline int run_desc(const unsigned char* p, int32_t nbytes, int (*fn)(const T*, slh_stream_t), slh_stream_t s,
                     const char* name) {
@@ -81,8 +104,7 @@ extern "C" int slh_run_program(const void* program, int64_t nbytes, slh_stream_t
                 if (sz != (int32_t)sizeof(slh_memset_desc)) { slh_set_error("slh_run_program: memset desc size"); return -3; }
                 slh_memset_desc d;
                 memcpy(&d, p, sizeof(d));
-                hipError_t e = hipMemsetAsync(d.ptr, d.value, (size_t)d.nbytes, (hipStream_t)stream);
-                if (e != hipSuccess) { slh_set_error("slh_run_program: memset failed: %s", hipGetErrorString(e)); rc = -2; }
+                rc = fill_bytes(d.ptr, d.value, (long)d.nbytes, (hipStream_t)stream);
                 break;
             }
             default:

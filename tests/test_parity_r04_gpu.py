@@ -178,37 +178,45 @@ def _oracle_with_lora(name, sd, dtype, device="cpu"):
 @pytest.mark.parametrize("name,action", [("tiny_sdxl", "enhance"), ("tiny_sd1", "erase")])
 def test_iteration_against_fp32_and_bf16_arm(dev, name, action):
     k, hw, gs = 3, 16, 4.0
-    cfg, emb, pool, noise, g = _setup(name)
-    store = LoraStore(cfg, rank=4, alpha=1.0, train_method="noxattn", device=dev)
-    for e in store.entries:
-        store.params[e.up_off:e.up_off + e.up_numel] = (torch.randn(e.up_numel, generator=g) * 0.03).to(dev, torch.bfloat16)
-    sd = store.state_dict()
-    eng = UNetEngine(cfg, build_unet(name, seed=0).state_dict(), dev)
-    tr = SliderTrainer(eng, store, hw, hw, lr=2e-4)
-    loss_e = tr.iteration(_pair(emb, pool, dev, action, gs), k, noise.to(dev)).item()
-    torch.cuda.synchronize()
-    den_e, tgt_e, g_e = tr.denoised.float().cpu(), tr.e_tgt.float().cpu(), store.grads.float().cpu()
-    arms = {}
-    for nm, dtype in (("fp32", torch.float32), ("bf16", torch.bfloat16)):
-        net, nw = _oracle_with_lora(name, sd, dtype)
-        den, tgt, loss = _ref_iteration(net, nw, cfg, emb, pool, noise, k, action, gs, dtype, hw)
-        arms[nm] = (den, tgt, loss.item(), _flat_grads(store, nw))
-    d32, t32, l32, g32 = arms["fp32"]
-    dbf, tbf, lbf, gbf = arms["bf16"]
-    res = {}
-    for nm, (den, tgt, loss, gr) in (("engine", (den_e, tgt_e, loss_e, g_e)), ("bf16 arm", (dbf, tbf, lbf, gbf))):
-        res[nm] = (rel_err(den, d32), rel_err(tgt, t32), abs(loss - l32) / l32, 1.0 - F.cosine_similarity(gr, g32, dim=0).item(),
-                   rel_err(gr, g32))
-        print(f"[parity] iteration {name} {nm:8s} vs fp32 loop: denoised rel_l2={res[nm][0]:.3e} target-eps rel_l2={res[nm][1]:.3e} "
-              f"loss rel={res[nm][2]:.3e} grad 1-cos={res[nm][3]:.3e} grad rel_l2={res[nm][4]:.3e}")
-    e, b = res["engine"], res["bf16 arm"]
-    # the engine is at most 1.5 x the reference-precision arm away from exact arithmetic (+ a floor of a few bf16 ulps of the
-    # quantity: single samples of a rounding process, not means) - on every quantity of the iteration
-    assert e[0] <= 1.5 * b[0] + 2e-3, "denoised latents"
-    assert e[1] <= 1.5 * b[1] + 2e-3, "target prediction"
-    assert e[2] <= 1.5 * b[2] + 1.5e-2, "loss"
-    assert e[3] <= 1.5 * b[3] + 5e-3, "gradient direction"
-    assert e[4] <= 1.5 * b[4] + 3e-2, "gradient"
+    seeds = (5, 6, 7, 8)
+    sq = {"engine": [0.0] * 5, "bf16 arm": [0.0] * 5}
+    for seed in seeds:
+        cfg, emb, pool, noise, g = _setup(name, seed=seed)
+        store = LoraStore(cfg, rank=4, alpha=1.0, train_method="noxattn", device=dev)
+        for e in store.entries:
+            store.params[e.up_off:e.up_off + e.up_numel] = (torch.randn(e.up_numel, generator=g) * 0.03).to(dev, torch.bfloat16)
+        sd = store.state_dict()
+        eng = UNetEngine(cfg, build_unet(name, seed=0).state_dict(), dev)
+        tr = SliderTrainer(eng, store, hw, hw, lr=2e-4)
+        loss_e = tr.iteration(_pair(emb, pool, dev, action, gs), k, noise.to(dev)).item()
+        torch.cuda.synchronize()
+        den_e, tgt_e, g_e = tr.denoised.float().cpu(), tr.e_tgt.float().cpu(), store.grads.float().cpu()
+        arms = {}
+        for nm, dtype in (("fp32", torch.float32), ("bf16", torch.bfloat16)):
+            net, nw = _oracle_with_lora(name, sd, dtype)
+            den, tgt, loss = _ref_iteration(net, nw, cfg, emb, pool, noise, k, action, gs, dtype, hw)
+            arms[nm] = (den, tgt, loss.item(), _flat_grads(store, nw))
+        d32, t32, l32, g32 = arms["fp32"]
+        dbf, tbf, lbf, gbf = arms["bf16"]
+        for nm, (den, tgt, loss, gr) in (("engine", (den_e, tgt_e, loss_e, g_e)), ("bf16 arm", (dbf, tbf, lbf, gbf))):
+            r = (rel_err(den, d32), rel_err(tgt, t32), abs(loss - l32) / l32, 1.0 - F.cosine_similarity(gr, g32, dim=0).item(),
+                 rel_err(gr, g32))
+            print(f"[parity] iteration {name} seed {seed} {nm:8s} vs fp32 loop: denoised rel_l2={r[0]:.3e} target-eps rel_l2={r[1]:.3e} "
+                  f"loss rel={r[2]:.3e} grad 1-cos={r[3]:.3e} grad rel_l2={r[4]:.3e}")
+            for i in range(5):
+                sq[nm][i] += r[i] * r[i] / len(seeds)
+    e = [v ** 0.5 for v in sq["engine"]]
+    b = [v ** 0.5 for v in sq["bf16 arm"]]
+    print(f"[parity] iteration {name} RMS over {len(seeds)} seeds, engine / bf16 arm: denoised {e[0]:.3e} / {b[0]:.3e}, target eps "
+          f"{e[1]:.3e} / {b[1]:.3e}, loss {e[2]:.3e} / {b[2]:.3e}, grad 1-cos {e[3]:.3e} / {b[3]:.3e}, grad rel_l2 {e[4]:.3e} / {b[4]:.3e}")
+    # the engine is at most 1.5 x the reference-precision arm away from exact arithmetic on every quantity of the iteration, in the
+    # RMS over the seeds (the loss is a difference of four predictions that each carry ~1e-2 of bf16 noise: a single sample of its
+    # error scatters by a factor of several in BOTH arms - one draw must not decide a test)
+    assert e[0] <= 1.5 * b[0] + 1e-3, "denoised latents"
+    assert e[1] <= 1.5 * b[1] + 1e-3, "target prediction"
+    assert e[2] <= 1.5 * b[2] + 5e-3, "loss"
+    assert e[3] <= 1.5 * b[3] + 2e-3, "gradient direction"
+    assert e[4] <= 1.5 * b[4] + 1e-2, "gradient"
 
 
 # ----------------------------------------------------------------------------------------------------------------------------------

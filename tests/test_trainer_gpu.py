@@ -129,6 +129,41 @@ def test_iteration_is_bit_reproducible_including_gradients(dev, name):
     assert torch.equal(p0, p1)
 
 
+@pytest.mark.parametrize("k", [5, None])
+def test_iterations_through_graphs_equal_plain_launches(dev, k, monkeypatch):
+    """Six iterations replayed as hipGraphs (every once-per-iteration program is captured at the third and REPLAYED from the
+    fourth) against the same six as plain launches: loss, four predictions, gradients and parameters equal bit for bit, with torch
+    temporaries and a device-to-host copy between iterations (what a training script does around the step: logging, lr schedule).
+    Round-4 regression: the programs' leading zero-fill used to be a hipMemsetAsync node, and its replays on the legacy default
+    stream stopped zeroing the right bytes once other blits (torch fill_ / copies) had gone through the same stream in between -
+    from the second replay on the frozen predictions drifted and the target prediction / gradients were garbage
+    (profiles/r04_graph_memset_node.md).  SLH_OP_MEMSET is a kernel of the library now."""
+    from sliders_amd import lib
+
+    def run(graphs):
+        monkeypatch.setattr(lib, "_GRAPHS_ON", graphs)
+        cfg, store, emb, pool, noise = _setup(dev, "tiny_sdxl")
+        eng = UNetEngine(cfg, build_unet("tiny_sdxl", seed=0).state_dict(), dev)
+        tr = SliderTrainer(eng, store, 16, 16, lr=2e-4)
+        pair = _pair(emb, pool, dev)
+        out = []
+        for it in range(6):
+            loss = tr.iteration(pair, k or 2 + it, noise.to(dev)).item()
+            logged = (store.grads * tr.grad_scale).to(torch.bfloat16).cpu()        # temporaries + a blit on the same stream
+            out.append((loss, tr.e_pos.clone(), tr.e_neu.clone(), tr.e_unc.clone(), tr.e_tgt.clone(), store.grads.clone(),
+                        store.params.clone()))
+            assert torch.isfinite(logged.float()).all()
+        p_tr = eng.plan(2 * tr.bs, 16, 16, "train")
+        assert (p_tr.prog._graphs is not None) == graphs and (p_tr.backward.prog._graphs is not None) == graphs
+        return out
+
+    plain, graph = run(False), run(True)
+    for it, (a, b) in enumerate(zip(plain, graph)):
+        assert a[0] == b[0], f"iteration {it}: loss {b[0]} through graphs, {a[0]} plain"
+        for name, x, y in zip(("positive", "neutral", "uncond", "target", "grads", "params"), a[1:], b[1:]):
+            assert torch.equal(x, y), f"iteration {it}: {name} differs between graph replay and plain launches"
+
+
 def test_dedup_frozen_equals_three_cfg_pairs(dev):
     """Same engine, same denoised latents, same timestep: the one-pass [uncond, positive, neutral] evaluation
     against the reference's three CFG-pair passes.  Every reduction of the pass runs in a fixed order (round 3), rows of different
