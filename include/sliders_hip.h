@@ -78,7 +78,15 @@ typedef struct slh_gemm_desc {
                                 workgroup, block tile (32*MI*WM) x (64*NI); stages 0|2: double buffer, 3|4: deep LDS ring;
                                 S: split-K factor (0|1 none), needs splitk_c32.
                                 WM = 8: ping-pong K loops, one 8-wave workgroup per CU (csrc/gemm8p.hip): 0x8042 = 256 x 256
-                                (no fused adapter), 0x801<NI> = 128 x 64*NI, NI = 3..5 (geglu 0 | 3 only, no ln_out / vt_out) */
+                                (no fused adapter), 0x801<NI> = 128 x 64*NI, NI = 3..5 (geglu 0 | 3 only, no ln_out / vt_out).
+                                Bit 20 (0x104412 only): stream-K - one workgroup per CU, each walking an equal run of the
+                                (tile, K tile) sequence; partial tiles go through splitk_c32 (at least ceil(#CUs * 64 KB /
+                                slab bytes) slabs) and are added in K order by the workgroup that holds a tile's first K
+                                tile (splitk_ticket = one zeroed 64-bit flag per workgroup); dense, no adapter / GEGLU /
+                                LayerNorm fold / vt_out; falls back to the plain launch when a run would be < 4 K tiles.
+                                Bit-reproducible.  Measured slower than the plain launch on this chip (the workgroups no
+                                longer walk K in lockstep, so operand slices are not shared through L2): kept as a
+                                tested option, never chosen by the tuned tables (profiles/r04_streamk.txt) */
     int32_t lora_rank;       /* 0 = 4.  With lora_up_rmajor: total rank 4 | 8 | 12 (T has that many columns) */
     int32_t lora_up_rmajor;  /* 1: lora_up is [rank][N] (= lora_down as stored): backward-data LoRA term */
     int32_t w_layout;        /* 0: w is [N][ldw].  1: frozen weights repacked once at load time into the order the kernel

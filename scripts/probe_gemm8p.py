@@ -61,6 +61,12 @@ for shp in [v for v in a.shapes.split(",") if v]:
         descs = [lib.GemmDesc(a0=x.data_ptr(), w=wp.data_ptr(), bias=bias.data_ptr(), residual=res.data_ptr(), c=c.data_ptr(),
                               lda0=K, ca0=K, mode=0, stride=1, ldw=0, M=M, N=N, K=K, ld_res=N, ldc=N, rows_per_sample=M, tile=tile,
                               w_layout=1) for wp in wps]
+        if tile >> 16:     # split-K (bits 16-19) / stream-K (bits 20-21): slab workspace + zeroed tickets
+            nsl = 8
+            ws = torch.empty(nsl * ((M + 255) // 256 * 256) * ((N + 127) // 128 * 128), device=dev, dtype=torch.float32)
+            tk = torch.zeros(4096, device=dev, dtype=torch.int64)
+            for d in descs:
+                d.splitk_c32, d.splitk_ticket, d.splitk_slabs = ws.data_ptr(), tk.data_ptr(), nsl
         err = ""
         if a.check:
             c.zero_()

@@ -54,7 +54,7 @@ __device__ __forceinline__ f32x16 mfma_slot(const bf16x8 a, const bf16x8 b, f32x
 #endif
 }
 
-template <int MI, int NI, int MODE, int STAGES, bool LORA, int WM>
+template <int MI, int NI, int MODE, int STAGES, bool LORA, int WM, bool SK = false>
 __global__ __launch_bounds__(128 * WM, gemm_waves_per_simd(MI, NI, STAGES, LORA, WM)) void gemm_kernel(const GemmArgs p) {
     constexpr int NW = 2 * WM;
     constexpr int BM = 32 * MI * WM;
@@ -76,13 +76,38 @@ __global__ __launch_bounds__(128 * WM, gemm_waves_per_simd(MI, NI, STAGES, LORA,
 #ifdef SLH_GEMM_PROBE
     if (p.probe & 16) return;   // diagnostics: launch + dispatch cost only
 #endif
-    const int tid = threadIdx.x;
+    // stream-K (SK): this workgroup's units [sk_unit, sk_end) of the K-tile sequence, walked segment by segment (gemm_common.h)
+    int sk_slot = 0, sk_unit = 0, sk_end = 0;
+    if (SK) {
+        sk_slot = gemm_remap_bid();
+        sk_unit = sk_slot * p.sk_per;
+        sk_end = min(sk_unit + p.sk_per, p.tiles_m * p.tiles_n * (p.K / BK));
+        if (sk_unit >= sk_end) return;
+    }
+  do {
+    int tid_ = threadIdx.x;
+    // SK: everything derived from the lane id is re-derived per segment - hoisted out of the segment loop and carried across the K
+    // loops and epilogues it costs ~90 registers (256 + scratch against 169)
+    if (SK) asm volatile("" : "+v"(tid_));
+    const int tid = tid_;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
-
     int tile_m, tile_n, ks_id;
-    gemm_map_tile(p, tile_m, tile_n, ks_id);
+    int kt_begin = 0, nk = p.K / BK;
+    if (SK) {
+        const int t = sk_unit / nk;
+        kt_begin = sk_unit - t * nk;
+        nk = min(nk - kt_begin, sk_end - sk_unit);
+        gemm_tile_of(p, t, tile_m, tile_n);
+        ks_id = 0;
+    } else {
+        gemm_map_tile(p, tile_m, tile_n, ks_id);
+        if (p.splitk > 1) {
+            kt_begin = ks_id * p.kper;          // K tiles per slice: computed once, by slh_gemm, which also makes every slice non-empty
+            nk = min(nk, kt_begin + p.kper) - kt_begin;
+        }
+    }
     const int m0 = tile_m * BM, n0 = tile_n * BN;
 
     // ---- per-lane fill geometry --------------------------------------------------------------
@@ -204,11 +229,6 @@ __global__ __launch_bounds__(128 * WM, gemm_waves_per_simd(MI, NI, STAGES, LORA,
         for (int i = 0; i < MI; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r) accl[i][r] = 0.f;
-    }
-    int kt_begin = 0, nk = p.K / BK;
-    if (p.splitk > 1) {
-        kt_begin = ks_id * p.kper;          // K tiles per slice: computed once, by slh_gemm, which also makes every slice non-empty
-        nk = min(nk, kt_begin + p.kper) - kt_begin;
     }
     const int lrow = lane & 31, lhi = lane >> 5;
 
@@ -484,7 +504,19 @@ __global__ __launch_bounds__(128 * WM, gemm_waves_per_simd(MI, NI, STAGES, LORA,
         if (g < nk) body(F_{}, F_{}, F_{});
     }
 
-    gemm_epilogue<MI, NI, MODE, LORA, NW, 2>(p, smem, acc, accl, ln_mean, ln_rstd, ln_on, tile_m, tile_n, ks_id, wave, wm, wn);
+    if (SK) {
+        if (kt_begin > 0) {
+            gemm_sk_publish<MI, NI>(p, sk_slot, gridDim.x, acc, wave, lane, tid);
+        } else {
+            if (nk < p.K / BK) gemm_sk_collect<MI, NI>(p, sk_slot, gridDim.x, p.K / BK - nk, acc, wave, lane, tid);
+            gemm_epilogue<MI, NI, MODE, LORA, NW, 2>(p, smem, acc, accl, ln_mean, ln_rstd, ln_on, tile_m, tile_n, ks_id, wave, wm, wn);
+        }
+        sk_unit += nk;
+        __syncthreads();          // the operand stages (recycled by the epilogue) are free for the next segment's tiles
+    } else {
+        gemm_epilogue<MI, NI, MODE, LORA, NW, 2>(p, smem, acc, accl, ln_mean, ln_rstd, ln_on, tile_m, tile_n, ks_id, wave, wm, wn);
+    }
+  } while (SK && sk_unit < sk_end);
 }
 
 template <int MI, int NI, int MODE, bool LORA, int WM>
@@ -502,6 +534,14 @@ int launch_gemm3(const GemmArgs& a, int stages, hipStream_t s) {
     else
         hipLaunchKernelGGL((gemm_kernel<MI, NI, MODE, 2, LORA, WM>), dim3(grid), dim3(128 * WM), 0, s, a);
     SLH_LAUNCH_CHECK("slh_gemm");
+    return 0;
+}
+
+// stream-K launch (dense 128 x 128 8-wave tile on the 4-slot ring - one workgroup per CU -, no fused adapter): grid workgroups, all
+// resident.  (The double-buffered loop with two workgroups per CU was measured too: slower everywhere and 376 B of scratch.)
+int launch_gemm_sk(const GemmArgs& a, int grid, hipStream_t s) {
+    hipLaunchKernelGGL((gemm_kernel<1, 2, 0, 4, false, 4, true>), dim3(grid), dim3(512), 0, s, a);
+    SLH_LAUNCH_CHECK("slh_gemm (stream-K)");
     return 0;
 }
 
@@ -726,6 +766,18 @@ extern "C" int slh_gemm(const slh_gemm_desc* d, slh_stream_t stream) {
         a.splitk = 1;
     }
     a.store16 = (d->ldc % 8 == 0) && (((uintptr_t)d->c & 15) == 0);
+    a.sk_per = 0;
+    const int sk = (d->tile >> 20) & 1;        // stream-K (tile 0x104412): one workgroup per CU, see gemm_common.h
+    if (sk) {
+        const int st = (d->tile >> 8) & 15;
+        SLH_CHECK(WM == 4 && MI == 1 && NI == 2 && d->mode == 0 && !d->lora_down && a.splitk == 1 && !d->ln_in && !d->ln_out &&
+                      !d->geglu && !d->vt_out,
+                  "slh_gemm: stream-K runs the dense 128 x 128 8-wave ring tile (0x104412) without adapter, split-K, GEGLU, "
+                  "LayerNorm fold or vt_out");
+        SLH_CHECK(st == 4, "slh_gemm: stream-K runs on the 4-slot ring (tile 0x104412)");
+        SLH_CHECK(d->splitk_c32 && d->splitk_ticket && ((uintptr_t)d->splitk_ticket & 7) == 0 && ((uintptr_t)d->splitk_c32 & 15) == 0,
+                  "slh_gemm: stream-K needs the slab workspace splitk_c32 and the (zeroed) flags splitk_ticket");
+    }
     if (WM == 8) {
         const int bm = MI == 1 ? 128 : 256, bn = 64 * NI * (MI == 4 ? 2 : 1);
         a.tiles_m = (d->M + bm - 1) / bm;
@@ -742,6 +794,29 @@ extern "C" int slh_gemm(const slh_gemm_desc* d, slh_stream_t stream) {
     a.group_m = pick_group_m(d, a.tiles_m);
     hipStream_t s = (hipStream_t)stream;
     const int stages = (d->tile >> 8) & 15;   // tile = (WM<<12)|(stages<<8)|(MI<<4)|NI ; stages 0/2 = double buffer
+    if (sk) {
+        static const int ncu = [] {
+            int dev = 0;
+            hipDeviceProp_t prop;
+            if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
+            return prop.multiProcessorCount;
+        }();
+        SLH_CHECK(ncu > 0, "slh_gemm: stream-K could not read the CU count");
+        const long units = (long)a.tiles_m * a.tiles_n * (d->K / 64);
+        int per = (int)((units + (long)ncu * sk - 1) / ((long)ncu * sk));
+        static const char* force_per = getenv("SLIDERS_SK_PER");      // measurement aid: K tiles per workgroup
+        if (force_per && atoi(force_per) > 0) per = atoi(force_per);
+        const int grid = (int)((units + per - 1) / per);
+        // fewer than 4 K tiles per workgroup: every tile would be cut several times - run the plain tile launch
+        SLH_CHECK(grid <= ncu, "slh_gemm: stream-K grid %d exceeds the %d CUs (every workgroup must be resident)", grid, ncu);
+        if (force_per || (per >= 4 && grid > a.tiles_m * a.tiles_n)) {
+            SLH_CHECK((long)grid * (128 * 128 * 4) <= (long)d->splitk_slabs * ((d->M + 255) / 256 * 256L) * ((d->N + 127) / 128 * 128L) * 4,
+                      "slh_gemm: stream-K publishes up to %d partial tiles of 64 KB: splitk_c32 (%d slabs) is too small", grid, d->splitk_slabs);
+            SLH_CHECK(grid <= 4096, "slh_gemm: stream-K flags");
+            a.sk_per = per;
+            return launch_gemm_sk(a, grid, s);
+        }
+    }
     if (WM == 4) {
         if (MI == 2) return launch_gemm<2, 2, 4>(a, d->mode, stages, s);   // 256 x 128, 8 waves
         if (NI == 1) return launch_gemm<1, 1, 4>(a, d->mode, stages, s);   // 128 x 64, 8 waves

@@ -116,6 +116,14 @@ def provision_splitk(plan, d, name: str):
     tiles) per K slice
     (each slice writes its own, the last slice of a tile to arrive adds them in slice order inside the launch - bit-reproducible) and, with a
     fused adapter, two [M][ld_t] slabs per slice for T.  Fixes d.tile for untuned shapes."""
+    if d.tile and (d.tile >> 20) & 1:
+        # stream-K (an opt-in tile, never in the tuned tables): one 64 KB partial tile and one flag per workgroup (= per CU)
+        ncu = torch.cuda.get_device_properties(torch.cuda.current_device()).multi_processor_count if torch.cuda.is_available() else 256
+        slab = ((d.M + 255) // 256 * 256) * ((d.N + 127) // 128 * 128)
+        d.splitk_slabs = (ncu * 128 * 128 + slab - 1) // slab
+        d.splitk_c32 = plan.arena.alloc((d.splitk_slabs, slab), torch.float32, name + ".streamk").ptr
+        d.splitk_ticket = _plan_tickets(plan, ncu)
+        return
     if not splitk_wanted(d):
         return
     if not d.tile and d.M * d.N <= (1 << 20):      # the untuned default only for the small products it was measured on

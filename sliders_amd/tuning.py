@@ -30,6 +30,8 @@ def tile_ok(d, tile: int) -> bool:
     """Can slh_gemm run descriptor d with this tile code?  (The constraints slh_gemm itself checks: used by the tuner to skip
     candidates and by the planner to drop a table entry that no longer fits the launch it is looked up for.)"""
     mi, ni, wm = (tile >> 4) & 15, tile & 15, (tile >> 12) & 15
+    if (tile >> 20) & 1:                          # stream-K: the dense 128 x 128 ring tile, bare or bias / residual epilogue
+        return (tile & 0xFFFFF) == 0x4412 and d.mode == 0 and not (d.lora_down or d.geglu or d.ln_in or d.ln_out or d.vt_out)
     if wm == 8 and (tile >> 16) & 15:             # split-K: the slabs of these tiles must fit the workspace contract
         bm, bn = (256, 256) if mi == 4 else (128 * mi, 64 * ni)
         r = lambda v, q: (v + q - 1) // q * q

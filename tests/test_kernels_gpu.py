@@ -1130,6 +1130,52 @@ def test_gemm_splitk_stress_same_slabs(dev, local):
     assert r.returncode == 0 and "stress ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
+@pytest.mark.parametrize("M,N,K", [(2048, 1280, 5120), (2048, 1280, 1280), (1100, 896, 2560), (3072, 1280, 5120)])
+def test_gemm_streamk(dev, M, N, K):
+    """Stream-K (slh_gemm_desc.tile bit 20, tile 0x104412): one workgroup per CU walks an equal run of the (tile, K tile)
+    sequence; a run that starts in the middle of a tile publishes its partial, the workgroup holding the tile's first K tile adds the
+    published parts in K order and runs the ordinary epilogue (bias + residual here).  Same result as the plain tile up to fp32
+    summation order, bit-reproducible, flags left zero, garbage in the workspace ignored; a workspace that cannot hold one
+    partial per workgroup is refused."""
+    torch.manual_seed(M + K)
+    x = bf(torch.randn(M, K, device=dev))
+    w = bf(torch.randn(N, K, device=dev) / math.sqrt(K))
+    bias = bf(torch.randn(N, device=dev))
+    res = bf(torch.randn(M, N, device=dev))
+    c = torch.zeros(M, N, device=dev, dtype=torch.bfloat16)
+    slab = ((M + 255) // 256 * 256) * ((N + 127) // 128 * 128)
+    ncu = torch.cuda.get_device_properties(0).multi_processor_count
+    S = (ncu * 128 * 128 + slab - 1) // slab
+    ws = torch.full((S, slab), float("nan"), device=dev)
+    flags = torch.zeros(4096, device=dev, dtype=torch.int64)
+    d = lib.GemmDesc(a0=p(x), w=p(w), bias=p(bias), residual=p(res), c=p(c), lda0=K, ca0=K, mode=0, stride=1, ldw=K,
+                     M=M, N=N, K=K, ld_res=N, ldc=N, rows_per_sample=M, tile=0x104412, splitk_c32=p(ws), splitk_slabs=S,
+                     splitk_ticket=p(flags))
+    lib.call(lib.OP_GEMM, d, stream())
+    torch.cuda.synchronize()
+    ref = x.float() @ w.float().t() + bias.float() + res.float()
+    report(f"stream-K {M}x{N}x{K}", c, ref, TOL)
+    assert int(flags.abs().sum()) == 0, "every finisher re-arms the flags it consumed"
+    c0 = c.clone()
+    for _ in range(3):
+        c.zero_()
+        ws.fill_(float("nan"))
+        lib.call(lib.OP_GEMM, d, stream())
+        torch.cuda.synchronize()
+        assert torch.equal(c, c0), "stream-K must be bit-reproducible"
+    # against the plain launch of the same tile: the same products, summed in a different order
+    d.tile = 0x4412
+    c.zero_()
+    lib.call(lib.OP_GEMM, d, stream())
+    torch.cuda.synchronize()
+    assert ((c.float() - c0.float()).norm() / c0.float().norm()).item() < 2e-3
+    d.tile = 0x104412
+    d.splitk_slabs = 0
+    d.splitk_c32 = 0
+    with pytest.raises(lib.SlidersHipError, match="stream-K"):
+        lib.call(lib.OP_GEMM, d, stream())
+
+
 @pytest.mark.parametrize("tile", [0x20412, 0x40421, 0x80422, 0x44412, 0x30011, 0x20022, 0xf0412, 0x28015, 0x38014])
 def test_gemm_splitk(dev, tile):
     """Split-K (slh_gemm_desc.tile bits 16-19): every K slice publishes its partial tile in its own fp32 slab (whatever the
