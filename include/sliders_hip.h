@@ -135,6 +135,18 @@ typedef struct slh_gemm_desc {
     int32_t ld_pre;
     int32_t vt_also_c;       /* with vt_out: 1 = the head-transposed columns are ALSO written row-major into c (training passes
                                 keep V, and the backward dO, in both layouts: no separate transpose launch) */
+    /* Cross-attention fused behind the query projection (diffusers Attention.to_q of attn2 + the xformers call behind it, no-grad
+     * passes, head dim 64): with xa_k the product is Q = a . w^T (bf16-rounded, LayerNorm fold / bias applied first) and c receives
+     *   softmax(Q_h K_h^T * xa_scale) V_h   per (sample, head h = columns [64h, 64h + 64))
+     * for the xa_tk <= 96 keys of the row's sample (text tokens): every wave of the 128 x 128 ring tile (tile 0x4412, required) owns
+     * 32 rows x one head, so scores, softmax and P.V stay in its registers (24 MFMAs behind the K loop; K / V^T of the workgroup's
+     * two heads staged once through LDS) and neither Q nor a second launch exists.  xa_k: this layer's keys, [B][xa_tk][xa_ldk]
+     * with head h in columns [64h, 64h + 64); xa_vt: this layer's first head inside a head-transposed V
+     * [B][xa_vt_heads][64][xa_ldvt >= 128] (slh_transpose_heads layout, key columns >= xa_tk zero); both 16-byte aligned;
+     * xa_tq = rows per sample (a multiple of 128).  Excludes residual, row bias, adapters, GEGLU, ln_out, vt_out, split-K. */
+    const void* xa_k; const void* xa_vt;
+    int32_t xa_tk, xa_tq, xa_ldk, xa_ldvt, xa_vt_heads;
+    float xa_scale;
 } slh_gemm_desc;
 int slh_gemm(const slh_gemm_desc* d, slh_stream_t stream);
 /* (WM<<12)|(MI<<8)|(NI<<4)|mode of the kernel instantiation gemm_kernel<MI,NI,mode,..,WM> slh_gemm would launch for d

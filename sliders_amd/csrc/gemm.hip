@@ -54,7 +54,7 @@ __device__ __forceinline__ f32x16 mfma_slot(const bf16x8 a, const bf16x8 b, f32x
 #endif
 }
 
-template <int MI, int NI, int MODE, int STAGES, bool LORA, int WM, bool SK = false>
+template <int MI, int NI, int MODE, int STAGES, bool LORA, int WM, bool SK = false, bool XA = false>
 __global__ __launch_bounds__(128 * WM, gemm_waves_per_simd(MI, NI, STAGES, LORA, WM)) void gemm_kernel(const GemmArgs p) {
     constexpr int NW = 2 * WM;
     constexpr int BM = 32 * MI * WM;
@@ -514,7 +514,8 @@ __global__ __launch_bounds__(128 * WM, gemm_waves_per_simd(MI, NI, STAGES, LORA,
         sk_unit += nk;
         __syncthreads();          // the operand stages (recycled by the epilogue) are free for the next segment's tiles
     } else {
-        gemm_epilogue<MI, NI, MODE, LORA, NW, 2>(p, smem, acc, accl, ln_mean, ln_rstd, ln_on, tile_m, tile_n, ks_id, wave, wm, wn);
+        // XA: the instantiation that carries the fused cross-attention (FEAT bit 8, gemm_common.h)
+        gemm_epilogue<MI, NI, MODE, LORA, NW, 2, XA ? 15 : 7>(p, smem, acc, accl, ln_mean, ln_rstd, ln_on, tile_m, tile_n, ks_id, wave, wm, wn);
     }
   } while (SK && sk_unit < sk_end);
 }
@@ -542,6 +543,15 @@ int launch_gemm3(const GemmArgs& a, int stages, hipStream_t s) {
 int launch_gemm_sk(const GemmArgs& a, int grid, hipStream_t s) {
     hipLaunchKernelGGL((gemm_kernel<1, 2, 0, 4, false, 4, true>), dim3(grid), dim3(512), 0, s, a);
     SLH_LAUNCH_CHECK("slh_gemm (stream-K)");
+    return 0;
+}
+
+// query projection + cross-attention (slh_gemm_desc.xa_k): the 128 x 128 8-wave ring tile (256 registers per lane to work with;
+// the double-buffered loop's 128 would spill the scores)
+int launch_gemm_xa(const GemmArgs& a, hipStream_t s) {
+    const int grid = a.tiles_m * a.tiles_n;
+    hipLaunchKernelGGL((gemm_kernel<1, 2, 0, 4, false, 4, false, true>), dim3(grid), dim3(512), 0, s, a);
+    SLH_LAUNCH_CHECK("slh_gemm (query projection + cross-attention)");
     return 0;
 }
 
@@ -766,6 +776,21 @@ extern "C" int slh_gemm(const slh_gemm_desc* d, slh_stream_t stream) {
         a.splitk = 1;
     }
     a.store16 = (d->ldc % 8 == 0) && (((uintptr_t)d->c & 15) == 0);
+    a.xa_k = (const __bf16*)d->xa_k; a.xa_vt = (const __bf16*)d->xa_vt;
+    a.xa_tk = d->xa_tk; a.xa_tq = d->xa_tq; a.xa_ldk = d->xa_ldk; a.xa_ldvt = d->xa_ldvt; a.xa_vt_heads = d->xa_vt_heads;
+    a.xa_scale = d->xa_scale;
+    if (d->xa_k) {
+        const int st = (d->tile >> 8) & 15;
+        SLH_CHECK(WM == 4 && MI == 1 && NI == 2 && st == 4 && a.splitk == 1 && !((d->tile >> 20) & 1),
+                  "slh_gemm: the fused cross-attention runs on the 128 x 128 8-wave ring tile (0x4412), no split-K / stream-K");
+        SLH_CHECK(d->mode == 0 && !d->lora_down && !d->lora_t && !d->residual && !d->rowbias && !d->geglu && !d->ln_out && !d->vt_out,
+                  "slh_gemm: xa_k excludes adapters, residual, row bias, GEGLU, ln_out, vt_out");
+        SLH_CHECK(d->xa_vt && d->N % 64 == 0 && d->xa_tk >= 1 && d->xa_tk <= 96 && d->xa_tq > 0 && d->xa_tq % 128 == 0 &&
+                      d->M % d->xa_tq == 0 && d->xa_ldvt >= 128 && d->xa_ldvt % 8 == 0 && d->xa_ldk % 8 == 0 &&
+                      d->xa_vt_heads >= d->N / 64 && ((uintptr_t)d->xa_k & 15) == 0 && ((uintptr_t)d->xa_vt & 15) == 0,
+                  "slh_gemm: xa_* need head dim 64 (N %% 64 == 0), 1 <= xa_tk <= 96, xa_tq %% 128 == 0, M %% xa_tq == 0, "
+                  "xa_ldvt >= 128 (two 64-key tiles are staged), 16-byte aligned keys / values");
+    }
     a.sk_per = 0;
     const int sk = (d->tile >> 20) & 1;        // stream-K (tile 0x104412): one workgroup per CU, see gemm_common.h
     if (sk) {
@@ -794,6 +819,7 @@ extern "C" int slh_gemm(const slh_gemm_desc* d, slh_stream_t stream) {
     a.group_m = pick_group_m(d, a.tiles_m);
     hipStream_t s = (hipStream_t)stream;
     const int stages = (d->tile >> 8) & 15;   // tile = (WM<<12)|(stages<<8)|(MI<<4)|NI ; stages 0/2 = double buffer
+    if (d->xa_k) return launch_gemm_xa(a, s);
     if (sk) {
         static const int ncu = [] {
             int dev = 0;

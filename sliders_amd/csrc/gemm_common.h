@@ -33,6 +33,8 @@ struct GemmArgs {
     int vt_also_c;        // the head-transposed columns are written to c as well (slh_gemm_desc.vt_also_c)
     __bf16* geglu_pre; int ld_pre;   // GEGLU: the bf16 pre-activation [M][N] kept for the backward (slh_gemm_desc.geglu_pre)
     int ln_in_chunks; float ln_eps;
+    // cross-attention behind the query projection (slh_gemm_desc.xa_*)
+    const __bf16* xa_k; const __bf16* xa_vt; int xa_tk, xa_tq, xa_ldk, xa_ldvt, xa_vt_heads; float xa_scale;
     int sk_per;  // stream-K (slh_gemm_desc.tile bits 20-21): K-tile units per workgroup; 0 = one tile (or K slice) per workgroup
     int probe;   // ablation builds only (-DSLH_GEMM_PROBE, scripts/build_variant.sh): 1 skip tile refills, 2 skip MFMA work,
                  // 4 skip the epilogue, 8 skip the first tile fill, 16 return at once; the default build ignores it
@@ -203,7 +205,8 @@ constexpr int gemm_epilogue_lds(int MI, int NI, int NW, int WN, bool LORA) {
 // (MFMA operand roles swapped: W rows feed the A operand, activation rows the B operand).  Must be entered by all waves of the
 // workgroup with the operand stages in `smem` no longer in use by the K loop's LDS-DMA (they are recycled as staging patches).
 // FEAT: optional forms a K loop's tiles can take - 1 the head-transposed V store (vt_out), 2 the 32 | 32 GEGLU forms (geglu = 1, 2),
-// 4 the LayerNorm chunk statistics (ln_out); compiled out where slh_gemm never routes them (registers and code of the odd-NI tiles)
+// 4 the LayerNorm chunk statistics (ln_out), 8 cross-attention behind the query projection (xa_k; MI = 1, NI = 2 only); compiled out
+// where slh_gemm never routes them (registers and code of the odd-NI tiles)
 template <int MI, int NI, int MODE, bool LORA, int NW, int WN, int FEAT = 7>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, char* smem, f32x16 (&acc)[MI][NI], f32x16 (&accl)[MI],
                                               const float (&ln_mean)[MI], const float (&ln_rstd)[MI], const bool ln_on,
@@ -515,6 +518,135 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, char* smem, f32
     } else {
         __syncthreads();                       // the column vectors are in LDS
     }
+    bool xa = false;
+    if constexpr ((FEAT & 8) != 0 && MI == 1 && NI == 2 && !LORA) {
+        if (p.xa_k != nullptr) {
+            // ---- cross-attention of this wave's 32 rows x one head, in registers (slh_gemm_desc.xa_*) ---------------------------
+            // The accumulators are Q^T of the head in the C layout: lane (lrow, lhi) holds, for query row lrow, the head dims
+            //   dim(j, r) = 32 j + 8 (r >> 2) + 4 lhi + (r & 3).
+            // A sum over dims does not care in which order the 16 dims of a k-step sit in the operand registers as long as both
+            // operands agree, so registers 8 (s & 1) .. + 7 of block j = s >> 1 ARE the B operand of k-step s (dims 16 s + 8 (e >> 2)
+            // + 4 lhi + (e & 3), e = 0..7) and the key rows of the A operand are gathered in the same order (two 8-byte pieces
+            // per k-step).  The scores come out transposed (S^T = K Q^T: lane = query, registers = keys), the softmax is a
+            // reduction over registers + one exchange with lane ^ 32, and the probabilities feed the second product (O^T = V^T
+            // P^T) by the same trick; O^T lands in the accumulator layout Q^T came in, so the ordinary store path below writes it.
+            xa = true;
+            const int mrow0 = m0 + wm * 32;
+            const int b = min(mrow0, p.M - 1) / p.xa_tq;
+            const int head = (n0 + wn * 64) >> 6;
+            const int tk = p.xa_tk;
+            // K and V^T of the workgroup's two heads go through LDS (LDS-DMA, 8 lanes per 128-byte row, the GEMM's slot swizzle):
+            // gathered straight from memory - every lane its own key row, 8 bytes at a time, rows 332 KB apart in the batched K / V
+            // matrix - the two small products cost as much as the separate attention launch they replace (measured: pass time
+            // unchanged).  Behind the store patches and column vectors: per head [96 keys][128 B] + 2 x [64 dims][128 B] (keys
+            // 0-63 | 64-127).
+            constexpr int XA_BASE = (NW * (32 * S * 16) + 4 * BN * 4 + 1023) & ~1023, XA_K = 96 * 128, XA_HEAD = XA_K + 2 * 8192;
+            {
+                const int frow = lane >> 3, fslot = lane & 7;
+                const unsigned xs0 = lds_addr_of(smem) + XA_BASE;
+                const int head0 = n0 >> 6;
+#pragma unroll
+                for (int it = 0; it < 7; ++it) {
+                    const int idx = wave + NW * it;                 // 56 groups of 8 rows: [head][12 K groups | 16 V groups]
+                    const int hh = idx >= 28 ? 1 : 0, g = idx - 28 * hh;
+                    const int hd = min(head0 + hh, p.N / 64 - 1);
+                    const __bf16* src;
+                    unsigned dst = xs0 + hh * XA_HEAD;
+                    if (g < 12) {
+                        const int row = g * 8 + frow;
+                        const int key = row < tk ? row : tk - 1;
+                        src = p.xa_k + ((long)b * tk + key) * p.xa_ldk + hd * 64 + ((fslot ^ ((row >> 1) & 7)) << 3);
+                        dst += g * 1024;
+                    } else {
+                        const int t = (g - 12) >> 3, row = ((g - 12) & 7) * 8 + frow;
+                        src = p.xa_vt + (((long)b * p.xa_vt_heads + hd) * 64 + row) * p.xa_ldvt + t * 64 + ((fslot ^ ((row >> 1) & 7)) << 3);
+                        dst += XA_K + (g - 12) * 1024;
+                    }
+                    glds16_hidden(src, dst);
+                }
+            }
+            // Q: LayerNorm fold / bias applied, rounded to bf16 (the unfused path stores it as a bf16 tensor)
+            bf16x8 qf[4];
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int cl = wn * 64 + j * 32 + q * 8 + lhi * 4;
+                    float v[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = acc[0][j][q * 4 + e];
+                    if (MODE == 0 && ln_on) {
+                        const f32x4 s4 = *(const f32x4*)(sCol + 2 * BN + cl), b4 = *(const f32x4*)(sCol + 3 * BN + cl);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = ln_rstd[0] * (v[e] - ln_mean[0] * s4[e]) + b4[e];
+                    }
+                    if (p.bias) {
+                        const f32x4 b4 = *(const f32x4*)(sCol + cl);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] += b4[e];
+                    }
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) qf[2 * j + (q >> 1)][(q & 1) * 4 + e] = (__bf16)v[e];
+                }
+            const f32x16 kZero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            lds_dma_syncthreads();                 // the heads' K / V^T have landed (every wave's share)
+            const char* xk = smem + XA_BASE + wn * XA_HEAD;
+            const char* xv = xk + XA_K;
+            f32x16 sc[3];
+#pragma unroll
+            for (int kb = 0; kb < 3; ++kb) {
+                sc[kb] = kZero16;
+#pragma unroll
+                for (int s_ = 0; s_ < 4; ++s_) {
+                    // dims 16 s + 4 lhi + {0..3} and 16 s + 8 + 4 lhi + {0..3} of key row 32 kb + lrow
+                    const bf16x4 k0 = *(const bf16x4*)(xk + lds_off(kb * 32 + lrow, 2 * s_) + 8 * lhi);
+                    const bf16x4 k1 = *(const bf16x4*)(xk + lds_off(kb * 32 + lrow, 2 * s_ + 1) + 8 * lhi);
+                    const bf16x8 kf = __builtin_shufflevector(k0, k1, 0, 1, 2, 3, 4, 5, 6, 7);
+                    sc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s_], sc[kb], 0, 0, 0);
+                }
+            }
+            // sc[kb][r] = S[query lrow][key 32 kb + 8 (r >> 2) + 4 lhi + (r & 3)]
+            const float cs = p.xa_scale * 1.4426950408889634f;
+            float mx = -1e30f;
+#pragma unroll
+            for (int kb = 0; kb < 3; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = kb * 32 + 8 * (r >> 2) + 4 * lhi + (r & 3);
+                    if (key >= tk) sc[kb][r] = -1e30f;
+                    mx = fmaxf(mx, sc[kb][r]);
+                }
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float mc = mx * cs;
+            float ps = 0.f;
+            bf16x8 pb[6];
+#pragma unroll
+            for (int kb = 0; kb < 3; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[kb][r], cs, -mc));
+                    ps += pv;
+                    pb[2 * kb + (r >> 3)][r & 7] = (__bf16)pv;
+                }
+            const float inv = 1.f / (ps + __shfl_xor(ps, 32, 64));
+#pragma unroll
+            for (int db = 0; db < 2; ++db) {
+                f32x16 o = kZero16;
+#pragma unroll
+                for (int s2 = 0; s2 < 6; ++s2) {
+                    // keys 16 s2 + 4 lhi + {0..3} and + 8 of dim row 32 db + lrow; key tile s2 >> 2, slots 2 (s2 & 3), 2 (s2 & 3) + 1
+                    const char* vt_ = xv + (s2 >> 2) * 8192 + 8 * lhi;
+                    const bf16x4 v0 = *(const bf16x4*)(vt_ + lds_off(db * 32 + lrow, 2 * (s2 & 3)));
+                    const bf16x4 v1 = *(const bf16x4*)(vt_ + lds_off(db * 32 + lrow, 2 * (s2 & 3) + 1));
+                    const bf16x8 vf = __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7);
+                    o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pb[s2], o, 0, 0, 0);
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[0][db][r] = o[r] * inv;
+            }
+        }
+    }
+    const bool epi_ln = ln_on && !xa, epi_bias = p.bias != nullptr && !xa;     // (the fused attention consumed them with Q)
     char* sE = smem + wave * (32 * S * 16);
     const float lscale = (LORA || p.lora_t != nullptr) ? *p.lora_scale : 0.f;
     const int ncol0 = n0 + wn * (32 * NI);
@@ -607,12 +739,12 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, char* smem, f32
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = acc[i][j][q * 4 + e];
                 if (mok && n < p.N) {
-                    if (MODE == 0 && ln_on) {
+                    if (MODE == 0 && epi_ln) {
                         const f32x4 s4 = *(const f32x4*)(sCol + 2 * BN + cl), b4 = *(const f32x4*)(sCol + 3 * BN + cl);
 #pragma unroll
                         for (int e = 0; e < 4; ++e) v[e] = ln_rstd[i] * (v[e] - ln_mean[i] * s4[e]) + b4[e];
                     }
-                    if (p.bias) {
+                    if (epi_bias) {
                         const f32x4 b4 = *(const f32x4*)(sCol + cl);
 #pragma unroll
                         for (int e = 0; e < 4; ++e) v[e] += b4[e];

@@ -36,7 +36,8 @@ GemmDesc = _struct("GemmDesc", _ptrs("a0", "a1", "w", "bias", "rowbias", "lora_t
                            "reserved_") + _ptrs("splitk_c32", "splitk_t32", "vt_out")
                    + _ints("vt_col0", "vt_D", "vt_heads", "vt_tokens", "vt_ld", "splitk_slabs")
                    + _ptrs("ln_out", "ln_in", "ln_s", "ln_b") + _ints("ln_in_chunks") + [("ln_eps", c_f32)]
-                   + _ptrs("splitk_ticket", "ln_mr_out", "geglu_pre") + _ints("ld_pre", "vt_also_c"))
+                   + _ptrs("splitk_ticket", "ln_mr_out", "geglu_pre") + _ints("ld_pre", "vt_also_c")
+                   + _ptrs("xa_k", "xa_vt") + _ints("xa_tk", "xa_tq", "xa_ldk", "xa_ldvt", "xa_vt_heads") + [("xa_scale", c_f32)])
 SkinnyDesc = _struct("SkinnyDesc", _ptrs("a0", "a1", "w", "bias", "out")
                      + _ints("lda0", "lda1", "ca0", "ca1", "mode", "batch", "hs", "ws", "src_xform", "stride",
                              "ho", "wo", "M", "R", "K", "ldo", "out_kind", "w_kmajor"))

@@ -254,7 +254,8 @@ class UNetPlan:
              lora_paths: Optional[List[str]] = None, geglu: bool = False, out: Optional[Act] = None,
              w_ptr: Optional[int] = None, bias_ptr: Optional[int] = None, vt_heads: Optional[int] = None,
              ln_stats: bool = False, ln_fold: Optional[Act] = None, geglu_pre: Optional[Act] = None,
-             ln_mr: Optional[Buf] = None, tape_x: Optional[Act] = None, geglu16: bool = False) -> Optional[Act]:
+             ln_mr: Optional[Buf] = None, tape_x: Optional[Act] = None, geglu16: bool = False,
+             xattn: Optional[dict] = None) -> Optional[Act]:
         """y = x . W^T (+bias)(+rowbias per sample)(+LoRA)(+residual).  conv: {'stride','xform'} for 3x3.
         vt_heads: the product is a fused q|k|v projection of that many heads; where the kernel supports it (no-grad
         passes, head_dim % 64 == 0) its V third is written head-transposed for slh_attn_fwd straight from the epilogue
@@ -265,7 +266,11 @@ class UNetPlan:
         (weights.py _put_ln_folded); returns None - nothing emitted - when the tile that would run cannot (split-K).
         Training passes: geglu_pre receives proj(x) itself next to the GEGLU output (the backward's pre-activation; the tape
         records this product with it as its output), ln_mr the rows' (mean, rstd) of a folded LayerNorm, and tape_x stands
-        in for the normalised tensor that was never written (a key for the gradient chain: nothing reads its memory)."""
+        in for the normalised tensor that was never written (a key for the gradient chain: nothing reads its memory).
+        xattn = {k, vt_ptr, vt_heads, Tk, Tq, scale}: the product is attn2.to_q and, when the tile that runs is the 128 x 128 ring
+        tile, the cross-attention behind it happens in its epilogue (slh_gemm_desc.xa_*): the returned activation is then the
+        attention output and self.xattn_done says so."""
+        self.xattn_done = False
         x0, x1 = _src_parts(x)
         cin = x0.C + (x1.C if x1 else 0)
         B = x0.B
@@ -326,6 +331,13 @@ class UNetPlan:
         d.ln_out = 0
         if not d.tile and M <= 192 and N >= 4096:
             d.tile = 0x12        # few rows, very wide: 64-row tiles waste the least of the short M
+        if xattn is not None and (d.tile == 0x4412 or os.environ.get("SLIDERS_XATTN_ALL")):
+            # (where the table prefers another tile for the query projection - the 640-channel level - the two launches stay)
+            d.tile = 0x4412
+            k = xattn["k"]
+            d.xa_k, d.xa_vt, d.xa_tk, d.xa_tq = k.ptr, xattn["vt_ptr"], xattn["Tk"], xattn["Tq"]
+            d.xa_ldk, d.xa_ldvt, d.xa_vt_heads, d.xa_scale = k.ld, xattn["ldvt"], xattn["vt_heads"], xattn["scale"]
+            self.xattn_done = True
         if ln_fold is not None:
             if ((d.tile >> 16) & 15) > 1 or (not d.tile and splitk_wanted(d)):
                 return None
@@ -393,7 +405,8 @@ class UNetPlan:
         return y
 
     def ln_gemm(self, h: Act, norm: str, wname: str, N: int, bias: bool = True, lora_paths: Optional[List[str]] = None,
-                geglu: bool = False, vt_heads: Optional[int] = None, geglu_pre: Optional[Act] = None, geglu16: bool = False) -> Act:
+                geglu: bool = False, vt_heads: Optional[int] = None, geglu_pre: Optional[Act] = None, geglu16: bool = False,
+                xattn: Optional[dict] = None) -> Act:
         """Linear(LayerNorm(h)): folded into one product when h's producer left row statistics, the consumer carries no adapter
         and the pass keeps no tape; the LayerNorm launch + the plain product otherwise."""
         grp = self._lora_group(lora_paths) if lora_paths else None
@@ -402,7 +415,7 @@ class UNetPlan:
             if not self.train:
                 amark, nallocs = self.arena.mark(), len(self.arena.allocs)
                 y = self.gemm(h, wname, N, wname, bias=False, geglu=geglu, vt_heads=vt_heads, ln_fold=h,
-                              geglu16=geglu16 and self.w.has(wname + ".lnw16"))
+                              geglu16=geglu16 and self.w.has(wname + ".lnw16"), xattn=xattn)
                 if y is not None:
                     return y
                 self.arena.reset(amark)           # fold refused: the output it had reserved goes back
@@ -424,7 +437,7 @@ class UNetPlan:
                 del self.arena.allocs[nallocs:]
         n = self.layernorm(h, norm, norm)
         return self.gemm(n, wname, N, wname, bias=bias, lora_paths=lora_paths, geglu=geglu, vt_heads=vt_heads,
-                         geglu_pre=geglu_pre, geglu16=geglu16 and geglu_pre is None and self.w.has(wname + ".w16"))
+                         geglu_pre=geglu_pre, geglu16=geglu16 and geglu_pre is None and self.w.has(wname + ".w16"), xattn=xattn)
 
     def attention(self, q: Act, k: Act, v: Act, Tk: int, heads: int, name: str, vt_pre=None) -> Act:
         """q [B*Tq][C] view, k/v [B*Tk][C] views (any ld); returns [B*Tq][C].  vt_pre = (pointer to this layer's first
@@ -544,7 +557,6 @@ class UNetPlan:
         T = h.HW
         o1 = self.attention(qkv.cols(0, C), qkv.cols(C, C), qkv.cols(2 * C, C), T, heads, a1 + ".sdpa", vt_pre=self.last_vt)
         h1 = self.gemm(o1, a1 + ".out", C, a1 + ".out", residual=h, lora_paths=[a1 + ".to_out.0"], ln_stats=True)
-        q2 = self.ln_gemm(h1, path + ".norm2", a2 + ".q", C, bias=False, lora_paths=[a2 + ".to_q"])
         vt_pre = None
         if self.kv_all is not None:
             k_off, v_off = self.w.kv_all_offset[a2]
@@ -558,7 +570,18 @@ class UNetPlan:
             k2, v2 = kv.cols(0, C), kv.cols(C, C)
         if self._lora_group([a2 + ".to_k", a2 + ".to_v"]) is None:
             self.nograd_kv.add(kv.buf.ptr)      # text K/V carry no gradient unless they are adapted
-        o2 = self.attention(q2, k2, v2, self.ctx_len, heads, a2 + ".sdpa", vt_pre=vt_pre)
+        # no-grad passes, head dim 64, text keys, no adapter on to_q: the attention runs in the epilogue of the query projection
+        xa = None
+        D2 = C // heads
+        if not self.train and vt_pre is not None and D2 == 64 and self.ctx_len <= 96 and h.HW % 128 == 0 and \
+                self._lora_group([a2 + ".to_q"]) is None and os.environ.get("SLIDERS_NO_FUSED_XATTN") is None:
+            xa = dict(k=k2, vt_ptr=vt_pre[0], vt_heads=vt_pre[1], Tk=self.ctx_len, Tq=h.HW, scale=D2 ** -0.5,
+                      ldvt=(self.ctx_len + 63) // 64 * 64)
+        q2 = self.ln_gemm(h1, path + ".norm2", a2 + ".q", C, bias=False, lora_paths=[a2 + ".to_q"], xattn=xa)
+        if xa is not None and self.xattn_done:
+            o2 = q2
+        else:
+            o2 = self.attention(q2, k2, v2, self.ctx_len, heads, a2 + ".sdpa", vt_pre=vt_pre)
         h2 = self.gemm(o2, a2 + ".out", C, a2 + ".out", residual=h1, lora_paths=[a2 + ".to_out.0"], ln_stats=True)
         if self.train and (self._lora_group([path + ".ff.net.0.proj"]) is not None or
                            os.environ.get("SLIDERS_TRAIN_UNFUSED_GEGLU") is not None):
