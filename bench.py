@@ -80,7 +80,7 @@ def measure_roofline(eng, plan):
             one.add(opcode, d)
             one.run(s)
 
-    def name(d):     # template arguments <MI, NI, MODE, STAGES, LORA, WM> exactly as rocprofv3 prints them
+    def name(d):     # template arguments exactly as rocprofv3 prints them
         v = lib.gemm_variant(d)
         st = (d.tile >> 8) & 15
         stages = st if st in (3, 4) else 2
@@ -92,7 +92,10 @@ def measure_roofline(eng, plan):
             if mi == 4:
                 return f"gemm8p_kernel<{v & 15}, false>"
             return f"gemm8pb_kernel<{mi}, {ni}, {v & 15}, {'true' if d.lora_down else 'false'}>"
-        return f"gemm_kernel<{mi}, {ni}, {v & 15}, {stages}, {'true' if d.lora_down else 'false'}, {wm}>"
+        # ... <MI, NI, MODE, STAGES, LORA, WM, SK (stream-K, never chosen by the tables), XA (cross-attention in the epilogue)>
+        sk = "true" if (d.tile >> 20) & 1 else "false"
+        xa = "true" if d.xa_k else "false"
+        return f"gemm_kernel<{mi}, {ni}, {v & 15}, {stages}, {'true' if d.lora_down else 'false'}, {wm}, {sk}, {xa}>"
 
     for _ in range(2):
         plan.prog.run(s)                        # warm-up passes (also make every input of every op valid)

@@ -67,7 +67,7 @@ def valid(d, tile):
     if (tile >> 16) & 15:                       # split-K candidates only where the planner provisioned a workspace
         if not d.splitk_c32 or (d.K // 64) < 4 * ((tile >> 16) & 15) or ((tile >> 16) & 15) > d.splitk_slabs:
             return False
-    if d.geglu and ni != 2:
+    if d.geglu in (1, 2) and ni != 2:           # (geglu = 3, the 16 | 16 block order, takes any tile)
         return False
     if d.ln_out and ni != 2:                    # folded LayerNorm: the producer writes 64-column chunk statistics
         return False

@@ -30,6 +30,8 @@ def tile_ok(d, tile: int) -> bool:
     """Can slh_gemm run descriptor d with this tile code?  (The constraints slh_gemm itself checks: used by the tuner to skip
     candidates and by the planner to drop a table entry that no longer fits the launch it is looked up for.)"""
     mi, ni, wm = (tile >> 4) & 15, tile & 15, (tile >> 12) & 15
+    if getattr(d, "xa_k", None):                  # cross-attention in the epilogue: the 128 x 128 ring tile only
+        return tile == 0x4412
     if (tile >> 20) & 1:                          # stream-K: the dense 128 x 128 ring tile, bare or bias / residual epilogue
         return (tile & 0xFFFFF) == 0x4412 and d.mode == 0 and not (d.lora_down or d.geglu or d.ln_in or d.ln_out or d.vt_out)
     if wm == 8 and (tile >> 16) & 15:             # split-K: the slabs of these tiles must fit the workspace contract
@@ -78,6 +80,9 @@ def tuned_tile(d) -> int:
     full = gemm_key(d, True)
     base = full.replace(",no", "").replace(",ni", "")          # entries measured before the LayerNorm folding existed
     t = tb.get(full, tb.get(base, tb.get(gemm_key(d), 0)))
+    if not t and d.geglu == 3:     # GEGLU in 16 | 16 blocks takes any tile: unmeasured shapes run the tile measured for the 32 | 32 form
+        g1 = lambda k: k.replace(",g3", ",g1")
+        t = tb.get(g1(full), tb.get(g1(base), tb.get(g1(gemm_key(d)), 0)))
     if not t and d.lora_down:      # adapter fused in but only the plain product was measured (backward-data GEMMs): same tile
         t = tb.get(base[:-1] + "0", 0)
     if t and not tile_ok(d, t):

@@ -103,10 +103,11 @@ class WeightStore:
         # LayerNorm folded into its consumer GEMMs in the no-grad passes (one more copy of the q|k|v, attn2.to_q and GEGLU
         # projection matrices, pre-scaled by the LayerNorm weight); SLIDERS_NO_LN_FOLD=1 keeps the LayerNorm launches
         self.ln_fold = os.environ.get("SLIDERS_NO_LN_FOLD") is None
-        # GEGLU.proj also in the 16 | 16 block order (geglu = 3) for the no-grad passes: opens the 128 x 320 / 256 x 320 tiles to
-        # ff.net.0.proj.  Measured equal to the 32 | 32 form on the tiles that win today (profiles/r04_gemm_pingpong.md), so the
-        # second copy of the weights (+3.6 GB for SDXL) is opt-in: SLIDERS_GEGLU16=1
-        self.geglu16 = os.environ.get("SLIDERS_GEGLU16", "0") == "1"
+        # GEGLU.proj also in the 16 | 16 block order (geglu = 3) for the no-grad passes: opens the 128 x 320 ping-pong tile to
+        # ff.net.0.proj (2048 x 10240 x 1280: 512 tiles = two even rounds instead of 2.5 of the 128 x 128 tile): pass -0.6 ms in a
+        # same-box A/B (profiles/r04_geglu16.txt).  Costs a second copy of those weights (+3.6 GB for SDXL); SLIDERS_GEGLU16=0
+        # keeps only the 32 | 32 form
+        self.geglu16 = os.environ.get("SLIDERS_GEGLU16", "1") == "1"
         self.temb_offsets: Dict[str, int] = {}
         self.resnet_paths: List[str] = []
         self._pack()
