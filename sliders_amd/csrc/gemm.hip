@@ -678,6 +678,8 @@ extern "C" int slh_gemm(const slh_gemm_desc* d, slh_stream_t stream) {
         SLH_CHECK((MI == 4 && NI == 2) || (MI == 1 && NI >= 3 && NI <= 5),
                   "slh_gemm: ping-pong tiles are 256 x 256 (0x8042) or 128 x 64*NI (0x801<NI>, NI = 3..5)");
         SLH_CHECK(!d->lora_down || MI == 1, "slh_gemm: the 256 x 256 tile does not take a fused adapter (lora_down)");
+        SLH_CHECK(!d->vt_out || (MI == 4 && NI == 2) || (MI == 1 && NI == 4 && d->mode == 0),
+                  "slh_gemm: vt_out on the ping-pong tiles needs 256 x 256 (0x8042) or the dense 128 x 256 tile (0x8014)");
     } else {
         SLH_CHECK((MI == 1 || MI == 2) && (NI == 1 || NI == 2), "slh_gemm: bad tile");
         SLH_CHECK(WM == 2 || NI == 2 || MI == 1, "slh_gemm: 8-wave tiles are 128x64, 128x128 or 256x128");

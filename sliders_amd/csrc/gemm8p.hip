@@ -629,7 +629,9 @@ __global__ __launch_bounds__(512, 2) void gemm8pb_kernel(const GemmArgs p) {
     if (grp == 0) __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_s_barrier();
 
-    gemm_epilogue<MI, NI, MODE, LORA, NW, WN, 0>(p, smem, acc, accl, ln_mean, ln_rstd, ln_on, tile_m, tile_n, ks_id, wave, wm, wn);
+    // NI = 4 (128 x 256): a wave's 128 columns lie on one side of vt_col0 (a multiple of 128), so the fused q|k|v projection can
+    // write its V third head-transposed from here as well (FEAT bit 1); the odd-NI tiles keep the trimmed epilogue
+    gemm_epilogue<MI, NI, MODE, LORA, NW, WN, (NI == 4 && MODE == 0) ? 1 : 0>(p, smem, acc, accl, ln_mean, ln_rstd, ln_on, tile_m, tile_n, ks_id, wave, wm, wn);
 }
 
 }  // namespace

@@ -358,7 +358,8 @@ class UNetPlan:
                 (not self.train or os.environ.get("SLIDERS_TRAIN_NO_FUSED_VT") is None):
             Cq = N // 3
             Dh, Tk = Cq // vt_heads, Ho * Wo
-            if Dh % 64 == 0 and (2 * Cq) % 128 == 0 and Tk % 64 == 0 and not (d.tile >> 16) & 15:
+            pp_ok = (d.tile >> 12) & 15 != 8 or (d.tile & 0xFF) in (0x42, 0x14)     # ping-pong tiles: 256 x 256 and 128 x 256 only
+            if Dh % 64 == 0 and (2 * Cq) % 128 == 0 and Tk % 64 == 0 and not (d.tile >> 16) & 15 and pp_ok:
                 vt = self.arena.alloc((B, vt_heads, Dh, Tk), torch.bfloat16, name + ".vt")
                 d.vt_out, d.vt_col0, d.vt_D, d.vt_heads, d.vt_tokens, d.vt_ld = vt.ptr, 2 * Cq, Dh, vt_heads, Tk, Tk
                 d.vt_also_c = 1 if self.train else 0      # the backward reads V row-major

@@ -44,7 +44,9 @@ def tile_ok(d, tile: int) -> bool:
             return not d.lora_down and d.geglu in (0, 1, 2, 3)
         if mi != 1 or ni < 3 or ni > 5:
             return False
-        if d.geglu in (1, 2) or d.ln_out or d.vt_out:     # 32 | 32 GEGLU blocks, chunk statistics and the V^T store assume NI = 2
+        if d.geglu in (1, 2) or d.ln_out:                 # 32 | 32 GEGLU blocks and the chunk statistics assume NI = 2
+            return False
+        if d.vt_out and not (ni == 4 and d.mode == 0):    # the V^T store: a wave's columns must not straddle vt_col0 (128 x 256 only)
             return False
         return True
     if not tile:

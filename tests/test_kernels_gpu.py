@@ -122,7 +122,7 @@ def test_gemm_two_source_rowbias_lora(dev, tile):
         report(f"gemm_2src_rowbias_lora g{groups}", c, ref, TOL)
 
 
-@pytest.mark.parametrize("tile", [0, 0x22, 0x12, 0x21, 0x11, 0x4012, 0x4011, 0x4022, 0x422, 0x4412, 0x4322, 0x312, 0x8042])
+@pytest.mark.parametrize("tile", [0, 0x22, 0x12, 0x21, 0x11, 0x4012, 0x4011, 0x4022, 0x422, 0x4412, 0x4322, 0x312, 0x8042, 0x8014])
 def test_gemm_head_transposed_v_store(dev, tile):
     """vt_out: the V third of a fused q|k|v projection leaves the epilogue in slh_attn_fwd's [B][H][D][T] layout
     (what slh_transpose_heads would make of c[:, 2C:]); q and k still land in c.  With the LoRA term of to_q/k/v."""
@@ -159,6 +159,23 @@ def test_gemm_head_transposed_v_store(dev, tile):
     report(f"gemm_vt also_c tile{tile:x} v^T", vt, vref, TOL)
     assert torch.equal(c[:, 2 * C:].reshape(B, T, heads, D).permute(0, 2, 3, 1).contiguous(), vt), "the two layouts hold the same bits"
     d.vt_also_c = 0
+    if tile in (0x4012, 0x8014):
+        # the production form of the no-grad passes: the adapter's down matrix fused in (third operand tile), three groups
+        A = bf(torch.randn(12, K, device=dev) / math.sqrt(K))
+        c.fill_(7.0)
+        vt.fill_(7.0)
+        df = lib.GemmDesc(a0=p(x), w=p(w), lora_down=p(A), lora_up=p(up), lora_scale=p(scale), c=p(c), lda0=K, ca0=K, mode=0,
+                          stride=1, ldw=K, M=M, N=N, K=K, ld_t=12, lora_groups=3, lora_rank=12, ldc=N, rows_per_sample=T, tile=tile,
+                          vt_out=p(vt), vt_col0=2 * C, vt_D=D, vt_heads=heads, vt_tokens=T, vt_ld=T)
+        lib.call(lib.OP_GEMM, df, stream())
+        torch.cuda.synchronize()
+        Tf = bf(x.float() @ A.float().t() * 0.5).float()       # scaled and rounded to bf16 ahead of the up-projection MFMA
+        reff = x.float() @ w.float().t()
+        for g in range(3):
+            reff[:, g * C:(g + 1) * C] += Tf[:, 4 * g:4 * g + 4] @ up.float()[g * C:(g + 1) * C].t()
+        report(f"gemm_vt fused adapter tile{tile:x} q|k", c[:, :2 * C], reff[:, :2 * C], TOL)
+        report(f"gemm_vt fused adapter tile{tile:x} v^T", vt, reff[:, 2 * C:].reshape(B, T, heads, D).permute(0, 2, 3, 1), TOL)
+        assert (c[:, 2 * C:].float() == 7.0).all()
     if tile in (0x4412, 0x22):
         # the same with K cut into slices: the last slice to arrive runs this epilogue on the slice-ordered sums
         c.fill_(7.0)
