@@ -147,6 +147,11 @@ typedef struct slh_gemm_desc {
     const void* xa_k; const void* xa_vt;
     int32_t xa_tk, xa_tq, xa_ldk, xa_ldvt, xa_vt_heads;
     float xa_scale;
+    /* ln_in together with a fused adapter (lora_down; ping-pong tiles 0x8013 / 0x8014 only): lora_down must hold A . gamma (bf16, what
+     * slh_lora_ln_fold writes) and the down-projection is normalised like the main product,
+     *   T = rstd_m * (a . (A gamma)^T - mean_m * ln_lora_s) + ln_lora_c,   ln_lora_s = row sums of the rounded A gamma, ln_lora_c = A . beta
+     * (fp32 [rank] each), ahead of the up-projection - Linear(LayerNorm(x)) + LoRA(LayerNorm(x)) without the LayerNorm launch. */
+    const float* ln_lora_s; const float* ln_lora_c;
 } slh_gemm_desc;
 int slh_gemm(const slh_gemm_desc* d, slh_stream_t stream);
 /* (WM<<12)|(MI<<8)|(NI<<4)|mode of the kernel instantiation gemm_kernel<MI,NI,mode,..,WM> slh_gemm would launch for d
@@ -426,6 +431,17 @@ int slh_transpose_heads_batch(const slh_batch_desc* d, slh_stream_t stream);
 typedef struct slh_gather16_desc { const void* src; const int32_t* idx; void* out; int64_t n; } slh_gather16_desc;
 int slh_gather16(const slh_gather16_desc* d, slh_stream_t stream);
 
+/* The adapter side of a LayerNorm folded into an adapter-carrying product (slh_gemm_desc.ln_lora_*): for every item
+ *   a_out[r][k] = bf16(a[r][k] * gamma[k]),  s_out[r] = sum_k float(a_out[r][k]),  c_out[r] = sum_k a[r][k] * beta[k]
+ * from the LIVE adapter parameters; one launch at the head of a pass covers every folded module (items = a device array). */
+typedef struct slh_lora_lnfold_item {
+    const void* a; const void* gamma; const void* beta;   /* bf16 [rows][K], [K], [K] */
+    void* a_out; float* s_out; float* c_out;               /* bf16 [rows][K], fp32 [rows], fp32 [rows] */
+    int32_t rows, K;                                       /* rows <= 16, K % 8 == 0 */
+} slh_lora_lnfold_item;
+typedef struct slh_lora_lnfold_desc { const slh_lora_lnfold_item* items; int32_t n; int32_t pad_; } slh_lora_lnfold_desc;
+int slh_lora_ln_fold(const slh_lora_lnfold_desc* d, slh_stream_t stream);
+
 /* Backward-data term of a 3x3 LoRA down conv (lora.py:82-87): gx[i][c] (+)= scale * sum_{tap,r} U[o][r] *
  * A[r][tap][c] for the output pixels o with o*stride + tap - 1 = i.  U fp32 [batch*ho*wo][ldu], A = lora_down
  * as stored [4][9*cin], gx bf16 pixel-major image of hl x wl. */
@@ -553,7 +569,8 @@ enum {
     SLH_OP_LAYERNORM_BWD = 18, SLH_OP_ATTN_BWD = 19, SLH_OP_MEMSET = 20, SLH_OP_LORA_CONV_DGRAD = 21,
     SLH_OP_TEMB_LORA_BWD = 22, SLH_OP_SGEMM = 23, SLH_OP_GN32_STATS = 24, SLH_OP_GN32_APPLY = 25, SLH_OP_SOFTMAX32 = 26,
     SLH_OP_VAE_CONV_IN = 27, SLH_OP_VAE_MOMENTS = 28, SLH_OP_VAE_SAMPLE = 29, SLH_OP_VAE_POST_QUANT = 30, SLH_OP_LION = 31,
-    SLH_OP_WGRAD_BATCH = 32, SLH_OP_TRANSPOSE_BATCH = 33, SLH_OP_GATHER16 = 34, SLH_OP_GN_FUSED = 35
+    SLH_OP_WGRAD_BATCH = 32, SLH_OP_TRANSPOSE_BATCH = 33, SLH_OP_GATHER16 = 34, SLH_OP_GN_FUSED = 35,
+    SLH_OP_LORA_LN_FOLD = 36
 };
 /* SLH_OP_MEMSET: byte fill by a kernel of this library (not hipMemsetAsync: a captured memset node is a runtime blit whose
  * replays were observed to go wrong on the legacy default stream - see the executor's comment) */

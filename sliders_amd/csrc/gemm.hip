@@ -717,8 +717,13 @@ extern "C" int slh_gemm(const slh_gemm_desc* d, slh_stream_t stream) {
         SLH_CHECK(((uintptr_t)d->ln_out & 7) == 0, "slh_gemm: ln_out alignment");
     }
     if (d->ln_in) {
-        SLH_CHECK(d->mode == 0 && !d->a1 && d->ln_s && d->ln_b && !d->bias && !d->lora_down && !d->lora_t,
-                  "slh_gemm: ln_in needs a dense single-source product, ln_s / ln_b, no bias (folded into ln_b), no adapter");
+        SLH_CHECK(d->mode == 0 && !d->a1 && d->ln_s && d->ln_b && !d->bias && !d->lora_t,
+                  "slh_gemm: ln_in needs a dense single-source product, ln_s / ln_b, no bias (folded into ln_b), no external T");
+        if (d->lora_down)
+            SLH_CHECK(WM == 8 && MI == 1 && NI <= 4 && d->ln_lora_s && d->ln_lora_c && !d->lora_up_rmajor && !d->lora_t_out && !d->ln_mr_out &&
+                          ((d->tile >> 16) & 15) <= 1,
+                      "slh_gemm: ln_in with a fused adapter runs on the ping-pong 128 x 192 / 128 x 256 tiles (0x8013, 0x8014) and needs "
+                      "ln_lora_s / ln_lora_c (lora_down = A . gamma); forward form, no split-K");
         SLH_CHECK(d->ln_in_chunks >= 1 && d->ln_in_chunks <= 20 && d->K == 64 * d->ln_in_chunks,
                   "slh_gemm: ln_in_chunks must be K / 64 (<= 20)");
         SLH_CHECK(((uintptr_t)d->ln_in & 7) == 0 && ((uintptr_t)d->ln_s & 15) == 0 && ((uintptr_t)d->ln_b & 15) == 0,
@@ -778,6 +783,7 @@ extern "C" int slh_gemm(const slh_gemm_desc* d, slh_stream_t stream) {
         a.splitk = 1;
     }
     a.store16 = (d->ldc % 8 == 0) && (((uintptr_t)d->c & 15) == 0);
+    a.ln_lora_s = d->ln_lora_s; a.ln_lora_c = d->ln_lora_c;
     a.xa_k = (const __bf16*)d->xa_k; a.xa_vt = (const __bf16*)d->xa_vt;
     a.xa_tk = d->xa_tk; a.xa_tq = d->xa_tq; a.xa_ldk = d->xa_ldk; a.xa_ldvt = d->xa_ldvt; a.xa_vt_heads = d->xa_vt_heads;
     a.xa_scale = d->xa_scale;

@@ -520,7 +520,8 @@ __global__ __launch_bounds__(512, 2) void gemm8pb_kernel(const GemmArgs p) {
     };
 
     float ln_mean[MI], ln_rstd[MI];
-    const bool ln_on = MODE == 0 && !LORA && p.ln_in != nullptr;
+    // with LORA: the adapter's down-projection is folded too (ln_lora_*; NI <= 4: the 128 x 320 tile has no registers left for it)
+    const bool ln_on = MODE == 0 && (!LORA || NI <= 4) && p.ln_in != nullptr;
     {
         f32x2 ln_pairs[MI][LN_MAXC];
         if (MODE == 0 && ln_on) {
@@ -631,7 +632,7 @@ __global__ __launch_bounds__(512, 2) void gemm8pb_kernel(const GemmArgs p) {
 
     // NI = 4 (128 x 256): a wave's 128 columns lie on one side of vt_col0 (a multiple of 128), so the fused q|k|v projection can
     // write its V third head-transposed from here as well (FEAT bit 1); the odd-NI tiles keep the trimmed epilogue
-    gemm_epilogue<MI, NI, MODE, LORA, NW, WN, (NI == 4 && MODE == 0) ? 1 : 0>(p, smem, acc, accl, ln_mean, ln_rstd, ln_on, tile_m, tile_n, ks_id, wave, wm, wn);
+    gemm_epilogue<MI, NI, MODE, LORA, NW, WN, ((NI == 4 && MODE == 0) ? 1 : 0) | ((LORA && MODE == 0 && NI <= 4) ? 16 : 0)>(p, smem, acc, accl, ln_mean, ln_rstd, ln_on, tile_m, tile_n, ks_id, wave, wm, wn);
 }
 
 }  // namespace

@@ -35,6 +35,7 @@ struct GemmArgs {
     int ln_in_chunks; float ln_eps;
     // cross-attention behind the query projection (slh_gemm_desc.xa_*)
     const __bf16* xa_k; const __bf16* xa_vt; int xa_tk, xa_tq, xa_ldk, xa_ldvt, xa_vt_heads; float xa_scale;
+    const float* ln_lora_s; const float* ln_lora_c;   // LayerNorm fold of the fused adapter's down-projection (slh_gemm_desc.ln_lora_*)
     int sk_per;  // stream-K (slh_gemm_desc.tile bits 20-21): K-tile units per workgroup; 0 = one tile (or K slice) per workgroup
     int probe;   // ablation builds only (-DSLH_GEMM_PROBE, scripts/build_variant.sh): 1 skip tile refills, 2 skip MFMA work,
                  // 4 skip the epilogue, 8 skip the first tile fill, 16 return at once; the default build ignores it
@@ -205,7 +206,8 @@ constexpr int gemm_epilogue_lds(int MI, int NI, int NW, int WN, bool LORA) {
 // (MFMA operand roles swapped: W rows feed the A operand, activation rows the B operand).  Must be entered by all waves of the
 // workgroup with the operand stages in `smem` no longer in use by the K loop's LDS-DMA (they are recycled as staging patches).
 // FEAT: optional forms a K loop's tiles can take - 1 the head-transposed V store (vt_out), 2 the 32 | 32 GEGLU forms (geglu = 1, 2),
-// 4 the LayerNorm chunk statistics (ln_out), 8 cross-attention behind the query projection (xa_k; MI = 1, NI = 2 only); compiled out
+// 4 the LayerNorm chunk statistics (ln_out), 8 cross-attention behind the query projection (xa_k; MI = 1, NI = 2 only), 16 the folded
+// LayerNorm (ln_in) together with a fused adapter; compiled out
 // where slh_gemm never routes them (registers and code of the odd-NI tiles)
 template <int MI, int NI, int MODE, bool LORA, int NW, int WN, int FEAT = 7>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, char* smem, f32x16 (&acc)[MI][NI], f32x16 (&accl)[MI],
@@ -518,6 +520,36 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, char* smem, f32
     } else {
         __syncthreads();                       // the column vectors are in LDS
     }
+    bool ln_done = false;
+    if constexpr ((FEAT & 16) != 0 && LORA && MODE == 0) {
+        if (ln_on) {
+            // Linear(LayerNorm(x)) + LoRA(LayerNorm(x)) from the raw rows: the main product is normalised HERE, ahead of the
+            // up-projection MFMA that adds the adapter term into the same accumulators, and the down-projection T (lora_down
+            // holds A . gamma) by the same algebra with the adapter's own row sums / offsets:
+            //   y = rstd (x W'^T - mean s) + b' + scale * B . bf16(rstd (x A'^T - mean sA) + cA)
+            ln_done = true;
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+#pragma unroll
+                for (int j = 0; j < NI; ++j)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int cl = wn * (32 * NI) + j * 32 + q * 8 + lhi * 4;
+                        const f32x4 s4 = *(const f32x4*)(sCol + 2 * BN + cl), b4 = *(const f32x4*)(sCol + 3 * BN + cl);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) acc[i][j][q * 4 + e] = ln_rstd[i] * (acc[i][j][q * 4 + e] - ln_mean[i] * s4[e]) + b4[e];
+                    }
+                // rank index of accl[i][e]: e < 4 -> e + 4 lhi, e >= 4 -> 8 + (e - 4) in the lhi = 0 half (unused in the other)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int rank = e < 4 ? e + 4 * lhi : 4 + e;
+                    const bool live = rank < p.lora_rank && (e < 4 || lhi == 0);
+                    const float sa = p.ln_lora_s[live ? rank : 0], ca = p.ln_lora_c[live ? rank : 0];
+                    accl[i][e] = live ? ln_rstd[i] * (accl[i][e] - ln_mean[i] * sa) + ca : accl[i][e];
+                }
+            }
+        }
+    }
     bool xa = false;
     if constexpr ((FEAT & 8) != 0 && MI == 1 && NI == 2 && !LORA) {
         if (p.xa_k != nullptr) {
@@ -646,7 +678,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, char* smem, f32
             }
         }
     }
-    const bool epi_ln = ln_on && !xa, epi_bias = p.bias != nullptr && !xa;     // (the fused attention consumed them with Q)
+    const bool epi_ln = ln_on && !xa && !ln_done, epi_bias = p.bias != nullptr && !xa;     // (consumed above where xa / ln_done)
     char* sE = smem + wave * (32 * S * 16);
     const float lscale = (LORA || p.lora_t != nullptr) ? *p.lora_scale : 0.f;
     const int ncol0 = n0 + wn * (32 * NI);

@@ -591,7 +591,46 @@ __global__ __launch_bounds__(256) void temb_lora_bwd_kernel(const slh_temb_lora_
         for (int r = 0; r < 4; ++r) d.d_down[(long)r * d.ted + k] += s * U[r] * x;
     }
 }
+// adapter side of a LayerNorm fold (slh_lora_ln_fold): one workgroup per (row, item); fixed-order sums (wave shuffles + LDS)
+__global__ __launch_bounds__(256) void lora_ln_fold_kernel(const slh_lora_lnfold_item* items) {
+    const slh_lora_lnfold_item it = items[blockIdx.y];
+    const int r = blockIdx.x;
+    if (r >= it.rows) return;
+    __shared__ float red[2][4];
+    const int tid = threadIdx.x;
+    const __bf16* a = (const __bf16*)it.a + (long)r * it.K;
+    __bf16* o = (__bf16*)it.a_out + (long)r * it.K;
+    float s = 0.f, c = 0.f;
+    for (int k = tid * 8; k < it.K; k += 256 * 8) {
+        const bf16x8 av = *(const bf16x8*)(a + k);
+        const bf16x8 gv = *(const bf16x8*)((const __bf16*)it.gamma + k);
+        const bf16x8 bv = *(const bf16x8*)((const __bf16*)it.beta + k);
+        bf16x8 ov;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            ov[e] = (__bf16)((float)av[e] * (float)gv[e]);
+            s += (float)ov[e];
+            c += (float)av[e] * (float)bv[e];
+        }
+        *(bf16x8*)(o + k) = ov;
+    }
+    s = wave_sum(s);
+    c = wave_sum(c);
+    if ((tid & 63) == 0) { red[0][tid >> 6] = s; red[1][tid >> 6] = c; }
+    __syncthreads();
+    if (tid == 0) {
+        it.s_out[r] = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+        it.c_out[r] = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+    }
+}
 }  // namespace
+
+extern "C" int slh_lora_ln_fold(const slh_lora_lnfold_desc* d, slh_stream_t stream) {
+    SLH_CHECK(d && d->items && d->n > 0, "slh_lora_ln_fold: null pointer / empty");
+    hipLaunchKernelGGL(lora_ln_fold_kernel, dim3(16, d->n), dim3(256), 0, (hipStream_t)stream, d->items);
+    SLH_LAUNCH_CHECK("slh_lora_ln_fold");
+    return 0;
+}
 
 extern "C" int slh_lora_conv_dgrad(const slh_lora_cdgrad_desc* d, slh_stream_t stream) {
     SLH_CHECK(d && d->u && d->a_down && d->scale && d->gx, "slh_lora_conv_dgrad: null pointer");

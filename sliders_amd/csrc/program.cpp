@@ -66,6 +66,7 @@ extern "C" int slh_run_program(const void* program, int64_t nbytes, slh_stream_t
             case SLH_OP_GN_STATS: rc = run_desc<slh_gn_desc>(p, sz, slh_gn_stats, stream, "gn_stats"); break;
             case SLH_OP_GN_APPLY: rc = run_desc<slh_gn_desc>(p, sz, slh_gn_apply, stream, "gn_apply"); break;
             case SLH_OP_GN_FUSED: rc = run_desc<slh_gn_desc>(p, sz, slh_gn_fused, stream, "gn_fused"); break;
+            case SLH_OP_LORA_LN_FOLD: rc = run_desc<slh_lora_lnfold_desc>(p, sz, slh_lora_ln_fold, stream, "lora_ln_fold"); break;
             case SLH_OP_LAYERNORM: rc = run_desc<slh_ln_desc>(p, sz, slh_layernorm, stream, "layernorm"); break;
             case SLH_OP_ATTN_FWD: rc = run_desc<slh_attn_desc>(p, sz, slh_attn_fwd, stream, "attn_fwd"); break;
             case SLH_OP_TRANSPOSE_HEADS:
@@ -187,7 +188,7 @@ extern "C" int slh_desc_sizes(int32_t* out, int32_t cap) {
         (int32_t)sizeof(slh_lora_cdgrad_desc), (int32_t)sizeof(slh_temb_lora_bwd_desc),
         (int32_t)sizeof(slh_sgemm_desc),    (int32_t)sizeof(slh_gn32_desc),     (int32_t)sizeof(slh_softmax32_desc),
         (int32_t)sizeof(slh_vae_conv_desc), (int32_t)sizeof(slh_vae_sample_desc), (int32_t)sizeof(slh_lion_desc),
-        (int32_t)sizeof(slh_batch_desc),    (int32_t)sizeof(slh_gather16_desc)};
+        (int32_t)sizeof(slh_batch_desc),    (int32_t)sizeof(slh_gather16_desc), (int32_t)sizeof(slh_lora_lnfold_desc)};
     const int n = (int)(sizeof(sizes) / sizeof(sizes[0]));
     for (int i = 0; i < n && i < cap; ++i) out[i] = sizes[i];
     return n;

@@ -163,6 +163,7 @@ class UNetPlan:
         self.lora_scale_ptr = lora_scale_ptr
         self.prog = lib.Program()
         self.tape: List[dict] = []
+        self.lnfold_items: List[tuple] = []       # adapter sides of LayerNorm folds (slh_lora_lnfold_item as int64 words)
         self.zmark = zarena.mark()
         self._build_io(io)
         self._forward()
@@ -172,6 +173,10 @@ class UNetPlan:
         if self.zend > self.zmark:
             p, n = zarena.region(self.zmark, self.zend)
             head.memset(p, n, 0, "zero_stats")
+        if self.lnfold_items:
+            self._lnfold_table = torch.tensor(self.lnfold_items, dtype=torch.int64, device=self.lora.params.device)
+            head.add(lib.OP_LORA_LN_FOLD, lib.LoraLnFoldDesc(items=self._lnfold_table.data_ptr(), n=len(self.lnfold_items)),
+                     "lora_ln_fold")
         head.extend(self.prog)
         self.prog = head
         # The text K/V of every cross-attention block depend only on the prompt embeddings (and frozen weights): inside a
@@ -180,7 +185,7 @@ class UNetPlan:
         # share the arena) and io["ctx"] is unchanged - the caller's responsibility (trainer / sampler loops).
         self.prog_text_cached = None
         if self.kv_all is not None:
-            skip = {"attn2_kv_all", "attn2_vt_all"}
+            skip = {"attn2_kv_all", "attn2_vt_all", "lora_ln_fold"}     # (the adapters do not change inside a denoise loop either)
             pc = lib.Program()
             for (op, d), nm in zip(self.prog.ops, self.prog.op_names):
                 if nm not in skip:
@@ -255,7 +260,7 @@ class UNetPlan:
              w_ptr: Optional[int] = None, bias_ptr: Optional[int] = None, vt_heads: Optional[int] = None,
              ln_stats: bool = False, ln_fold: Optional[Act] = None, geglu_pre: Optional[Act] = None,
              ln_mr: Optional[Buf] = None, tape_x: Optional[Act] = None, geglu16: bool = False,
-             xattn: Optional[dict] = None) -> Optional[Act]:
+             xattn: Optional[dict] = None, ln_norm: Optional[str] = None) -> Optional[Act]:
         """y = x . W^T (+bias)(+rowbias per sample)(+LoRA)(+residual).  conv: {'stride','xform'} for 3x3.
         vt_heads: the product is a fused q|k|v projection of that many heads; where the kernel supports it (no-grad
         passes, head_dim % 64 == 0) its V third is written head-transposed for slh_attn_fwd straight from the epilogue
@@ -269,7 +274,10 @@ class UNetPlan:
         in for the normalised tensor that was never written (a key for the gradient chain: nothing reads its memory).
         xattn = {k, vt_ptr, vt_heads, Tk, Tq, scale}: the product is attn2.to_q and, when the tile that runs is the 128 x 128 ring
         tile, the cross-attention behind it happens in its epilogue (slh_gemm_desc.xa_*): the returned activation is then the
-        attention output and self.xattn_done says so."""
+        attention output and self.xattn_done says so.
+        ln_fold together with lora_paths (ln_norm = the LayerNorm's weight name): the adapter's down-projection is folded as well
+        (slh_gemm_desc.ln_lora_*; A . gamma and its row sums / offsets are rebuilt from the live parameters by ONE
+        slh_lora_ln_fold launch at the head of the program) - only on the ping-pong tiles; None when another tile would run."""
         self.xattn_done = False
         x0, x1 = _src_parts(x)
         cin = x0.C + (x1.C if x1 else 0)
@@ -341,6 +349,15 @@ class UNetPlan:
         if ln_fold is not None:
             if ((d.tile >> 16) & 15) > 1 or (not d.tile and splitk_wanted(d)):
                 return None
+            if grp is not None:
+                if not fused or ln_norm is None or (d.tile >> 12) & 15 != 8 or (d.tile >> 4) & 15 != 1 or (d.tile & 15) > 4:
+                    return None                   # (the 128-register tiles of gemm.hip have no room for the second fold)
+                R = 4 * len(grp)
+                a2 = self.arena.alloc((R, K), torch.bfloat16, name + ".lnA")
+                sc = self.f32((2, 16), name + ".lnA_sc")
+                d.lora_down, d.ln_lora_s, d.ln_lora_c = a2.ptr, sc.ptr, sc.ptr + 64
+                self.lnfold_items.append((self.lora.down_ptr(grp[0]), self.w.ptr(ln_norm + ".g"), self.w.ptr(ln_norm + ".b"),
+                                          a2.ptr, sc.ptr, sc.ptr + 64, R | (K << 32)))
             if ln_mr is not None:
                 d.ln_mr_out = ln_mr.ptr
         else:
@@ -411,8 +428,18 @@ class UNetPlan:
         """Linear(LayerNorm(h)): folded into one product when h's producer left row statistics, the consumer carries no adapter
         and the pass keeps no tape; the LayerNorm launch + the plain product otherwise."""
         grp = self._lora_group(lora_paths) if lora_paths else None
-        if grp is None and h.ln is not None and getattr(self.w, "ln_fold", False) and \
-                self.w.has(wname + ".lnw") and h.C % 64 == 0 and h.C <= 1280 and h.ld == h.C:
+        foldable = h.ln is not None and getattr(self.w, "ln_fold", False) and \
+            self.w.has(wname + ".lnw") and h.C % 64 == 0 and h.C <= 1280 and h.ld == h.C
+        if grp is not None and foldable and not self.train and not geglu and os.environ.get("SLIDERS_NO_LORA_LN_FOLD") is None:
+            # adapter-carrying consumer (q|k|v under noxattn): the fold covers the adapter's down-projection too
+            amark, nallocs, nitems = self.arena.mark(), len(self.arena.allocs), len(self.lnfold_items)
+            y = self.gemm(h, wname, N, wname, bias=False, lora_paths=lora_paths, vt_heads=vt_heads, ln_fold=h, ln_norm=norm)
+            if y is not None:
+                return y
+            self.arena.reset(amark)
+            del self.arena.allocs[nallocs:]
+            del self.lnfold_items[nitems:]
+        if grp is None and foldable:
             if not self.train:
                 amark, nallocs = self.arena.mark(), len(self.arena.allocs)
                 y = self.gemm(h, wname, N, wname, bias=False, geglu=geglu, vt_heads=vt_heads, ln_fold=h,

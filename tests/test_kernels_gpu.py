@@ -432,6 +432,66 @@ def test_gemm_layernorm_folded(dev, C, offset):
         lib.call(lib.OP_GEMM, bad, stream())
 
 
+@pytest.mark.parametrize("tile", [0x8014, 0x8013])
+@pytest.mark.parametrize("offset", [0.0, 20.0])
+def test_gemm_layernorm_folded_with_fused_adapter(dev, tile, offset):
+    """norm1 folded into the adapter-carrying q|k|v projection (slh_gemm_desc.ln_in + lora_down + ln_lora_s / ln_lora_c): the main
+    product AND the adapter's down-projection are computed from the raw rows and normalised in the epilogue, ahead of the
+    up-projection; A . gamma, its row sums and A . beta come from slh_lora_ln_fold.  Against the reference's op sequence
+    (LayerNorm -> bf16 -> Linear + LoRA with T rounded to bf16), with the V third written head-transposed as in production."""
+    from sliders_amd.weights import fold_layernorm
+    torch.manual_seed(int(offset) + tile)
+    B, T, heads, D = 2, 192, 4, 64
+    C = heads * D
+    M, N, K = B * T, 3 * C, C
+    x = bf(torch.randn(M, K, device=dev) * 1.5 + offset)
+    w = bf(torch.randn(N, K, device=dev) / math.sqrt(K))
+    gamma, beta = bf(torch.randn(K, device=dev) * 0.5 + 1.0), bf(torch.randn(K, device=dev) * 0.3)
+    A = bf(torch.randn(12, K, device=dev) / math.sqrt(K))
+    up = bf(torch.randn(N, 4, device=dev))
+    scale = torch.tensor([0.5], device=dev)
+    xc = x.float().view(M, K // 64, 64)
+    mean = xc.mean(-1)
+    chunks = torch.stack([mean, ((xc - mean[..., None]) ** 2).sum(-1)], -1).permute(1, 0, 2).contiguous()
+    wf, sv, bp = fold_layernorm(w, None, gamma, beta)
+    # adapter side of the fold, by the library
+    A2 = torch.zeros_like(A)
+    sc = torch.full((2, 16), float("nan"), device=dev)
+    items = torch.tensor([[p(A), p(gamma), p(beta), p(A2), sc.data_ptr(), sc.data_ptr() + 64, 12 | (K << 32)]], dtype=torch.int64, device=dev)
+    lib.call(lib.OP_LORA_LN_FOLD, lib.LoraLnFoldDesc(items=items.data_ptr(), n=1), stream())
+    torch.cuda.synchronize()
+    A2_ref = bf(A.float() * gamma.float())
+    assert torch.equal(A2, A2_ref)
+    assert float((sc[0, :12] - A2_ref.float().sum(1)).abs().max()) < 1e-4
+    assert float((sc[1, :12] - A.float() @ beta.float()).abs().max()) < 1e-4
+    c = torch.full((M, N), 7.0, device=dev, dtype=torch.bfloat16)
+    vt = torch.full((B, heads, D, T), 7.0, device=dev, dtype=torch.bfloat16)
+    d = lib.GemmDesc(a0=p(x), w=p(wf), c=p(c), lora_down=p(A2), lora_up=p(up), lora_scale=p(scale), lda0=K, ca0=K, mode=0, stride=1,
+                     ldw=K, M=M, N=N, K=K, ldc=N, rows_per_sample=T, ld_t=12, lora_groups=3, lora_rank=12, tile=tile,
+                     ln_in=p(chunks), ln_in_chunks=K // 64, ln_s=p(sv), ln_b=p(bp), ln_eps=1e-5,
+                     ln_lora_s=sc.data_ptr(), ln_lora_c=sc.data_ptr() + 64)
+    if tile == 0x8014:
+        d.vt_out, d.vt_col0, d.vt_D, d.vt_heads, d.vt_tokens, d.vt_ld = p(vt), 2 * C, D, heads, T, T
+    lib.call(lib.OP_GEMM, d, stream())
+    torch.cuda.synchronize()
+    ln = bf(F.layer_norm(x.float(), (K,), gamma.float(), beta.float(), 1e-5)).float()
+    Tt = bf(ln @ A.float().t() * 0.5).float()
+    ref = ln @ w.float().t()
+    for g in range(3):
+        ref[:, g * C:(g + 1) * C] += Tt[:, 4 * g:4 * g + 4] @ up.float()[g * C:(g + 1) * C].t()
+    if tile == 0x8014:
+        report(f"ln + fused adapter tile{tile:x} off{offset} q|k", c[:, :2 * C], ref[:, :2 * C], TOL)
+        report(f"ln + fused adapter tile{tile:x} off{offset} v^T", vt, ref[:, 2 * C:].reshape(B, T, heads, D).permute(0, 2, 3, 1), TOL)
+    else:
+        report(f"ln + fused adapter tile{tile:x} off{offset}", c, ref, TOL)
+    # the adapter term is really there (and normalised): without it the result is off by its size
+    eff = ((ref - ln @ w.float().t()).norm() / ref.norm()).item()
+    assert eff > 0.05
+    d.tile = 0x4012
+    with pytest.raises(lib.SlidersHipError, match="ln_in with a fused adapter"):
+        lib.call(lib.OP_GEMM, d, stream())
+
+
 @pytest.mark.parametrize("fold", [False, True])
 @pytest.mark.parametrize("Tk", [77, 64, 96, 5])
 def test_gemm_fused_cross_attention(dev, fold, Tk):
