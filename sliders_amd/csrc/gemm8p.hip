@@ -522,14 +522,12 @@ __global__ __launch_bounds__(512, 2) void gemm8pb_kernel(const GemmArgs p) {
     float ln_mean[MI], ln_rstd[MI];
     // with LORA: the adapter's down-projection is folded too (ln_lora_*; NI <= 4: the 128 x 320 tile has no registers left for it)
     const bool ln_on = MODE == 0 && (!LORA || NI <= 4) && p.ln_in != nullptr;
-    {
-        f32x2 ln_pairs[MI][LN_MAXC];
-        if (MODE == 0 && ln_on) {
-            gemm_ln_request<MI>(p, m0 + wm * (32 * MI), lrow, ln_pairs);
-            gemm_ln_finish<MI>(p, m0 + wm * (32 * MI), lrow, tile_n == 0 && wn == 0 && lhi == 0, ln_pairs, ln_mean, ln_rstd);
-        }
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // nothing of the compiler's own loads is pending when the counting starts
+    // The chunk statistics of a folded LayerNorm are requested AHEAD of the prologue's LDS-DMA (older in the in-order vmcnt queue:
+    // the counted wait below retires them with the first units) and merged behind it - requested and merged in front of it they
+    // were a serial round trip at the head of a kernel that owns its CU alone.
+    f32x2 ln_pairs[MI][LN_MAXC];
+    if (MODE == 0 && ln_on) gemm_ln_request_hidden<MI>(p, m0 + wm * (32 * MI), lrow, ln_pairs);
 
     // ---- prologue: tile 0 complete + the phase-0 units of tile 1 in flight; the phase-0 units of tile 0 landed -----------------
     issue_unit(0, 0);
@@ -538,6 +536,10 @@ __global__ __launch_bounds__(512, 2) void gemm8pb_kernel(const GemmArgs p) {
     issue_unit(0, BUF);
     issue_unit(1, BUF);
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(G) : "memory");
+    if (MODE == 0 && ln_on) {
+        gemm_ln_landed<MI>(ln_pairs);
+        gemm_ln_finish<MI>(p, m0 + wm * (32 * MI), lrow, tile_n == 0 && wn == 0 && lhi == 0, ln_pairs, ln_mean, ln_rstd);
+    }
 
     f32x16 acc[MI][NI];
 #pragma unroll

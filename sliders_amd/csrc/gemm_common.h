@@ -162,6 +162,32 @@ __device__ __forceinline__ void gemm_ln_request(const GemmArgs& p, int row0, int
     }
 }
 
+// The same requests issued from inline asm, i.e. invisible to hipcc's waitcnt bookkeeping (ping-pong kernels: the loads go out ahead
+// of the prologue's LDS-DMA - older in the in-order vmcnt queue, retired by the prologue's own counted wait - and hipcc, which
+// does not see the DMA, would otherwise drain everything with vmcnt(0) in front of the first use).  Unconditional loads at a
+// clamped chunk index.  The caller waits (counted vmcnt covering these loads) and then calls gemm_ln_landed.
+template <int MI>
+__device__ __forceinline__ void gemm_ln_request_hidden(const GemmArgs& p, int row0, int lrow, f32x2 (&pairs)[MI][LN_MAXC]) {
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+        int m = row0 + i * 32 + lrow;
+        m = m < p.M ? m : p.M - 1;
+        const f32x2* src = (const f32x2*)p.ln_in + m;
+#pragma unroll
+        for (int c = 0; c < LN_MAXC; ++c) {
+            const f32x2* q = src + (long)(c < p.ln_in_chunks ? c : 0) * p.M;
+            asm volatile("global_load_dwordx2 %0, %1, off" : "=&v"(pairs[i][c]) : "v"(q) : "memory");
+        }
+    }
+}
+template <int MI>
+__device__ __forceinline__ void gemm_ln_landed(f32x2 (&pairs)[MI][LN_MAXC]) {      // pins the first uses behind the caller's wait
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int c = 0; c < LN_MAXC; ++c) asm volatile("" : "+v"(pairs[i][c]));
+}
+
 // row0: first row of the wave's sub-tile; writer: this lane also stores the merged pairs (ln_mr_out)
 template <int MI>
 __device__ __forceinline__ void gemm_ln_finish(const GemmArgs& p, int row0, int lrow, bool writer, const f32x2 (&pairs)[MI][LN_MAXC],
