@@ -24,6 +24,7 @@ python $R/scripts/make_pmc_traffic.py $O/r04_pmc_fetch_size_fwd_lora_on.csv $O/r
 cd $R
 # the bench line reads the counter file of THIS tree (copied next to the sources on the box)
 cp $O/r04_pmc_traffic.json $R/profiles/r04_pmc_traffic.json
+cp $O/r04_pmc_mfma_busy_fwd_lora_on.csv $R/profiles/r04_pmc_mfma_busy_fwd_lora_on.csv      # (mfma_util_pmc is read from the newest committed file)
 timeout 600 python bench.py > $O/r04_bench_line.json 2> $O/r04_bench_line.err
 timeout 300 python scripts/time_train_iter.py --breakdown > $O/r04_iteration_pieces.txt 2>&1
 timeout 200 python scripts/probe_gn.py > $O/r04_probe_gn.txt 2>&1
