@@ -483,6 +483,15 @@ def main():
             torch.cuda.empty_cache()
             try:
                 extra.append(run_config(b, dev, world, rank, main_line=False))
+                if workload == "image":
+                    # the same loop with the VAE in exact-fp32 MFMA arithmetic (the reference declares its VAE fp32; the default
+                    # here is the bf16 hi/lo split, 16 mantissa bits per operand): quoted beside the split-mode rate
+                    b2 = argparse.Namespace(**vars(b))
+                    b2.vae_exact_fp32, b2.no_roofline = True, True
+                    torch.cuda.empty_cache()
+                    r2 = run_config(b2, dev, world, rank, main_line=False)
+                    extra[-1]["value_with_exact_fp32_vae"] = r2.get("value")
+                    extra[-1]["ms_per_step_with_exact_fp32_vae"] = r2.get("ms_per_step")
             except Exception as e:          # the contract line must survive whatever an extra configuration does
                 extra.append({"config": {"workload": f"{model} {workload} {res_px}"}, "error": f"{type(e).__name__}: {e}"})
         res["extra_configs"] = extra
