@@ -76,6 +76,7 @@ class _FakeWeights:
         self.kv_all_vbase = 0
         self.gemm_shape = {}
         self.ln_fold = True
+        self.geglu16 = True          # WeightStore's default: GEGLU.proj also in the 16 | 16 block order
 
     def ptr(self, name):
         return 0x1000
@@ -160,7 +161,22 @@ def test_planner_fusions_of_the_no_grad_pass(name, hw):
     assert all(d.geglu_pre for o, d in pt.prog.ops if o == lib.OP_GEMM and d.geglu)
     assert sum(1 for o, d in pt.prog.ops if o == lib.OP_GEMM and d.geglu) == n_self
     if p.prog_text_cached is not None:
-        assert p.prog_text_cached.n_ops == p.prog.n_ops - 2
+        assert p.prog_text_cached.n_ops == p.prog.n_ops - 2 - sum(1 for o, _ in ops if o == lib.OP_LORA_LN_FOLD)
+    # round 4: GEGLU.proj in the 16 | 16 block order in the no-grad passes (any tile), the 32 | 32 order with geglu_pre in training
+    assert all(d.geglu == 3 for o, d in ops if o == lib.OP_GEMM and d.geglu)
+    assert all(d.geglu == 1 for o, d in pt.prog.ops if o == lib.OP_GEMM and d.geglu)
+    n_fold = sum(1 for o, d in ops if o == lib.OP_GEMM and d.ln_in and d.lora_down)
+    n_head = sum(1 for o, _ in ops if o == lib.OP_LORA_LN_FOLD)
+    if name == "sdxl":
+        # norm1 folded into the adapter-carrying q|k|v of the 1280-channel level (60 blocks; its tuned tile is the 128 x 256
+        # ping-pong tile): one slh_lora_ln_fold launch at the head of the program rebuilds A . gamma for all of them, and only the
+        # 640-channel level keeps its LayerNorm launches
+        assert n_fold == 60 and n_head == 1 and p.prog.ops[1][0] == lib.OP_LORA_LN_FOLD and p.prog.ops[1][1].n == 60
+        assert all(d.ln_lora_s and d.ln_lora_c and (d.tile >> 12) & 15 == 8 and d.vt_out for o, d in ops if o == lib.OP_GEMM and d.ln_in and d.lora_down)
+        assert sum(1 for o, _ in ops if o == lib.OP_LAYERNORM) == 10           # of 210 LayerNorms: norm1 of the ten 640-channel blocks
+    else:
+        assert n_fold == 0 and n_head == 0
+    assert not any(d.ln_in and d.lora_down for o, d in pt.prog.ops if o == lib.OP_GEMM), "training passes keep the LayerNorm launch"
 
 
 def test_checkpoint_file_is_reference_loadable(tmp_path):
