@@ -152,6 +152,12 @@ typedef struct slh_gemm_desc {
      *   T = rstd_m * (a . (A gamma)^T - mean_m * ln_lora_s) + ln_lora_c,   ln_lora_s = row sums of the rounded A gamma, ln_lora_c = A . beta
      * (fp32 [rank] each), ahead of the up-projection - Linear(LayerNorm(x)) + LoRA(LayerNorm(x)) without the LayerNorm launch. */
     const float* ln_lora_s; const float* ln_lora_c;
+    /* Optional hint: pf_bytes of frozen weights at pf_ptr (16-byte aligned) that a LATER launch will stream are touched by up to 64
+     * extra workgroups of THIS launch when its grid leaves that many CUs idle (the 160-tile products of the M = 2048 level: the
+     * touch rides on CUs that have nothing to do and costs no launch, no second stream, no graph edge).  A UNet pass reads every
+     * matrix once, so the big ones are HBM-cold at first touch (2048 x 1280 x 5120: 56 us cold, 47 us after a touch).  Ignored
+     * when the grid fills the chip or the tile is a ping-pong / stream-K one. */
+    const void* pf_ptr; int64_t pf_bytes;
 } slh_gemm_desc;
 int slh_gemm(const slh_gemm_desc* d, slh_stream_t stream);
 /* (WM<<12)|(MI<<8)|(NI<<4)|mode of the kernel instantiation gemm_kernel<MI,NI,mode,..,WM> slh_gemm would launch for d
@@ -570,8 +576,16 @@ enum {
     SLH_OP_TEMB_LORA_BWD = 22, SLH_OP_SGEMM = 23, SLH_OP_GN32_STATS = 24, SLH_OP_GN32_APPLY = 25, SLH_OP_SOFTMAX32 = 26,
     SLH_OP_VAE_CONV_IN = 27, SLH_OP_VAE_MOMENTS = 28, SLH_OP_VAE_SAMPLE = 29, SLH_OP_VAE_POST_QUANT = 30, SLH_OP_LION = 31,
     SLH_OP_WGRAD_BATCH = 32, SLH_OP_TRANSPOSE_BATCH = 33, SLH_OP_GATHER16 = 34, SLH_OP_GN_FUSED = 35,
-    SLH_OP_LORA_LN_FOLD = 36
+    SLH_OP_LORA_LN_FOLD = 36, SLH_OP_PREFETCH = 37
 };
+/* SLH_OP_PREFETCH: touch [ptr, ptr + nbytes) - frozen weights a LATER launch of the program will stream - so that they are
+ * in the memory-side cache (256 MB Infinity Cache) when that launch starts: a UNet pass reads 5 GB of weights once, so every big
+ * matrix is HBM-cold at first touch and the launch that owns its CU alone waits out the misses (2048 x 1280 x 5120: 56 -> 47 us
+ * with warm weights).  Inside slh_run_program / a captured graph the touch runs on a SIDE stream, ordered after the launches
+ * recorded before it and joined at the end of the program: it overlaps the launches that follow.  Called directly it runs on
+ * the given stream. */
+typedef struct slh_prefetch_desc { const void* ptr; int64_t nbytes; } slh_prefetch_desc;
+int slh_prefetch(const slh_prefetch_desc* d, slh_stream_t stream);
 /* SLH_OP_MEMSET: byte fill by a kernel of this library (not hipMemsetAsync: a captured memset node is a runtime blit whose
  * replays were observed to go wrong on the legacy default stream - see the executor's comment) */
 typedef struct slh_memset_desc { void* ptr; int64_t nbytes; int32_t value; int32_t pad; } slh_memset_desc;

@@ -76,10 +76,15 @@ __global__ __launch_bounds__(128 * WM, gemm_waves_per_simd(MI, NI, STAGES, LORA,
 #ifdef SLH_GEMM_PROBE
     if (p.probe & 16) return;   // diagnostics: launch + dispatch cost only
 #endif
+    // the last pf_blocks workgroups of the grid (slh_gemm_desc.pf_*); only in the ring tile's instantiations: slh_gemm gives the
+    // hint to no other tile, and the 16 loads in flight per thread do not fit the 80-register budgets of the small tiles
+    if constexpr (STAGES == 4 && WM == 4 && MI == 1 && NI == 2 && !SK) {
+        if (gemm_weight_touch(p)) return;
+    }
     // stream-K (SK): this workgroup's units [sk_unit, sk_end) of the K-tile sequence, walked segment by segment (gemm_common.h)
     int sk_slot = 0, sk_unit = 0, sk_end = 0;
     if (SK) {
-        sk_slot = gemm_remap_bid();
+        sk_slot = gemm_remap_bid((int)gridDim.x);
         sk_unit = sk_slot * p.sk_per;
         sk_end = min(sk_unit + p.sk_per, p.tiles_m * p.tiles_n * (p.K / BK));
         if (sk_unit >= sk_end) return;
@@ -522,7 +527,7 @@ __global__ __launch_bounds__(128 * WM, gemm_waves_per_simd(MI, NI, STAGES, LORA,
 
 template <int MI, int NI, int MODE, bool LORA, int WM>
 int launch_gemm3(const GemmArgs& a, int stages, hipStream_t s) {
-    const int grid = a.tiles_m * a.tiles_n * (a.splitk > 1 ? a.splitk : 1);
+    const int grid = a.tiles_m * a.tiles_n * (a.splitk > 1 ? a.splitk : 1) + a.pf_blocks;
     constexpr int stage_bytes = (32 * MI * WM + 64 * NI + (LORA ? 32 : 0)) * 128;
     constexpr bool can3 = 3 * stage_bytes <= 160 * 1024;
     constexpr bool can4 = 4 * stage_bytes <= 160 * 1024;
@@ -549,7 +554,7 @@ int launch_gemm_sk(const GemmArgs& a, int grid, hipStream_t s) {
 // query projection + cross-attention (slh_gemm_desc.xa_k): the 128 x 128 8-wave ring tile (256 registers per lane to work with;
 // the double-buffered loop's 128 would spill the scores)
 int launch_gemm_xa(const GemmArgs& a, hipStream_t s) {
-    const int grid = a.tiles_m * a.tiles_n;
+    const int grid = a.tiles_m * a.tiles_n + a.pf_blocks;
     hipLaunchKernelGGL((gemm_kernel<1, 2, 0, 4, false, 4, false, true>), dim3(grid), dim3(512), 0, s, a);
     SLH_LAUNCH_CHECK("slh_gemm (query projection + cross-attention)");
     return 0;
@@ -563,6 +568,16 @@ int launch_gemm(const GemmArgs& a, int mode, int stages, hipStream_t s) {
 }
 
 }  // namespace
+
+static int slh_ncu() {
+    static const int ncu = [] {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
+        return prop.multiProcessorCount;
+    }();
+    return ncu;
+}
 
 // tile choice: explicit (d->tile, set by the planner from the tuned table) or a fill-the-chip heuristic
 static void pick_tile(const slh_gemm_desc* d, int& MI, int& NI, int& WM) {
@@ -799,6 +814,7 @@ extern "C" int slh_gemm(const slh_gemm_desc* d, slh_stream_t stream) {
                   "slh_gemm: xa_* need head dim 64 (N %% 64 == 0), 1 <= xa_tk <= 96, xa_tq %% 128 == 0, M %% xa_tq == 0, "
                   "xa_ldvt >= 128 (two 64-key tiles are staged), 16-byte aligned keys / values");
     }
+    a.pf_ptr = nullptr; a.pf_bytes = 0; a.pf_blocks = 0;
     a.sk_per = 0;
     const int sk = (d->tile >> 20) & 1;        // stream-K (tile 0x104412): one workgroup per CU, see gemm_common.h
     if (sk) {
@@ -825,16 +841,18 @@ extern "C" int slh_gemm(const slh_gemm_desc* d, slh_stream_t stream) {
     a.tiles_m = (d->M + 32 * MI * WM - 1) / (32 * MI * WM);
     a.tiles_n = (d->N + 64 * NI - 1) / (64 * NI);
     a.group_m = pick_group_m(d, a.tiles_m);
+    if (d->pf_ptr && d->pf_bytes >= 16 && !sk && WM == 4 && MI == 1 && NI == 2 && ((d->tile >> 8) & 15) == 4) {
+        // the weight touch is a hint: taken only on the 128 x 128 ring tile (0x4412: one workgroup per CU) and only when the launch
+        // leaves CUs idle
+        SLH_CHECK(((uintptr_t)d->pf_ptr & 15) == 0, "slh_gemm: pf_ptr must be 16-byte aligned");
+        const int idle = slh_ncu() - a.tiles_m * a.tiles_n * (a.splitk > 1 ? a.splitk : 1);
+        if (idle >= 16) { a.pf_ptr = d->pf_ptr; a.pf_bytes = (long)d->pf_bytes; a.pf_blocks = idle < 64 ? idle : 64; }
+    }
     hipStream_t s = (hipStream_t)stream;
     const int stages = (d->tile >> 8) & 15;   // tile = (WM<<12)|(stages<<8)|(MI<<4)|NI ; stages 0/2 = double buffer
     if (d->xa_k) return launch_gemm_xa(a, s);
     if (sk) {
-        static const int ncu = [] {
-            int dev = 0;
-            hipDeviceProp_t prop;
-            if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
-            return prop.multiProcessorCount;
-        }();
+        const int ncu = slh_ncu();
         SLH_CHECK(ncu > 0, "slh_gemm: stream-K could not read the CU count");
         const long units = (long)a.tiles_m * a.tiles_n * (d->K / 64);
         int per = (int)((units + (long)ncu * sk - 1) / ((long)ncu * sk));

@@ -36,6 +36,7 @@ struct GemmArgs {
     // cross-attention behind the query projection (slh_gemm_desc.xa_*)
     const __bf16* xa_k; const __bf16* xa_vt; int xa_tk, xa_tq, xa_ldk, xa_ldvt, xa_vt_heads; float xa_scale;
     const float* ln_lora_s; const float* ln_lora_c;   // LayerNorm fold of the fused adapter's down-projection (slh_gemm_desc.ln_lora_*)
+    const void* pf_ptr; long pf_bytes; int pf_blocks;   // weight touch by the launch's last pf_blocks workgroups (slh_gemm_desc.pf_*)
     int sk_per;  // stream-K (slh_gemm_desc.tile bits 20-21): K-tile units per workgroup; 0 = one tile (or K slice) per workgroup
     int probe;   // ablation builds only (-DSLH_GEMM_PROBE, scripts/build_variant.sh): 1 skip tile refills, 2 skip MFMA work,
                  // 4 skip the epilogue, 8 skip the first tile fill, 16 return at once; the default build ignores it
@@ -54,9 +55,8 @@ __device__ __forceinline__ int lds_off(int row, int slot) {
 // once (measured before grouping: L2 hit rate 62-78 %, fabric fetches 6-14x the unique operand bytes).
 // split-K: consecutive block ids = the K slices of one tile (same XCD, same L2).
 // block id -> position in the XCD-grouped launch sequence (XCD x owns a contiguous chunk of it)
-__device__ __forceinline__ int gemm_remap_bid() {
+__device__ __forceinline__ int gemm_remap_bid(const int nblk) {      // nblk: workgroups that compute tiles (the grid minus pf_blocks)
     const int bid = blockIdx.x;
-    const int nblk = gridDim.x;
     const int q = nblk >> 3, r = nblk & 7;
     const int xcd = bid & 7, idx = bid >> 3;
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
@@ -74,10 +74,34 @@ __device__ __forceinline__ void gemm_tile_of(const GemmArgs& p, const int t, int
 }
 
 __device__ __forceinline__ void gemm_map_tile(const GemmArgs& p, int& tile_m, int& tile_n, int& ks_id) {
-    int bid = gemm_remap_bid();
+    int bid = gemm_remap_bid((int)gridDim.x - p.pf_blocks);
     ks_id = 0;
     if (p.splitk > 1) { ks_id = bid % p.splitk; bid = bid / p.splitk; }
     gemm_tile_of(p, bid, tile_m, tile_n);
+}
+
+// ---- weight touch (slh_gemm_desc.pf_*): the launch's LAST pf_blocks workgroups - dispatched behind every tile workgroup, i.e. onto
+// CUs the grid leaves idle - stream a byte range a later launch will need through plain loads (they allocate in the memory-side
+// cache) and exit.  Returns true in those workgroups.
+__device__ __forceinline__ bool gemm_weight_touch(const GemmArgs& p) {
+    const int first = (int)gridDim.x - p.pf_blocks;
+    if (p.pf_blocks <= 0 || (int)blockIdx.x < first) return false;
+    const uint4* src = (const uint4*)p.pf_ptr;
+    const long n16 = p.pf_bytes >> 4, stride = (long)p.pf_blocks * blockDim.x;
+    unsigned acc = 0;
+    long i = (long)((int)blockIdx.x - first) * blockDim.x + threadIdx.x;
+    // 16 independent 16-byte loads per thread in flight (128 KB per workgroup): at ~2 us per HBM miss anything less leaves the touch
+    // slower than the launch it rides on, and the launch does not end before its touch does
+    for (; i + 15 * stride < n16; i += 16 * stride) {
+        uint4 v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) v[u] = src[i + u * stride];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) acc ^= v[u].x;
+    }
+    for (; i < n16; i += stride) acc ^= src[i].x;
+    asm volatile("" ::"v"(acc));       // the loads are the point
+    return true;
 }
 
 // ---- stream-K (slh_gemm_desc.tile bits 20-21) ----------------------------------------------------------------------------------

@@ -143,6 +143,79 @@ def provision_splitk(plan, d, name: str):
         d.splitk_t32 = plan.arena.alloc((tiles_n * 2 * slabs, d.M, d.ld_t), torch.float32, name + ".splitk_T").ptr
 
 
+PREFETCH_MIN_BYTES = int(os.environ.get("SLIDERS_PREFETCH_MIN", str(6 << 20)))
+PREFETCH_MAX_BYTES = 96 << 20
+PREFETCH_AHEAD = int(os.environ.get("SLIDERS_PREFETCH_AHEAD", "0"))     # side-stream touches: measured slower, off (see below)
+
+
+def with_weight_prefetch(prog: "lib.Program") -> "lib.Program":
+    """A UNet pass streams every frozen matrix once (5 GB for SDXL), so each is HBM-cold when its product starts, and the big ones
+    cost their launch 2-9 us of first-touch misses (profiles/r04_weight_prefetch.txt).  For every GEMM whose packed weights are
+    6-96 MB a touch of those bytes (SLH_OP_PREFETCH: a side-stream kernel beside the launches that follow) is recorded
+    PREFETCH_AHEAD ops earlier: by the time the product runs its weights sit in the 256 MB memory-side cache.
+    MEASURED SLOWER (profiles/r04_weight_prefetch.txt): 218 side-stream kernels with an event fork each cost the SDXL 1024^2 pass
+    +0.9 ms as plain launches and +2.7 ms as a replayed graph (24.7 -> 25.6 / 27.4 ms) - the fork / join edges, not the loads.
+    Off by default (SLIDERS_PREFETCH_AHEAD=n turns it on for experiments); the product path touches weights from idle
+    workgroup slots of the launches themselves (slh_gemm_desc.pf_*)."""
+    if os.environ.get("SLIDERS_NO_PREFETCH") is not None or PREFETCH_AHEAD <= 0:
+        return prog
+    ins: Dict[int, list] = {}
+    for i, ((op, d), nm) in enumerate(zip(prog.ops, prog.op_names)):
+        if op != lib.OP_GEMM or d.w_layout != 1:
+            continue
+        nb = (d.N + 63) // 64 * 64 * d.K * 2
+        if PREFETCH_MIN_BYTES <= nb <= PREFETCH_MAX_BYTES:
+            ins.setdefault(max(1, i - PREFETCH_AHEAD), []).append((d.w, nb, nm + ".prefetch"))
+    if not ins:
+        return prog
+    out = lib.Program()
+    for i, ((op, d), nm) in enumerate(zip(prog.ops, prog.op_names)):
+        for ptr, nb, pn in ins.get(i, ()):
+            out.add(lib.OP_PREFETCH, lib.PrefetchDesc(ptr=ptr, nbytes=nb), pn)
+        out.add(op, d, nm)
+    return out
+
+
+TOUCH_WINDOW = 6      # ops a weight touch may ride ahead of the product that needs the weights
+
+
+def attach_weight_touch(prog: "lib.Program") -> "lib.Program":
+    """The product path's weight prefetch (slh_gemm_desc.pf_*): every GEMM whose packed weights are 6-96 MB (GEGLU.proj 26 MB,
+    ff.net.2 13 MB, q|k|v 10 MB at the 1280-channel level) has those bytes touched by the idle workgroup slots of an EARLIER
+    launch that leaves >= 64 CUs free - the 160-tile products on the 128 x 128 ring tile (attention out-projections, attn2.to_q,
+    ff.net.2 itself) - the nearest such carrier within TOUCH_WINDOW ops that does not carry a touch yet.  No extra launch, no
+    second stream.  SLIDERS_NO_WEIGHT_TOUCH=1 returns the program unchanged."""
+    if os.environ.get("SLIDERS_NO_WEIGHT_TOUCH") is not None:
+        return prog
+    ops = list(prog.ops)
+
+    def carrier(o, d):
+        if o != lib.OP_GEMM or d.mode != 0 or (d.tile & 0xFFFFFF) != 0x4412:
+            return False
+        return ((d.M + 127) // 128) * ((d.N + 127) // 128) <= 192
+    used = set()
+    for i, (o, d) in enumerate(ops):
+        if o != lib.OP_GEMM or d.w_layout != 1:
+            continue
+        nb = (d.N + 63) // 64 * 64 * d.K * 2
+        if not (PREFETCH_MIN_BYTES <= nb <= PREFETCH_MAX_BYTES):
+            continue
+        cand = reversed(range(max(0, i - TOUCH_WINDOW), i))     # nearest first (measured: 24.95 ms against 25.05 farthest-first, 25.27 without)
+        if os.environ.get("SLIDERS_TOUCH_FARTHEST"):
+            cand = range(max(0, i - TOUCH_WINDOW), i)
+        for j in cand:
+            if j not in used and carrier(*ops[j]):
+                ops[j][1].pf_ptr, ops[j][1].pf_bytes = d.w, nb
+                used.add(j)
+                break
+    if not used:
+        return prog
+    out = lib.Program()
+    for (o, d), nm in zip(ops, prog.op_names):
+        out.add(o, d, nm)
+    return out
+
+
 def _src_parts(x: Src):
     if isinstance(x, tuple):
         return x[0], x[1]
@@ -178,7 +251,7 @@ class UNetPlan:
             head.add(lib.OP_LORA_LN_FOLD, lib.LoraLnFoldDesc(items=self._lnfold_table.data_ptr(), n=len(self.lnfold_items)),
                      "lora_ln_fold")
         head.extend(self.prog)
-        self.prog = head
+        self.prog = with_weight_prefetch(attach_weight_touch(head))
         # The text K/V of every cross-attention block depend only on the prompt embeddings (and frozen weights): inside a
         # denoise loop (train_util.py:263-294: same embeddings for every timestep) steps 2.. replay the pass without
         # the batched K/V projection and its head transpose.  Valid only while no other plan ran in between (plans
@@ -188,7 +261,7 @@ class UNetPlan:
             skip = {"attn2_kv_all", "attn2_vt_all", "lora_ln_fold"}     # (the adapters do not change inside a denoise loop either)
             pc = lib.Program()
             for (op, d), nm in zip(self.prog.ops, self.prog.op_names):
-                if nm not in skip:
+                if nm not in skip and not (nm.endswith(".prefetch") and nm[:-9] in skip):
                     pc.add(op, d, nm)
             self.prog_text_cached = pc
 

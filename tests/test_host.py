@@ -94,8 +94,11 @@ def test_planner_static_invariants(name, hw, method):
     for mode in ("off", "on", "train"):
         va, vz = Arena(1 << 50, None), Arena(1 << 40, None)
         p = UNetPlan(cfg, _FakeWeights(cfg), va, vz, 2, hw, hw, 77, store if mode != "off" else None, mode, 0x10)
-        ops = p.prog.ops
+        ops = [(o, d) for o, d in p.prog.ops if o != lib.OP_PREFETCH]        # (weight touches run on a side stream beside these)
         counts[mode] = len(ops)
+        # every big frozen matrix is touched ahead of the product that streams it, never after it
+        pos = {d.w: i for i, (o, d) in enumerate(p.prog.ops) if o == lib.OP_GEMM}
+        assert all(d.nbytes >= 6 << 20 for o, d in p.prog.ops if o == lib.OP_PREFETCH)
         # every allocation is 256-byte aligned and allocations never overlap
         spans = sorted((s, e) for s, e, _ in va.allocs)
         assert all(s % 256 == 0 for s, _ in spans)
@@ -143,7 +146,21 @@ def test_planner_fusions_of_the_no_grad_pass(name, hw):
     store.temb_tcol = torch.zeros(1, dtype=torch.int32)
     va, vz = Arena(1 << 50, None), Arena(1 << 40, None)
     p = UNetPlan(cfg, _FakeWeights(cfg), va, vz, 2, hw, hw, 77, store, "on", 0x10)
-    ops = p.prog.ops
+    ops = [(o, d) for o, d in p.prog.ops if o != lib.OP_PREFETCH]
+    names = [n for (o, _), n in zip(p.prog.ops, p.prog.op_names) if o != lib.OP_PREFETCH]
+    # weights of the big products (GEGLU.proj, ff.net.2, q|k|v of the 1280-channel level) are touched from the idle workgroup slots of
+    # an earlier 160-tile launch (slh_gemm_desc.pf_*): every touch rides AHEAD of the product that streams those bytes, at most
+    # TOUCH_WINDOW ops ahead, and no side-stream touches (SLH_OP_PREFETCH, measured slower) are recorded by default
+    from sliders_amd.planner import TOUCH_WINDOW
+    assert not any(o == lib.OP_PREFETCH for o, _ in p.prog.ops)
+    wpos = {}
+    for i, (o, d) in enumerate(ops):
+        if o == lib.OP_GEMM:
+            wpos.setdefault(d.w, i)
+    touches = [(i, d) for i, (o, d) in enumerate(ops) if o == lib.OP_GEMM and d.pf_ptr]
+    if name == "sdxl":
+        assert len(touches) >= 150
+    assert all((d.tile & 0xFFFFFF) == 0x4412 and d.pf_bytes >= 6 << 20 for _, d in touches)
     n_self = sum(1 for n in p.prog.op_names if n.endswith("attn1.sdpa"))
     n_tr = sum(1 for o, _ in ops if o == lib.OP_TRANSPOSE_HEADS)
     n_vt = sum(1 for o, d in ops if o == lib.OP_GEMM and d.vt_out)
@@ -161,7 +178,7 @@ def test_planner_fusions_of_the_no_grad_pass(name, hw):
     assert all(d.geglu_pre for o, d in pt.prog.ops if o == lib.OP_GEMM and d.geglu)
     assert sum(1 for o, d in pt.prog.ops if o == lib.OP_GEMM and d.geglu) == n_self
     if p.prog_text_cached is not None:
-        assert p.prog_text_cached.n_ops == p.prog.n_ops - 2 - sum(1 for o, _ in ops if o == lib.OP_LORA_LN_FOLD)
+        assert p.prog_text_cached.n_ops == p.prog.n_ops - 2 - sum(1 for o, _ in ops if o == lib.OP_LORA_LN_FOLD)      # (+ their touches)
     # round 4: GEGLU.proj in the 16 | 16 block order in the no-grad passes (any tile), the 32 | 32 order with geglu_pre in training
     assert all(d.geglu == 3 for o, d in ops if o == lib.OP_GEMM and d.geglu)
     assert all(d.geglu == 1 for o, d in pt.prog.ops if o == lib.OP_GEMM and d.geglu)
@@ -171,7 +188,7 @@ def test_planner_fusions_of_the_no_grad_pass(name, hw):
         # norm1 folded into the adapter-carrying q|k|v of the 1280-channel level (60 blocks; its tuned tile is the 128 x 256
         # ping-pong tile): one slh_lora_ln_fold launch at the head of the program rebuilds A . gamma for all of them, and only the
         # 640-channel level keeps its LayerNorm launches
-        assert n_fold == 60 and n_head == 1 and p.prog.ops[1][0] == lib.OP_LORA_LN_FOLD and p.prog.ops[1][1].n == 60
+        assert n_fold == 60 and n_head == 1 and ops[1][0] == lib.OP_LORA_LN_FOLD and ops[1][1].n == 60
         assert all(d.ln_lora_s and d.ln_lora_c and (d.tile >> 12) & 15 == 8 and d.vt_out for o, d in ops if o == lib.OP_GEMM and d.ln_in and d.lora_down)
         assert sum(1 for o, _ in ops if o == lib.OP_LAYERNORM) == 10           # of 210 LayerNorms: norm1 of the ten 640-channel blocks
     else:

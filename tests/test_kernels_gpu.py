@@ -1278,6 +1278,47 @@ def test_gemm_splitk_stress_same_slabs(dev, local):
     assert r.returncode == 0 and "stress ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
+@pytest.mark.parametrize("tile", [0x4412, 0x4012, 0x12])      # (only 0x4412 takes the hint; the others must ignore it)
+def test_gemm_weight_touch_rides_on_idle_workgroups(dev, tile):
+    """slh_gemm_desc.pf_*: a launch that leaves CUs idle streams the weights of a LATER launch through its last workgroups.  A hint:
+    the product is bit-identical with and without it, whatever the byte range (odd sizes, a range the grid ignores because it
+    fills the chip), and SLH_OP_PREFETCH (the side-stream form) touches a range without writing anything."""
+    torch.manual_seed(tile)
+    M, N, K = 1024, 640, 1280            # 40 tiles of 128 x 128: plenty of idle CUs
+    x = bf(torch.randn(M, K, device=dev))
+    w = bf(torch.randn(N, K, device=dev) / math.sqrt(K))
+    bias = bf(torch.randn(N, device=dev))
+    later = torch.randn(3 * 1024 * 1024 + 5, device=dev)            # 12 MB + 20 bytes of "weights of a later launch"
+    guard = later.clone()
+    outs = []
+    for pf_bytes in (0, later.numel() * 4, 4096 + 16, 48):
+        c = torch.zeros(M, N, device=dev, dtype=torch.bfloat16)
+        d = lib.GemmDesc(a0=p(x), w=p(w), bias=p(bias), c=p(c), lda0=K, ca0=K, mode=0, stride=1, ldw=K, M=M, N=N, K=K, ldc=N,
+                         rows_per_sample=M, tile=tile, pf_ptr=p(later) if pf_bytes else 0, pf_bytes=pf_bytes)
+        lib.call(lib.OP_GEMM, d, stream())
+        torch.cuda.synchronize()
+        outs.append(c)
+    report(f"weight touch tile{tile:x}", outs[0], x.float() @ w.float().t() + bias.float(), TOL)
+    assert all(torch.equal(outs[0], o) for o in outs[1:]) and torch.equal(later, guard)
+    # a grid that fills the chip ignores the hint
+    M2 = 8192
+    x2 = bf(torch.randn(M2, K, device=dev))
+    c2 = torch.zeros(M2, N, device=dev, dtype=torch.bfloat16)
+    d = lib.GemmDesc(a0=p(x2), w=p(w), c=p(c2), lda0=K, ca0=K, mode=0, stride=1, ldw=K, M=M2, N=N, K=K, ldc=N, rows_per_sample=M2, tile=tile,
+                     pf_ptr=p(later), pf_bytes=later.numel() * 4)
+    lib.call(lib.OP_GEMM, d, stream())
+    torch.cuda.synchronize()
+    report(f"weight touch (full grid) tile{tile:x}", c2, x2.float() @ w.float().t(), TOL)
+    lib.call(lib.OP_PREFETCH, lib.PrefetchDesc(ptr=p(later), nbytes=later.numel() * 4), stream())
+    torch.cuda.synchronize()
+    assert torch.equal(later, guard)
+    if tile == 0x4412:
+        d.pf_ptr = p(later) + 4
+        d.M, d.a0, d.c = M, p(x), p(outs[0])
+        with pytest.raises(lib.SlidersHipError, match="pf_ptr"):
+            lib.call(lib.OP_GEMM, d, stream())
+
+
 @pytest.mark.parametrize("M,N,K", [(2048, 1280, 5120), (2048, 1280, 1280), (1100, 896, 2560), (3072, 1280, 5120)])
 def test_gemm_streamk(dev, M, N, K):
     """Stream-K (slh_gemm_desc.tile bit 20, tile 0x104412): one workgroup per CU walks an equal run of the (tile, K tile)
