@@ -30,6 +30,6 @@ timeout 300 python scripts/time_train_iter.py --breakdown > $O/r04_iteration_pie
 timeout 200 python scripts/probe_gn.py > $O/r04_probe_gn.txt 2>&1
 timeout 200 python scripts/probe_attn.py > $O/r04_probe_attn.txt 2>&1
 cut -c1-220 $O/r04_bench_line.json; cat $O/r04_fwd_kernel_gaps.txt | tail -3; head -4 $O/r04_pmc_mfma_busy_fwd_lora_on.csv | cut -c1-200
-# frozen B=3 pass beside the training forward on a second stream (SLIDERS_OVERLAP_FROZEN=1): same-box A/B of the contract line
-SLIDERS_OVERLAP_FROZEN=1 timeout 300 python bench.py --no-cpu-baseline --no-extra > $O/r04_bench_overlap_frozen.json 2> $O/r04_bench_overlap_frozen.err
-cut -c1-200 $O/r04_bench_overlap_frozen.json
+# frozen B=3 pass beside the training forward on a second stream (the default) against back to back (SLIDERS_OVERLAP_FROZEN=0): same-box A/B
+SLIDERS_OVERLAP_FROZEN=0 timeout 300 python bench.py --no-cpu-baseline --no-extra > $O/r04_bench_no_overlap_frozen.json 2> $O/r04_bench_no_overlap_frozen.err
+cut -c1-200 $O/r04_bench_no_overlap_frozen.json
