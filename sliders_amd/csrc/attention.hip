@@ -382,6 +382,172 @@ __global__ __launch_bounds__(64 * NW, DT == 1 ? (NW == 4 ? ATTN_OCC41 : 3) : ((D
 #endif
 }
 
+// ---- key-split form for grids that do not fill the SIMDs evenly (D = 64, whole key tiles, Tk % 128 == 0) -----------------------
+// SDXL at 1024^2: the 32 x 32 level has 1280 wave tiles of 32 queries for 1024 SIMDs - a quarter of the SIMDs run two waves, and the
+// time per key tile grows with the waves per SIMD (1400 + 1400 N cycles): the launch takes what TWO rounds take.  Here a workgroup is
+// 4 waves = 2 query tiles x 2 key halves: wave (qi, kh) runs queries qi over the key tiles of half kh, so 2560 half-length waves
+// spread as 2-3 per SIMD (1.5 rounds), and the two halves of a query tile meet in LDS at the end (fixed order: half 0 + half 1).
+// LDS per half: K double-buffered, V^T single-buffered (48 KB per workgroup -> three workgroups per CU, all 640 resident): the K
+// tile of step t+1 and the V^T tile of step t are requested at the top of step t (V^T first, so a counted vmcnt retires it while
+// K stays in flight), and a second barrier in front of P.V publishes V^T.
+__global__ __launch_bounds__(256, 3) void attn_fwd_ks_kernel(const slh_attn_desc p) {
+    __shared__ __attribute__((aligned(16))) char smem[2 * 24576];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int qi = wave & 1, kh = wave >> 1;
+    const int lrow = lane & 31, lhi = lane >> 5;
+    const int frow = lane >> 3, fslot = lane & 7;
+    int vb = blockIdx.x;
+    {
+        const int nblk = gridDim.x;
+        const int qd = nblk >> 3, rm = nblk & 7;
+        const int xcd = vb & 7, idx = vb >> 3;
+        vb = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + idx;
+    }
+    const int nqb = p.Tq >> 6;
+    const int qb = vb % nqb, hb = vb / nqb;
+    const int h = hb % p.H, b = hb / p.H;
+    const int qrow = qb * 64 + qi * 32 + lrow;
+    const int vt_heads = p.vt_batch_heads > 0 ? p.vt_batch_heads : p.H;
+    const __bf16* Q = (const __bf16*)p.q;
+    const __bf16* K = (const __bf16*)p.k;
+    const __bf16* VT = (const __bf16*)p.vt;
+
+    bf16x8 qf[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) qf[ks] = *(const bf16x8*)(Q + ((long)b * p.Tq + qrow) * p.ldq + h * 64 + ks * 16 + lhi * 8);
+
+    const int nth = (p.Tk >> 6) >> 1;                    // key tiles per half
+    // staging: the two waves of a half share its tiles; wave qi copies the 8-row groups qi, qi + 2, qi + 4, qi + 6
+    const __bf16* kp;
+    const __bf16* vp;
+    long khalf;
+    {
+        const int row = qi * 8 + frow;
+        const int ks = fslot ^ ((row >> 1) & 7);          // the same for rows row + 16 i
+        kp = K + ((long)b * p.Tk + (long)kh * nth * 64 + row) * p.ldk + h * 64 + ks * 8;
+        khalf = 16L * p.ldk;
+        vp = VT + (((long)b * vt_heads + h) * 64 + row) * p.ldvt + (long)kh * nth * 64 + ks * 8;
+    }
+    const unsigned base = lds_addr_of(smem) + kh * 24576;
+    long kstep = 64L * p.ldk;
+    auto stage_k = [&](const int buf) {      // (past the last tile: four pieces from the zero page into the idle buffer - the waits stay uniform)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) glds16_hidden(kp + i * khalf, base + buf * 8192 + (qi + 2 * i) * 1024);
+        kp += kstep;
+    };
+    auto stage_v = [&]() {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) glds16_hidden(vp + (long)i * 16 * p.ldvt, base + 16384 + (qi + 2 * i) * 1024);
+        vp += 64;
+    };
+
+    f32x16 o[2];
+#pragma unroll
+    for (int dd = 0; dd < 2; ++dd)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[dd][r] = 0.f;
+    float m_run = -1e30f, l_run = 0.f;
+    const f32x16 kZero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const float c = p.scale * 1.4426950408889634f;
+    const int prow = (lrow & 3) | (((lrow >> 3) & 1) << 2) | (((lrow >> 2) & 1) << 3) | (lrow & 16);
+    const char* sKh = smem + kh * 24576;
+    const char* cV = sKh + 16384;
+
+    stage_v();
+    stage_k(0);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) asm volatile("" ::"v"(qf[ks]));     // the Q loads are waited for here, not inside the loop
+    for (int t = 0; t < nth; ++t) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                // K(t) landed for every wave; every wave is past P.V of step t-1
+        if (t > 0) stage_v();                        // V^T(t) over V^T(t-1) ...
+        if (t + 1 == nth) { kp = (const __bf16*)slh_zero_page; khalf = 0; kstep = 0; }
+        stage_k((t + 1) & 1);                        // ... then K(t+1): the counted wait below retires V^T and leaves K in flight
+        const char* cK = sKh + (t & 1) * 8192;
+        f32x16 sc[2];
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const bf16x8 kf = *(const bf16x8*)(cK + lds_off(kt * 32 + prow, ks * 2 + lhi));
+                if (ks == 0) sc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[0], kZero16, 0, 0, 0);
+                else sc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], sc[kt], 0, 0, 0);
+            }
+        float mx = sc[0][0];
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sc[kt][r]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m_run, mx);
+        const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
+        const float mc = m_new * c;
+        m_run = m_new;
+        bf16x8 pb[2][2];
+        float ps = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[kt][r], c, -mc));
+                ps += pv;
+                pb[kt][r >> 3][r & 7] = (__bf16)pv;
+            }
+        l_run = l_run * alpha + ps;
+        if (__builtin_amdgcn_ballot_w64(alpha != 1.f) != 0) {
+#pragma unroll
+            for (int dd = 0; dd < 2; ++dd)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[dd][r] *= alpha;
+        }
+        // V^T(t): this wave's pieces have landed (the four K(t+1) pieces issued behind them may still fly), then everybody's
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+#pragma unroll
+        for (int dd = 0; dd < 2; ++dd)
+#pragma unroll
+            for (int kstep = 0; kstep < 4; ++kstep) {
+                const bf16x8 vf = *(const bf16x8*)(cV + lds_off(dd * 32 + lrow, kstep * 2 + lhi));
+                o[dd] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pb[kstep >> 1][kstep & 1], o[dd], 0, 0, 0);
+            }
+    }
+    float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    // ---- the two key halves of a query tile meet: half 1 leaves (O, m, l) in LDS, half 0 combines in a fixed order and stores --
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the zero-page pieces of the step past the end)
+    __syncthreads();                                  // every wave is done with the tiles
+    float* ex = (float*)smem + qi * (34 * 64);
+    if (kh == 1) {
+#pragma unroll
+        for (int dd = 0; dd < 2; ++dd)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) ex[(dd * 16 + r) * 64 + lane] = o[dd][r];
+        ex[32 * 64 + lane] = m_run;
+        ex[33 * 64 + lane] = l_tot;
+    }
+    __syncthreads();
+    if (kh == 1) return;
+    const float m1 = ex[32 * 64 + lane], l1 = ex[33 * 64 + lane];
+    const float m = fmaxf(m_run, m1);
+    const float a0 = __builtin_amdgcn_exp2f((m_run - m) * c), a1 = __builtin_amdgcn_exp2f((m1 - m) * c);
+    l_tot = l_tot * a0 + l1 * a1;
+    const float inv = 1.f / l_tot;
+    __bf16* O = (__bf16*)p.o + ((long)b * p.Tq + qrow) * p.ldo + h * 64;
+#pragma unroll
+    for (int dd = 0; dd < 2; ++dd)
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd) {
+            bf16x4 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int r = qd * 4 + e;
+                v[e] = (__bf16)((o[dd][r] * a0 + ex[(dd * 16 + r) * 64 + lane] * a1) * inv);
+            }
+            *(bf16x4*)(O + dd * 32 + qd * 8 + lhi * 4) = v;
+        }
+    if (p.lse && lhi == 0) p.lse[((long)b * p.H + h) * p.Tq + qrow] = m * c + log2f(l_tot);
+}
+
 // src [B][T][ld], head h = columns [h*D, (h+1)*D) -> dst [B][H][Dp][ldt], Dp = 64*ceil(D/64); rows d >= D and
 // tokens >= T are written as zeros.  grid = (ldt/64, H * Dp/64, B)
 __device__ __forceinline__ void transpose_heads_body(const slh_transpose_desc& p, int D, int DT, int bx, int by, int bz) {
@@ -442,6 +608,16 @@ int launch_fwd(const slh_attn_desc* d, hipStream_t s) {
     // 128-query workgroups once they fill every CU twice; below that the 64-query form (same waves per SIMD at most, finer
     // placement: T = 1024 with 40 heads 31.2 -> 28.9 us, same box).  (Capping the workgroups per CU with unused dynamic LDS so
     // that the dispatcher must spread them was tried: the hardware already places them evenly, the cap only delays backfill.)
+    // key-split form (attn_fwd_ks_kernel above): D = 64, whole key tiles in two equal halves, and a 64-query grid that neither
+    // fills every SIMD twice (>= 1024 workgroups) nor is so small that one round of full-length waves is cheaper
+    static const int knob_ks = getenv("SLH_ATTN_KS") ? atoi(getenv("SLH_ATTN_KS")) : 1;        // A/B: 0 = never
+    const long blocks2 = (long)(d->Tq / 64) * d->H * d->B;
+    if (DT == 1 && !tail && knob_ks && (d->D == 0 || d->D == 64) && d->Tq % 64 == 0 && d->Tk % 128 == 0 && d->Tk >= 256 &&
+        blocks4 < 512 && blocks2 > 128 && blocks2 <= 768) {
+        hipLaunchKernelGGL(attn_fwd_ks_kernel, dim3((unsigned)blocks2), dim3(256), 0, s, *d);
+        SLH_LAUNCH_CHECK("slh_attn_fwd (key split)");
+        return 0;
+    }
     if (blocks4 >= 512 && !knob_nw2) {
         const dim3 grid((unsigned)blocks4);
         if (tail) hipLaunchKernelGGL((attn_fwd_kernel<4, DT, true>), grid, dim3(256), 0, s, *d);

@@ -776,7 +776,10 @@ def test_layernorm(dev, C):
     report(f"layernorm_bwd C{C}", dx, xi.grad + dx_init.float(), 1.5e-2)
 
 
-@pytest.mark.parametrize("B,H,Tq,Tk,D", [(2, 5, 1024, 1024, 64), (1, 3, 192, 192, 64), (2, 4, 256, 77, 64),
+# (2, 5 / 10 / 20, 1024, 1024, 64) and (2, 10, 512, 256, 64) run the key-split form (attn_fwd_ks_kernel: 64-query grids of 129..768
+# workgroups, D = 64, Tk a multiple of 128), (3, 20, 1024, 1024, 64) - the frozen B = 3 pass - the plain 64-query form
+@pytest.mark.parametrize("B,H,Tq,Tk,D", [(2, 5, 1024, 1024, 64), (2, 20, 1024, 1024, 64), (2, 10, 1024, 1024, 64), (2, 10, 512, 256, 64),
+                                          (3, 20, 1024, 1024, 64), (1, 3, 192, 192, 64), (2, 4, 256, 77, 64),
                                           (1, 2, 100, 333, 64), (4, 8, 2048, 2048, 64), (2, 8, 1024, 1024, 40),
                                           (1, 8, 256, 77, 80), (2, 8, 64, 64, 160), (1, 4, 200, 77, 160), (1, 8, 96, 96, 8)])
 def test_attention_fwd(dev, B, H, Tq, Tk, D):
