@@ -86,7 +86,8 @@ typedef struct slh_gemm_desc {
                                 LayerNorm fold / vt_out; falls back to the plain launch when a run would be < 4 K tiles.
                                 Bit-reproducible.  The launch must have the GPU to itself: finishers wait on flags, so two
                                 stream-K launches that share the chip (two streams, two processes) can hold each other's
-                                CUs and deadlock (seen once with pytest-xdist workers; the wait is bounded and faults).
+                                CUs and stall (seen once with pytest-xdist workers; the wait is bounded: it gives up after about a minute
+                                and leaves that tile wrong).
                                 Measured slower than the plain launch on this chip (the workgroups no
                                 longer walk K in lockstep, so operand slices are not shared through L2): kept as a
                                 tested option, never chosen by the tuned tables (profiles/r04_streamk.txt) */
