@@ -158,12 +158,23 @@ def measure_roofline(eng, plan):
             pmj = json.load(f)
             pm = pmj["kernels"].get(kname.replace(", ", "; "))
             thead = pmj.get("tree_head")
-        from sliders_amd.srchash import kernel_source_hash
+        from sliders_amd.srchash import file_hashes, kernel_files, kernel_source_hash
         here_hash, there_hash = kernel_source_hash(), pmj.get("kernel_source_hash")
+        here_files, there_files = file_hashes(), pmj.get("file_hashes") or {}
+        need = kernel_files(kname, here_files)
+        same_kernel = bool(there_files) and set(here_files) == set(there_files) and all(here_files.get(f) == there_files.get(f) for f in need)
         if pm and there_hash == here_hash:
             traffic = pm["fetch_bytes_per_launch"] + pm["write_bytes_per_launch"]
             tsrc = (f"profiles/{os.path.basename(tpath)} (FETCH_SIZE x2 + WRITE_SIZE per launch, LoRA-on forward pass; counter passes "
                     f"taken on tree {thead or 'unrecorded'}, kernel sources + tile tables hash {there_hash} = this tree's)")
+        elif pm and same_kernel:
+            # other kernels changed since the counter passes; every file THIS kernel is built from, the public header and all tile
+            # tables are byte-identical to the tree the passes were taken on
+            changed = sorted(f for f in here_files if here_files[f] != there_files.get(f))
+            traffic = pm["fetch_bytes_per_launch"] + pm["write_bytes_per_launch"]
+            tsrc = (f"profiles/{os.path.basename(tpath)} (FETCH_SIZE x2 + WRITE_SIZE per launch, LoRA-on forward pass; counter passes "
+                    f"taken on tree {thead or 'unrecorded'}: {', '.join(need)} are byte-identical in this tree; changed since: "
+                    f"{', '.join(changed)})")
         else:
             # a counter file of OTHER kernels is not evidence about these: say so instead of pairing the numbers silently
             tsrc = (f"none: profiles/{os.path.basename(tpath)} was taken on kernel sources / tile tables hash {there_hash or 'unrecorded'}, "

@@ -84,11 +84,7 @@ typedef struct slh_gemm_desc {
                                 slab bytes) slabs) and are added in K order by the workgroup that holds a tile's first K
                                 tile (splitk_ticket = one zeroed 64-bit flag per workgroup); dense, no adapter / GEGLU /
                                 LayerNorm fold / vt_out; falls back to the plain launch when a run would be < 4 K tiles.
-                                Bit-reproducible.  The launch must have the GPU to itself: finishers wait on flags, so two
-                                stream-K launches that share the chip (two streams, two processes) can hold each other's
-                                CUs and stall (seen once with pytest-xdist workers; the wait is bounded: it gives up after about a minute
-                                and leaves that tile wrong).
-                                Measured slower than the plain launch on this chip (the workgroups no
+                                Bit-reproducible.  Measured slower than the plain launch on this chip (the workgroups no
                                 longer walk K in lockstep, so operand slices are not shared through L2): kept as a
                                 tested option, never chosen by the tuned tables (profiles/r04_streamk.txt) */
     int32_t lora_rank;       /* 0 = 4.  With lora_up_rmajor: total rank 4 | 8 | 12 (T has that many columns) */

@@ -8,7 +8,7 @@ import os
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from sliders_amd.srchash import kernel_source_hash
+from sliders_amd.srchash import file_hashes, kernel_source_hash
 
 
 def rows(path):
@@ -29,7 +29,7 @@ for r in rows(write):
     k["write_bytes_per_launch"] = int(1024 * float(r["WRITE_SIZE"]) / n)
     hit, miss = float(r["TCC_HIT_sum"]), float(r["TCC_MISS_sum"])
     k["l2_hit_rate"] = round(hit / (hit + miss), 3) if hit + miss > 0 else None
-res = {"tree_head": tree_head, "kernel_source_hash": kernel_source_hash(), "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum (separate passes, --kernel-trace only) over "
+res = {"tree_head": tree_head, "kernel_source_hash": kernel_source_hash(), "file_hashes": file_hashes(), "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum (separate passes, --kernel-trace only) over "
                  "LoRA-on SDXL 1024x1024 B=2 UNet passes (scripts/bench_forward.py --lora --warm 0 --iters 1: the first call "
                  "plus one replay); FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports 64 B per 128-B request); "
                  "WRITE_SIZE uncalibrated; KB -> bytes",

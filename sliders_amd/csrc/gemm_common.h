@@ -144,14 +144,7 @@ __device__ __forceinline__ void gemm_sk_collect(const GemmArgs& p, const int slo
     const __amdgpu_buffer_rsrc_t slabs = __builtin_amdgcn_make_buffer_rsrc(p.c32, 0, grid * tile_bytes, 0x00020000);
     for (int c = slot + 1; missing > 0; ++c, missing -= p.sk_per) {
         if (tid == 0) {
-            // bounded: the publisher is resident or about to be (the grid never exceeds the CU count) and needs nothing from this
-            // workgroup; a minute of polling means the launch contract was broken (the GPU shared with another waiting launch):
-            // give up - the tile comes out wrong, which the caller's checks see - rather than hang the queue for good
-            unsigned spins = 0;
-            while (__hip_atomic_load(p.ticket + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0ull) {
-                __builtin_amdgcn_s_sleep(8);
-                if (++spins > (1u << 25)) break;
-            }
+            while (__hip_atomic_load(p.ticket + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0ull) __builtin_amdgcn_s_sleep(4);
             __hip_atomic_store(p.ticket + c, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // left zero for the next launch
         }
         __syncthreads();
