@@ -60,6 +60,45 @@ def gemm_flops(d):
     return 2.0 * d.M * n * d.K
 
 
+def pmc_traffic_for(kname, profiles_dir=None):
+    """(bytes per launch, source note) of kernel `kname` from the newest committed counter passes (profiles/r*_pmc_traffic.json), or
+    (None, why): the figures are attached only when the tree this runs from is the tree the passes were taken on - as a whole, or in
+    every file the kernel is built from (sliders_amd/srchash.py)."""
+    import glob
+    traffic, tsrc = None, None
+    profiles_dir = profiles_dir or os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
+    cands = sorted(glob.glob(os.path.join(profiles_dir, "r*_pmc_traffic.json")))
+    if cands:                                   # PMC counters cannot be read from inside the timed process: the
+        tpath = cands[-1]                       # per-launch HBM-side bytes come from the newest committed --pmc passes
+        with open(tpath) as f:
+            pmj = json.load(f)
+            pm = pmj["kernels"].get(kname.replace(", ", "; "))
+            thead = pmj.get("tree_head")
+        from sliders_amd.srchash import file_hashes, kernel_files, kernel_source_hash
+        here_hash, there_hash = kernel_source_hash(), pmj.get("kernel_source_hash")
+        here_files, there_files = file_hashes(), pmj.get("file_hashes") or {}
+        need = kernel_files(kname, here_files)
+        same_kernel = bool(there_files) and set(here_files) == set(there_files) and all(here_files.get(f) == there_files.get(f) for f in need)
+        if pm and there_hash == here_hash:
+            traffic = pm["fetch_bytes_per_launch"] + pm["write_bytes_per_launch"]
+            tsrc = (f"profiles/{os.path.basename(tpath)} (FETCH_SIZE x2 + WRITE_SIZE per launch, LoRA-on forward pass; counter passes "
+                    f"taken on tree {thead or 'unrecorded'}, kernel sources + tile tables hash {there_hash} = this tree's)")
+        elif pm and same_kernel:
+            # other kernels changed since the counter passes; every file THIS kernel is built from, the public header and all tile
+            # tables are byte-identical to the tree the passes were taken on
+            changed = sorted(f for f in here_files if here_files[f] != there_files.get(f))
+            traffic = pm["fetch_bytes_per_launch"] + pm["write_bytes_per_launch"]
+            tsrc = (f"profiles/{os.path.basename(tpath)} (FETCH_SIZE x2 + WRITE_SIZE per launch, LoRA-on forward pass; counter passes "
+                    f"taken on tree {thead or 'unrecorded'}: {', '.join(need)} are byte-identical in this tree; changed since: "
+                    f"{', '.join(changed)})")
+        else:
+            # a counter file of OTHER kernels is not evidence about these: say so instead of pairing the numbers silently
+            tsrc = (f"none: profiles/{os.path.basename(tpath)} was taken on kernel sources / tile tables hash {there_hash or 'unrecorded'}, "
+                    f"this tree hashes {here_hash}" + ("" if pm else f"; it has no row for {kname}") +
+                    " - re-run scripts/measure_round4.sh")
+    return traffic, tsrc
+
+
 def measure_roofline(eng, plan):
     """Time EVERY launch of one LoRA-on UNet denoise pass IN SITU: the pass is replayed op by op in program order on the
     launch stream with a HIP event pair around each launch, so every kernel sees the cache state it sees in the real pass
@@ -149,37 +188,8 @@ def measure_roofline(eng, plan):
     achieved = g["flops"] / (g["ms"] * 1e-3) / 1e12
     table = {k: dict(calls_per_pass=x["calls"], ms_per_pass=round(x["ms"], 3),
                      tflops=round(x["flops"] / (x["ms"] * 1e-3) / 1e12, 1)) for k, x in sorted(groups.items())}
-    traffic, tsrc = None, None
+    traffic, tsrc = pmc_traffic_for(kname)
     import glob
-    cands = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r*_pmc_traffic.json")))
-    if cands:                                   # PMC counters cannot be read from inside the timed process: the
-        tpath = cands[-1]                       # per-launch HBM-side bytes come from the newest committed --pmc passes
-        with open(tpath) as f:
-            pmj = json.load(f)
-            pm = pmj["kernels"].get(kname.replace(", ", "; "))
-            thead = pmj.get("tree_head")
-        from sliders_amd.srchash import file_hashes, kernel_files, kernel_source_hash
-        here_hash, there_hash = kernel_source_hash(), pmj.get("kernel_source_hash")
-        here_files, there_files = file_hashes(), pmj.get("file_hashes") or {}
-        need = kernel_files(kname, here_files)
-        same_kernel = bool(there_files) and set(here_files) == set(there_files) and all(here_files.get(f) == there_files.get(f) for f in need)
-        if pm and there_hash == here_hash:
-            traffic = pm["fetch_bytes_per_launch"] + pm["write_bytes_per_launch"]
-            tsrc = (f"profiles/{os.path.basename(tpath)} (FETCH_SIZE x2 + WRITE_SIZE per launch, LoRA-on forward pass; counter passes "
-                    f"taken on tree {thead or 'unrecorded'}, kernel sources + tile tables hash {there_hash} = this tree's)")
-        elif pm and same_kernel:
-            # other kernels changed since the counter passes; every file THIS kernel is built from, the public header and all tile
-            # tables are byte-identical to the tree the passes were taken on
-            changed = sorted(f for f in here_files if here_files[f] != there_files.get(f))
-            traffic = pm["fetch_bytes_per_launch"] + pm["write_bytes_per_launch"]
-            tsrc = (f"profiles/{os.path.basename(tpath)} (FETCH_SIZE x2 + WRITE_SIZE per launch, LoRA-on forward pass; counter passes "
-                    f"taken on tree {thead or 'unrecorded'}: {', '.join(need)} are byte-identical in this tree; changed since: "
-                    f"{', '.join(changed)})")
-        else:
-            # a counter file of OTHER kernels is not evidence about these: say so instead of pairing the numbers silently
-            tsrc = (f"none: profiles/{os.path.basename(tpath)} was taken on kernel sources / tile tables hash {there_hash or 'unrecorded'}, "
-                    f"this tree hashes {here_hash}" + ("" if pm else f"; it has no row for {kname}") +
-                    " - re-run scripts/measure_round4.sh")
     # MFMA utilisation from the newest committed counter pass: SQ_VALU_MFMA_BUSY_CYCLES (32 per 32x32x16 MFMA, summed over
     # the SIMDs) / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs)
     def mfma_util(kernel_prefix):

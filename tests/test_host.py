@@ -593,3 +593,43 @@ def test_step_sampler_ranks_agree_on_shared_draws_including_dynamic_resolution()
     # the SD-1.x image-slider script draws k from 1 .. max-2 (train_lora-scale.py:186-188)
     s = StepSampler(1, 0, 1, 3, 49)
     assert max(s.next()[0] for _ in range(400)) == 48
+
+
+def test_bench_pairs_counter_traffic_only_with_identical_kernel_sources(tmp_path):
+    """bench.py attaches roofline.traffic (per-launch bytes from committed --pmc passes) only when the tree it runs from is the tree
+    the passes were taken on - as a whole, or in every file the reported kernel is built from (its translation unit, the headers it
+    includes, the public header, every tile table).  A changed file of ANOTHER kernel does not void the pairing; a changed file of
+    this kernel, a changed tile table or a counter file without per-file hashes does."""
+    import json
+    import bench
+    from sliders_amd import srchash
+    k = "gemm_kernel<1, 2, 0, 4, false, 4, false, false>"
+    here = srchash.file_hashes()
+    assert set(srchash.kernel_files(k, here)) >= {"gemm.hip", "gemm_common.h", "common.h", "sliders_hip.h"} and \
+        "attention.hip" not in srchash.kernel_files(k, here) and all(f in srchash.kernel_files(k, here) for f in here if f.endswith(".json"))
+    prof = tmp_path / "profiles"
+    prof.mkdir()
+
+    def write(fh, combined):
+        json.dump({"tree_head": "abc1234", "kernel_source_hash": combined, "file_hashes": fh,
+                   "kernels": {k.replace(", ", "; "): {"fetch_bytes_per_launch": 100, "write_bytes_per_launch": 23, "launches": 1}}},
+                  open(prof / "r09_pmc_traffic.json", "w"))
+    # 1. identical tree
+    write(dict(here), srchash.kernel_source_hash())
+    assert bench.pmc_traffic_for(k, str(prof))[0] == 123
+    # 2. another kernel's file changed since the passes: still this kernel's numbers
+    other = dict(here)
+    other["attention.hip"] = "0" * 16
+    write(other, "f" * 16)
+    t, src = bench.pmc_traffic_for(k, str(prof))
+    assert t == 123 and "attention.hip" in src and "byte-identical" in src
+    # 3. this kernel's own header changed / a tile table changed / no per-file hashes: no pairing
+    for bad in ("gemm_common.h", next(f for f in here if f.endswith(".json"))):
+        o2 = dict(here)
+        o2[bad] = "0" * 16
+        write(o2, "f" * 16)
+        assert bench.pmc_traffic_for(k, str(prof))[0] is None
+    write({}, "f" * 16)
+    t, src = bench.pmc_traffic_for(k, str(prof))
+    assert t is None and "re-run" in src
+
