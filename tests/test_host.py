@@ -79,7 +79,10 @@ class _FakeWeights:
         self.geglu16 = True          # WeightStore's default: GEGLU.proj also in the 16 | 16 block order
 
     def ptr(self, name):
-        return 0x1000
+        # a distinct, 256-byte aligned fake address per tensor name (the planner's weight-touch pass matches launches by pointer)
+        if not hasattr(self, "_ids"):
+            self._ids = {}
+        return 0x10000000 + 0x100 * self._ids.setdefault(name, len(self._ids) + 1)
 
     def has(self, name):
         return True
@@ -161,6 +164,10 @@ def test_planner_fusions_of_the_no_grad_pass(name, hw):
     if name == "sdxl":
         assert len(touches) >= 150
     assert all((d.tile & 0xFFFFFF) == 0x4412 and d.pf_bytes >= 6 << 20 for _, d in touches)
+    for j, dj in touches:       # the bytes a launch touches are the packed weights of a product at most TOUCH_WINDOW ops LATER
+        later = [d for o, d in ops[j + 1:j + 1 + TOUCH_WINDOW] if o == lib.OP_GEMM and d.w == dj.pf_ptr]
+        assert later and dj.pf_bytes == (later[0].N + 63) // 64 * 64 * later[0].K * 2, (j, hex(dj.pf_ptr))
+    assert len({d.pf_ptr for _, d in touches}) == len(touches), "no matrix is touched twice in a pass"
     n_self = sum(1 for n in p.prog.op_names if n.endswith("attn1.sdpa"))
     n_tr = sum(1 for o, _ in ops if o == lib.OP_TRANSPOSE_HEADS)
     n_vt = sum(1 for o, d in ops if o == lib.OP_GEMM and d.vt_out)
