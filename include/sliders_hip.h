@@ -79,14 +79,10 @@ typedef struct slh_gemm_desc {
                                 S: split-K factor (0|1 none), needs splitk_c32.
                                 WM = 8: ping-pong K loops, one 8-wave workgroup per CU (csrc/gemm8p.hip): 0x8042 = 256 x 256
                                 (no fused adapter), 0x801<NI> = 128 x 64*NI, NI = 3..5 (geglu 0 | 3 only, no ln_out / vt_out).
-                                Bit 20 (0x104412 only): stream-K - one workgroup per CU, each walking an equal run of the
-                                (tile, K tile) sequence; partial tiles go through splitk_c32 (at least ceil(#CUs * 64 KB /
-                                slab bytes) slabs) and are added in K order by the workgroup that holds a tile's first K
-                                tile (splitk_ticket = one zeroed 64-bit flag per workgroup); dense, no adapter / GEGLU /
-                                LayerNorm fold / vt_out; falls back to the plain launch when a run would be < 4 K tiles.
-                                Bit-reproducible.  Measured slower than the plain launch on this chip (the workgroups no
-                                longer walk K in lockstep, so operand slices are not shared through L2): kept as a
-                                tested option, never chosen by the tuned tables (profiles/r04_streamk.txt) */
+                                Bits 20 and up must be zero.  (Round 4 carried a stream-K form under bit 20 whose finishing
+                                workgroups waited on flags of other workgroups; it was slower than the plain launch on every
+                                shape and could hang two concurrent launches - removed: no kernel of this library waits on
+                                another workgroup, profiles/r04_streamk.txt keeps the measurement.) */
     int32_t lora_rank;       /* 0 = 4.  With lora_up_rmajor: total rank 4 | 8 | 12 (T has that many columns) */
     int32_t lora_up_rmajor;  /* 1: lora_up is [rank][N] (= lora_down as stored): backward-data LoRA term */
     int32_t w_layout;        /* 0: w is [N][ldw].  1: frozen weights repacked once at load time into the order the kernel
@@ -156,7 +152,7 @@ typedef struct slh_gemm_desc {
      * extra workgroups of THIS launch when its grid leaves that many CUs idle (the 160-tile products of the M = 2048 level: the
      * touch rides on CUs that have nothing to do and costs no launch, no second stream, no graph edge).  A UNet pass reads every
      * matrix once, so the big ones are HBM-cold at first touch (2048 x 1280 x 5120: 56 us cold, 47 us after a touch).  Ignored
-     * when the grid fills the chip or the tile is a ping-pong / stream-K one. */
+     * when the grid fills the chip or the tile is a ping-pong one. */
     const void* pf_ptr; int64_t pf_bytes;
 } slh_gemm_desc;
 int slh_gemm(const slh_gemm_desc* d, slh_stream_t stream);
@@ -224,6 +220,8 @@ typedef struct slh_gn_desc {
      * pairs in row-block order and leaves the cluster pair; slh_gn_apply adds the cluster pairs (double accumulation).
      * With R = slh_gn_row_blocks(c0+c1, hw, groups) and L = slh_gn_clusters(R): */
     float* partial;          /* [batch][R + L][groups][2] fp32 scratch, any contents; must stay untouched between the two launches */
+    /* No aliasing: slh_gn_apply re-reads the statistics' pivot (the first element of every group) from x0 / x1 in every workgroup,
+     * so y must be a different buffer (checked) and x must be unchanged between slh_gn_stats and slh_gn_apply. */
     uint32_t* ticket;        /* [batch][1 + L] arrival counters, ZERO before the launch (left zero by it) */
 } slh_gn_desc;
 int slh_gn_stats(const slh_gn_desc* d, slh_stream_t stream);
@@ -576,16 +574,8 @@ enum {
     SLH_OP_TEMB_LORA_BWD = 22, SLH_OP_SGEMM = 23, SLH_OP_GN32_STATS = 24, SLH_OP_GN32_APPLY = 25, SLH_OP_SOFTMAX32 = 26,
     SLH_OP_VAE_CONV_IN = 27, SLH_OP_VAE_MOMENTS = 28, SLH_OP_VAE_SAMPLE = 29, SLH_OP_VAE_POST_QUANT = 30, SLH_OP_LION = 31,
     SLH_OP_WGRAD_BATCH = 32, SLH_OP_TRANSPOSE_BATCH = 33, SLH_OP_GATHER16 = 34, SLH_OP_GN_FUSED = 35,
-    SLH_OP_LORA_LN_FOLD = 36, SLH_OP_PREFETCH = 37
+    SLH_OP_LORA_LN_FOLD = 36      /* 37 was SLH_OP_PREFETCH (side-stream weight touch: measured slower, removed in round 5) */
 };
-/* SLH_OP_PREFETCH: touch [ptr, ptr + nbytes) - frozen weights a LATER launch of the program will stream - so that they are
- * in the memory-side cache (256 MB Infinity Cache) when that launch starts: a UNet pass reads 5 GB of weights once, so every big
- * matrix is HBM-cold at first touch and the launch that owns its CU alone waits out the misses (2048 x 1280 x 5120: 56 -> 47 us
- * with warm weights).  Inside slh_run_program / a captured graph the touch runs on a SIDE stream, ordered after the launches
- * recorded before it and joined at the end of the program: it overlaps the launches that follow.  Called directly it runs on
- * the given stream. */
-typedef struct slh_prefetch_desc { const void* ptr; int64_t nbytes; } slh_prefetch_desc;
-int slh_prefetch(const slh_prefetch_desc* d, slh_stream_t stream);
 /* SLH_OP_MEMSET: byte fill by a kernel of this library (not hipMemsetAsync: a captured memset node is a runtime blit whose
  * replays were observed to go wrong on the legacy default stream - see the executor's comment) */
 typedef struct slh_memset_desc { void* ptr; int64_t nbytes; int32_t value; int32_t pad; } slh_memset_desc;

@@ -54,7 +54,7 @@ __device__ __forceinline__ f32x16 mfma_slot(const bf16x8 a, const bf16x8 b, f32x
 #endif
 }
 
-template <int MI, int NI, int MODE, int STAGES, bool LORA, int WM, bool SK = false, bool XA = false>
+template <int MI, int NI, int MODE, int STAGES, bool LORA, int WM, bool XA = false>
 __global__ __launch_bounds__(128 * WM, gemm_waves_per_simd(MI, NI, STAGES, LORA, WM)) void gemm_kernel(const GemmArgs p) {
     constexpr int NW = 2 * WM;
     constexpr int BM = 32 * MI * WM;
@@ -78,35 +78,16 @@ __global__ __launch_bounds__(128 * WM, gemm_waves_per_simd(MI, NI, STAGES, LORA,
 #endif
     // the last pf_blocks workgroups of the grid (slh_gemm_desc.pf_*); only in the ring tile's instantiations: slh_gemm gives the
     // hint to no other tile, and the 16 loads in flight per thread do not fit the 80-register budgets of the small tiles
-    if constexpr (STAGES == 4 && WM == 4 && MI == 1 && NI == 2 && !SK) {
+    if constexpr (STAGES == 4 && WM == 4 && MI == 1 && NI == 2) {
         if (gemm_weight_touch(p)) return;
     }
-    // stream-K (SK): this workgroup's units [sk_unit, sk_end) of the K-tile sequence, walked segment by segment (gemm_common.h)
-    int sk_slot = 0, sk_unit = 0, sk_end = 0;
-    if (SK) {
-        sk_slot = gemm_remap_bid((int)gridDim.x);
-        sk_unit = sk_slot * p.sk_per;
-        sk_end = min(sk_unit + p.sk_per, p.tiles_m * p.tiles_n * (p.K / BK));
-        if (sk_unit >= sk_end) return;
-    }
-  do {
-    int tid_ = threadIdx.x;
-    // SK: everything derived from the lane id is re-derived per segment - hoisted out of the segment loop and carried across the K
-    // loops and epilogues it costs ~90 registers (256 + scratch against 169)
-    if (SK) asm volatile("" : "+v"(tid_));
-    const int tid = tid_;
+    const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
     int tile_m, tile_n, ks_id;
     int kt_begin = 0, nk = p.K / BK;
-    if (SK) {
-        const int t = sk_unit / nk;
-        kt_begin = sk_unit - t * nk;
-        nk = min(nk - kt_begin, sk_end - sk_unit);
-        gemm_tile_of(p, t, tile_m, tile_n);
-        ks_id = 0;
-    } else {
+    {
         gemm_map_tile(p, tile_m, tile_n, ks_id);
         if (p.splitk > 1) {
             kt_begin = ks_id * p.kper;          // K tiles per slice: computed once, by slh_gemm, which also makes every slice non-empty
@@ -509,20 +490,8 @@ __global__ __launch_bounds__(128 * WM, gemm_waves_per_simd(MI, NI, STAGES, LORA,
         if (g < nk) body(F_{}, F_{}, F_{});
     }
 
-    if (SK) {
-        if (kt_begin > 0) {
-            gemm_sk_publish<MI, NI>(p, sk_slot, gridDim.x, acc, wave, lane, tid);
-        } else {
-            if (nk < p.K / BK) gemm_sk_collect<MI, NI>(p, sk_slot, gridDim.x, p.K / BK - nk, acc, wave, lane, tid);
-            gemm_epilogue<MI, NI, MODE, LORA, NW, 2>(p, smem, acc, accl, ln_mean, ln_rstd, ln_on, tile_m, tile_n, ks_id, wave, wm, wn);
-        }
-        sk_unit += nk;
-        __syncthreads();          // the operand stages (recycled by the epilogue) are free for the next segment's tiles
-    } else {
-        // XA: the instantiation that carries the fused cross-attention (FEAT bit 8, gemm_common.h)
-        gemm_epilogue<MI, NI, MODE, LORA, NW, 2, XA ? 15 : 7>(p, smem, acc, accl, ln_mean, ln_rstd, ln_on, tile_m, tile_n, ks_id, wave, wm, wn);
-    }
-  } while (SK && sk_unit < sk_end);
+    // XA: the instantiation that carries the fused cross-attention (FEAT bit 8, gemm_common.h)
+    gemm_epilogue<MI, NI, MODE, LORA, NW, 2, XA ? 15 : 7>(p, smem, acc, accl, ln_mean, ln_rstd, ln_on, tile_m, tile_n, ks_id, wave, wm, wn);
 }
 
 template <int MI, int NI, int MODE, bool LORA, int WM>
@@ -543,19 +512,11 @@ int launch_gemm3(const GemmArgs& a, int stages, hipStream_t s) {
     return 0;
 }
 
-// stream-K launch (dense 128 x 128 8-wave tile on the 4-slot ring - one workgroup per CU -, no fused adapter): grid workgroups, all
-// resident.  (The double-buffered loop with two workgroups per CU was measured too: slower everywhere and 376 B of scratch.)
-int launch_gemm_sk(const GemmArgs& a, int grid, hipStream_t s) {
-    hipLaunchKernelGGL((gemm_kernel<1, 2, 0, 4, false, 4, true>), dim3(grid), dim3(512), 0, s, a);
-    SLH_LAUNCH_CHECK("slh_gemm (stream-K)");
-    return 0;
-}
-
 // query projection + cross-attention (slh_gemm_desc.xa_k): the 128 x 128 8-wave ring tile (256 registers per lane to work with;
 // the double-buffered loop's 128 would spill the scores)
 int launch_gemm_xa(const GemmArgs& a, hipStream_t s) {
     const int grid = a.tiles_m * a.tiles_n + a.pf_blocks;
-    hipLaunchKernelGGL((gemm_kernel<1, 2, 0, 4, false, 4, false, true>), dim3(grid), dim3(512), 0, s, a);
+    hipLaunchKernelGGL((gemm_kernel<1, 2, 0, 4, false, 4, true>), dim3(grid), dim3(512), 0, s, a);
     SLH_LAUNCH_CHECK("slh_gemm (query projection + cross-attention)");
     return 0;
 }
@@ -638,6 +599,7 @@ extern "C" int slh_gemm_variant(const slh_gemm_desc* d) {
 extern "C" int slh_gemm(const slh_gemm_desc* d, slh_stream_t stream) {
     SLH_CHECK(d && d->a0 && d->w && d->c, "slh_gemm: null pointer");
     SLH_CHECK(d->M > 0 && d->N > 0 && d->K > 0, "slh_gemm: bad shape M=%d N=%d K=%d", d->M, d->N, d->K);
+    SLH_CHECK((d->tile >> 20) == 0, "slh_gemm: tile 0x%x uses reserved bits (20 and up must be zero)", d->tile);
     SLH_CHECK(d->K % 64 == 0, "slh_gemm: K=%d must be a multiple of 64", d->K);
     SLH_CHECK(d->N % 4 == 0, "slh_gemm: N=%d must be a multiple of 4", d->N);
     SLH_CHECK(d->ca0 % 64 == 0 && d->ca1 % 64 == 0, "slh_gemm: channel counts must be multiples of 64");
@@ -804,8 +766,8 @@ extern "C" int slh_gemm(const slh_gemm_desc* d, slh_stream_t stream) {
     a.xa_scale = d->xa_scale;
     if (d->xa_k) {
         const int st = (d->tile >> 8) & 15;
-        SLH_CHECK(WM == 4 && MI == 1 && NI == 2 && st == 4 && a.splitk == 1 && !((d->tile >> 20) & 1),
-                  "slh_gemm: the fused cross-attention runs on the 128 x 128 8-wave ring tile (0x4412), no split-K / stream-K");
+        SLH_CHECK(WM == 4 && MI == 1 && NI == 2 && st == 4 && a.splitk == 1,
+                  "slh_gemm: the fused cross-attention runs on the 128 x 128 8-wave ring tile (0x4412), no split-K");
         SLH_CHECK(d->mode == 0 && !d->lora_down && !d->lora_t && !d->residual && !d->rowbias && !d->geglu && !d->ln_out && !d->vt_out,
                   "slh_gemm: xa_k excludes adapters, residual, row bias, GEGLU, ln_out, vt_out");
         SLH_CHECK(d->xa_vt && d->N % 64 == 0 && d->xa_tk >= 1 && d->xa_tk <= 96 && d->xa_tq > 0 && d->xa_tq % 128 == 0 &&
@@ -815,18 +777,6 @@ extern "C" int slh_gemm(const slh_gemm_desc* d, slh_stream_t stream) {
                   "xa_ldvt >= 128 (two 64-key tiles are staged), 16-byte aligned keys / values");
     }
     a.pf_ptr = nullptr; a.pf_bytes = 0; a.pf_blocks = 0;
-    a.sk_per = 0;
-    const int sk = (d->tile >> 20) & 1;        // stream-K (tile 0x104412): one workgroup per CU, see gemm_common.h
-    if (sk) {
-        const int st = (d->tile >> 8) & 15;
-        SLH_CHECK(WM == 4 && MI == 1 && NI == 2 && d->mode == 0 && !d->lora_down && a.splitk == 1 && !d->ln_in && !d->ln_out &&
-                      !d->geglu && !d->vt_out,
-                  "slh_gemm: stream-K runs the dense 128 x 128 8-wave ring tile (0x104412) without adapter, split-K, GEGLU, "
-                  "LayerNorm fold or vt_out");
-        SLH_CHECK(st == 4, "slh_gemm: stream-K runs on the 4-slot ring (tile 0x104412)");
-        SLH_CHECK(d->splitk_c32 && d->splitk_ticket && ((uintptr_t)d->splitk_ticket & 7) == 0 && ((uintptr_t)d->splitk_c32 & 15) == 0,
-                  "slh_gemm: stream-K needs the slab workspace splitk_c32 and the (zeroed) flags splitk_ticket");
-    }
     if (WM == 8) {
         const int bm = MI == 1 ? 128 : 256, bn = 64 * NI * (MI == 4 ? 2 : 1);
         a.tiles_m = (d->M + bm - 1) / bm;
@@ -841,7 +791,7 @@ extern "C" int slh_gemm(const slh_gemm_desc* d, slh_stream_t stream) {
     a.tiles_m = (d->M + 32 * MI * WM - 1) / (32 * MI * WM);
     a.tiles_n = (d->N + 64 * NI - 1) / (64 * NI);
     a.group_m = pick_group_m(d, a.tiles_m);
-    if (d->pf_ptr && d->pf_bytes >= 16 && !sk && WM == 4 && MI == 1 && NI == 2 && ((d->tile >> 8) & 15) == 4) {
+    if (d->pf_ptr && d->pf_bytes >= 16 && WM == 4 && MI == 1 && NI == 2 && ((d->tile >> 8) & 15) == 4) {
         // the weight touch is a hint: taken only on the 128 x 128 ring tile (0x4412: one workgroup per CU) and only when the launch
         // leaves CUs idle
         SLH_CHECK(((uintptr_t)d->pf_ptr & 15) == 0, "slh_gemm: pf_ptr must be 16-byte aligned");
@@ -851,24 +801,6 @@ extern "C" int slh_gemm(const slh_gemm_desc* d, slh_stream_t stream) {
     hipStream_t s = (hipStream_t)stream;
     const int stages = (d->tile >> 8) & 15;   // tile = (WM<<12)|(stages<<8)|(MI<<4)|NI ; stages 0/2 = double buffer
     if (d->xa_k) return launch_gemm_xa(a, s);
-    if (sk) {
-        const int ncu = slh_ncu();
-        SLH_CHECK(ncu > 0, "slh_gemm: stream-K could not read the CU count");
-        const long units = (long)a.tiles_m * a.tiles_n * (d->K / 64);
-        int per = (int)((units + (long)ncu * sk - 1) / ((long)ncu * sk));
-        static const char* force_per = getenv("SLIDERS_SK_PER");      // measurement aid: K tiles per workgroup
-        if (force_per && atoi(force_per) > 0) per = atoi(force_per);
-        const int grid = (int)((units + per - 1) / per);
-        // fewer than 4 K tiles per workgroup: every tile would be cut several times - run the plain tile launch
-        SLH_CHECK(grid <= ncu, "slh_gemm: stream-K grid %d exceeds the %d CUs (every workgroup must be resident)", grid, ncu);
-        if (force_per || (per >= 4 && grid > a.tiles_m * a.tiles_n)) {
-            SLH_CHECK((long)grid * (128 * 128 * 4) <= (long)d->splitk_slabs * ((d->M + 255) / 256 * 256L) * ((d->N + 127) / 128 * 128L) * 4,
-                      "slh_gemm: stream-K publishes up to %d partial tiles of 64 KB: splitk_c32 (%d slabs) is too small", grid, d->splitk_slabs);
-            SLH_CHECK(grid <= 4096, "slh_gemm: stream-K flags");
-            a.sk_per = per;
-            return launch_gemm_sk(a, grid, s);
-        }
-    }
     if (WM == 4) {
         if (MI == 2) return launch_gemm<2, 2, 4>(a, d->mode, stages, s);   // 256 x 128, 8 waves
         if (NI == 1) return launch_gemm<1, 1, 4>(a, d->mode, stages, s);   // 128 x 64, 8 waves

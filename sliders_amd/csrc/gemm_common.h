@@ -37,7 +37,6 @@ struct GemmArgs {
     const __bf16* xa_k; const __bf16* xa_vt; int xa_tk, xa_tq, xa_ldk, xa_ldvt, xa_vt_heads; float xa_scale;
     const float* ln_lora_s; const float* ln_lora_c;   // LayerNorm fold of the fused adapter's down-projection (slh_gemm_desc.ln_lora_*)
     const void* pf_ptr; long pf_bytes; int pf_blocks;   // weight touch by the launch's last pf_blocks workgroups (slh_gemm_desc.pf_*)
-    int sk_per;  // stream-K (slh_gemm_desc.tile bits 20-21): K-tile units per workgroup; 0 = one tile (or K slice) per workgroup
     int probe;   // ablation builds only (-DSLH_GEMM_PROBE, scripts/build_variant.sh): 1 skip tile refills, 2 skip MFMA work,
                  // 4 skip the epilogue, 8 skip the first tile fill, 16 return at once; the default build ignores it
 };
@@ -102,68 +101,6 @@ __device__ __forceinline__ bool gemm_weight_touch(const GemmArgs& p) {
     for (; i < n16; i += stride) acc ^= src[i].x;
     asm volatile("" ::"v"(acc));       // the loads are the point
     return true;
-}
-
-// ---- stream-K (slh_gemm_desc.tile bits 20-21) ----------------------------------------------------------------------------------
-// The launch is G workgroups (a multiple of the CU count, all resident at once); workgroup b owns the K-tile units
-// [b*sk_per, (b+1)*sk_per) of the sequence (tile 0: k 0..nk-1, tile 1: k 0..nk-1, ...), i.e. the tail of one tile, whole tiles, and
-// the head of another.  A segment that does not begin at k = 0 is PUBLISHED (fp32 partial tile in the accumulator layout, slab b
-// of splitk_c32, write-through stores, then flag b); the workgroup that holds a tile's k = 0 segment is its finisher: it reaches
-// that segment LAST in its own sequence, by which time the later parts (the FIRST segment of the following workgroups) were
-// published long ago - it adds them in k order (fixed: the cut points are a function of the shape alone, bit-reproducible) and
-// runs the ordinary epilogue.  A workgroup publishes at most once; nobody waits for a workgroup with a lower id, and every
-// workgroup is resident, so the flag waits cannot deadlock.
-template <int MI, int NI>
-__device__ __forceinline__ void gemm_sk_publish(const GemmArgs& p, const int slot, const int grid, f32x16 (&acc)[MI][NI], const int wave,
-                                                const int lane, const int tid) {
-    constexpr int WAVE_BYTES = MI * NI * 4096;
-    const int tile_bytes = (int)(blockDim.x >> 6) * WAVE_BYTES;
-    const __amdgpu_buffer_rsrc_t slabs = __builtin_amdgcn_make_buffer_rsrc(p.c32, 0, grid * tile_bytes, 0x00020000);
-    unsigned off = (unsigned)slot * tile_bytes + wave * WAVE_BYTES + lane * 16;
-    asm volatile("" : "+v"(off));
-#pragma unroll
-    for (int i = 0; i < MI; ++i)
-#pragma unroll
-        for (int j = 0; j < NI; ++j)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const f32x4 v = {acc[i][j][q * 4], acc[i][j][q * 4 + 1], acc[i][j][q * 4 + 2], acc[i][j][q * 4 + 3]};
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), slabs, off + ((i * NI + j) * 4 + q) * 1024, 0, 16 /* sc1 */);
-            }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's partials have reached the memory side
-    __syncthreads();
-    if (tid == 0) __hip_atomic_store(p.ticket + slot, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-// adds the published partials of the workgroups slot+1 .. that complete this tile (`missing` K tiles) to acc, in k order
-template <int MI, int NI>
-__device__ __forceinline__ void gemm_sk_collect(const GemmArgs& p, const int slot, const int grid, int missing, f32x16 (&acc)[MI][NI],
-                                                const int wave, const int lane, const int tid) {
-    constexpr int WAVE_BYTES = MI * NI * 4096;
-    const int tile_bytes = (int)(blockDim.x >> 6) * WAVE_BYTES;
-    const __amdgpu_buffer_rsrc_t slabs = __builtin_amdgcn_make_buffer_rsrc(p.c32, 0, grid * tile_bytes, 0x00020000);
-    for (int c = slot + 1; missing > 0; ++c, missing -= p.sk_per) {
-        if (tid == 0) {
-            while (__hip_atomic_load(p.ticket + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0ull) __builtin_amdgcn_s_sleep(4);
-            __hip_atomic_store(p.ticket + c, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // left zero for the next launch
-        }
-        __syncthreads();
-        unsigned off = (unsigned)c * tile_bytes + wave * WAVE_BYTES + lane * 16;
-        asm volatile("" : "+v"(off));
-#pragma unroll
-        for (int i = 0; i < MI; ++i)
-#pragma unroll
-            for (int j = 0; j < NI; ++j) {
-                f32x4 t[4];        // one 32 x 32 block per batch of loads
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    t[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(slabs, off + ((i * NI + j) * 4 + q) * 1024, 0, 16 /* sc1 */));
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    acc[i][j][q * 4] += t[q][0]; acc[i][j][q * 4 + 1] += t[q][1]; acc[i][j][q * 4 + 2] += t[q][2]; acc[i][j][q * 4 + 3] += t[q][3];
-                }
-            }
-    }
 }
 
 // ---- LayerNorm of the A operand, folded (consumer side) ---------------------------------------------------------------------

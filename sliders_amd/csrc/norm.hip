@@ -559,6 +559,10 @@ extern "C" int slh_gn_fused(const slh_gn_desc* d, slh_stream_t stream) {
 extern "C" int slh_gn_apply(const slh_gn_desc* d, slh_stream_t stream) {
     SLH_CHECK(d && d->x0 && d->stats && d->y && d->gamma && d->beta, "slh_gn_apply: null pointer");
     SLH_CHECK(d->partial, "slh_gn_apply: needs the partial sums slh_gn_stats left (same descriptor)");
+    // every workgroup rebuilds (mean, rstd) from the partial sums AND the pivot x[b][row 0][first channel of the group], which it
+    // re-reads from the input: an in-place call would let workgroups that run later see a normalised pivot - different means per
+    // workgroup, silently
+    SLH_CHECK(d->y != d->x0 && (!d->x1 || d->y != d->x1), "slh_gn_apply: y must not alias x0 / x1 (the statistics' pivot is re-read from x)");
     if (gn_check("slh_gn_apply", d->c0, d->c1, d->groups, d->ldx0, d->ldx1, d->x1)) return -1;
     SLH_CHECK(d->ldy % 8 == 0, "slh_gn_apply: ldy");
     const GnGeom g = gn_geom(d->c0, d->c1, d->hw, d->groups);

@@ -360,31 +360,6 @@ __global__ __launch_bounds__(256) void gather16_kernel(const unsigned short* src
 }
 }  // namespace
 
-// slh_prefetch: stream a byte range through plain loads (they allocate in L2 and in the memory-side cache); the never-true store
-// keeps the loads alive
-__global__ __launch_bounds__(256) void prefetch_kernel(const uint4* src, long n16, unsigned* sink) {
-    const long stride = (long)gridDim.x * 256;
-    unsigned acc = 0;
-    long i = (long)blockIdx.x * 256 + threadIdx.x;
-    for (; i + 3 * stride < n16; i += 4 * stride) {
-        const uint4 a = src[i], b = src[i + stride], c = src[i + 2 * stride], e = src[i + 3 * stride];
-        acc ^= a.x ^ b.y ^ c.z ^ e.w;
-    }
-    for (; i < n16; i += stride) acc ^= src[i].x;
-    if (acc == 0x5bd1e995u && sink != nullptr) *sink = acc;
-}
-
-extern "C" int slh_prefetch(const slh_prefetch_desc* d, slh_stream_t stream) {
-    SLH_CHECK(d && d->ptr && d->nbytes > 0 && ((uintptr_t)d->ptr & 15) == 0, "slh_prefetch: null / empty / unaligned range");
-    const long n16 = d->nbytes / 16;
-    if (n16 == 0) return 0;
-    long blocks = (n16 + 256 * 8 - 1) / (256 * 8);
-    if (blocks > 192) blocks = 192;
-    hipLaunchKernelGGL(prefetch_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const uint4*)d->ptr, n16, (unsigned*)nullptr);
-    SLH_LAUNCH_CHECK("slh_prefetch");
-    return 0;
-}
-
 extern "C" int slh_gather16(const slh_gather16_desc* d, slh_stream_t stream) {
     SLH_CHECK(d && d->src && d->idx && d->out && d->n > 0, "slh_gather16: null pointer / empty");
     hipLaunchKernelGGL(gather16_kernel, dim3((unsigned)((d->n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,

@@ -47,29 +47,10 @@ inline int run_desc(const unsigned char* p, int32_t nbytes, int (*fn)(const T*, 
 }
 }  // namespace
 
-namespace {
-// SLH_OP_PREFETCH runs beside the launches that follow it: a side stream forked from the program's stream by an event (inside a
-// stream capture this pulls the side stream into the capture: the touch becomes a graph node with one predecessor and the join
-// below as its only successor) and joined when the program ends.  One side stream / event pair per process (programs are
-// issued from one host thread).
-struct Side {
-    hipStream_t stream = nullptr;
-    hipEvent_t fork = nullptr, join = nullptr;
-    bool ok = false;
-    Side() {
-        ok = hipStreamCreateWithFlags(&stream, hipStreamNonBlocking) == hipSuccess &&
-             hipEventCreateWithFlags(&fork, hipEventDisableTiming) == hipSuccess &&
-             hipEventCreateWithFlags(&join, hipEventDisableTiming) == hipSuccess;
-    }
-};
-Side& side() { static Side s; return s; }
-}  // namespace
-
 extern "C" int slh_run_program(const void* program, int64_t nbytes, slh_stream_t stream) {
     const unsigned char* p = (const unsigned char*)program;
     const unsigned char* end = p + nbytes;
     int idx = 0;
-    bool side_used = false;
     int rc_all = 0;
     while (p < end) {
         if (end - p < 8) { slh_set_error("slh_run_program: truncated record header at op %d", idx); return -3; }
@@ -121,20 +102,6 @@ extern "C" int slh_run_program(const void* program, int64_t nbytes, slh_stream_t
             case SLH_OP_WGRAD_BATCH: rc = run_desc<slh_batch_desc>(p, sz, slh_lora_wgrad_batch, stream, "wgrad_batch"); break;
             case SLH_OP_TRANSPOSE_BATCH: rc = run_desc<slh_batch_desc>(p, sz, slh_transpose_heads_batch, stream, "transpose_batch"); break;
             case SLH_OP_GATHER16: rc = run_desc<slh_gather16_desc>(p, sz, slh_gather16, stream, "gather16"); break;
-            case SLH_OP_PREFETCH: {
-                if (sz != (int32_t)sizeof(slh_prefetch_desc)) { slh_set_error("slh_run_program: prefetch desc size"); return -3; }
-                slh_prefetch_desc d;
-                memcpy(&d, p, sizeof(d));
-                Side& sd = side();
-                if (!sd.ok) { slh_set_error("slh_run_program: side stream for SLH_OP_PREFETCH could not be created"); return -2; }
-                if (hipEventRecord(sd.fork, (hipStream_t)stream) != hipSuccess || hipStreamWaitEvent(sd.stream, sd.fork, 0) != hipSuccess) {
-                    slh_set_error("slh_run_program: prefetch fork failed at op %d", idx);
-                    return -2;
-                }
-                side_used = true;
-                rc = slh_prefetch(&d, (slh_stream_t)sd.stream);
-                break;
-            }
             case SLH_OP_MEMSET: {
                 if (sz != (int32_t)sizeof(slh_memset_desc)) { slh_set_error("slh_run_program: memset desc size"); return -3; }
                 slh_memset_desc d;
@@ -149,13 +116,6 @@ extern "C" int slh_run_program(const void* program, int64_t nbytes, slh_stream_t
         if (rc != 0) { rc_all = rc; break; }
         p += (sz + 7) & ~7;
         ++idx;
-    }
-    if (side_used) {       // join (also on an error exit: a capture in progress must see the side stream return)
-        Side& sd = side();
-        if (hipEventRecord(sd.join, sd.stream) != hipSuccess || hipStreamWaitEvent((hipStream_t)stream, sd.join, 0) != hipSuccess) {
-            slh_set_error("slh_run_program: prefetch join failed");
-            return -2;
-        }
     }
     return rc_all;
 }
@@ -229,8 +189,7 @@ extern "C" int slh_desc_sizes(int32_t* out, int32_t cap) {
         (int32_t)sizeof(slh_lora_cdgrad_desc), (int32_t)sizeof(slh_temb_lora_bwd_desc),
         (int32_t)sizeof(slh_sgemm_desc),    (int32_t)sizeof(slh_gn32_desc),     (int32_t)sizeof(slh_softmax32_desc),
         (int32_t)sizeof(slh_vae_conv_desc), (int32_t)sizeof(slh_vae_sample_desc), (int32_t)sizeof(slh_lion_desc),
-        (int32_t)sizeof(slh_batch_desc),    (int32_t)sizeof(slh_gather16_desc), (int32_t)sizeof(slh_lora_lnfold_desc),
-        (int32_t)sizeof(slh_prefetch_desc)};
+        (int32_t)sizeof(slh_batch_desc),    (int32_t)sizeof(slh_gather16_desc), (int32_t)sizeof(slh_lora_lnfold_desc)};
     const int n = (int)(sizeof(sizes) / sizeof(sizes[0]));
     for (int i = 0; i < n && i < cap; ++i) out[i] = sizes[i];
     return n;

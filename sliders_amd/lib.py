@@ -96,7 +96,6 @@ VaeConvDesc = _struct("VaeConvDesc", _ptrs("x", "w", "bias", "qw", "qb", "y") + 
 BatchDesc = _struct("BatchDesc", _ptrs("table", "prefix") + _ints("n", "total", "arg", "pad_") + _ptrs("slabs", "tickets"))
 Gather16Desc = _struct("Gather16Desc", _ptrs("src", "idx", "out") + [("n", c_i64)])
 LoraLnFoldDesc = _struct("LoraLnFoldDesc", _ptrs("items") + _ints("n", "pad_"))
-PrefetchDesc = _struct("PrefetchDesc", _ptrs("ptr") + [("nbytes", c_i64)])
 LORA_LNFOLD_ITEM_I64 = 7          # slh_lora_lnfold_item as int64 words: a, gamma, beta, a_out, s_out, c_out, rows | K << 32
 VaeSampleDesc = _struct("VaeSampleDesc", _ptrs("moments", "post_noise", "noise", "latent_f32", "noisy_f32", "noisy_bf16")
                         + _ints("batch", "hw") + [("scaling", c_f32), ("sqrt_alpha", c_f32), ("sqrt_one_minus_alpha", c_f32)]
@@ -106,7 +105,7 @@ VaeSampleDesc = _struct("VaeSampleDesc", _ptrs("moments", "post_noise", "noise",
 _SIZE_ORDER = [GemmDesc, SkinnyDesc, GemvDesc, GnDesc, GnBwdDesc, LnDesc, LnBwdDesc, AttnDesc, TransposeDesc,
                AttnBwdDesc, TembedDesc, ConvInDesc, EwDesc, CfgDdimDesc, LossDesc, WgradDesc, AdamwDesc, MemsetDesc,
                LoraCdgradDesc, TembLoraBwdDesc, SgemmDesc, Gn32Desc, Softmax32Desc, VaeConvDesc, VaeSampleDesc, LionDesc,
-               BatchDesc, Gather16Desc, LoraLnFoldDesc, PrefetchDesc]
+               BatchDesc, Gather16Desc, LoraLnFoldDesc]
 
 # opcodes (enum in sliders_hip.h)
 OP_GEMM, OP_SKINNY, OP_GEMV, OP_GN_STATS, OP_GN_APPLY, OP_LAYERNORM, OP_ATTN_FWD, OP_TRANSPOSE_HEADS = range(1, 9)
@@ -116,7 +115,7 @@ OP_LORA_CONV_DGRAD, OP_TEMB_LORA_BWD = 21, 22
 OP_SGEMM, OP_GN32_STATS, OP_GN32_APPLY, OP_SOFTMAX32, OP_VAE_CONV_IN, OP_VAE_MOMENTS, OP_VAE_SAMPLE, OP_VAE_POST_QUANT = range(23, 31)
 OP_LION = 31
 OP_WGRAD_BATCH, OP_TRANSPOSE_BATCH, OP_GATHER16, OP_GN_FUSED = 32, 33, 34, 35
-OP_LORA_LN_FOLD, OP_PREFETCH = 36, 37
+OP_LORA_LN_FOLD = 36
 
 EW_COPY, EW_ADD, EW_GEGLU_FWD, EW_GEGLU_BWD, EW_UPSAMPLE_BWD, EW_COLSUM = range(6)
 
@@ -138,7 +137,7 @@ _ENTRY = {
     OP_VAE_POST_QUANT: ("slh_vae_post_quant", VaeConvDesc), OP_LION: ("slh_lion", LionDesc),
     OP_WGRAD_BATCH: ("slh_lora_wgrad_batch", BatchDesc), OP_TRANSPOSE_BATCH: ("slh_transpose_heads_batch", BatchDesc),
     OP_GATHER16: ("slh_gather16", Gather16Desc), OP_GN_FUSED: ("slh_gn_fused", GnDesc),
-    OP_LORA_LN_FOLD: ("slh_lora_ln_fold", LoraLnFoldDesc), OP_PREFETCH: ("slh_prefetch", PrefetchDesc),
+    OP_LORA_LN_FOLD: ("slh_lora_ln_fold", LoraLnFoldDesc),
 }
 
 EXPORTS = ["slh_version", "slh_last_error", "slh_run_program", "slh_desc_sizes", "slh_graph_capture", "slh_graph_launch",
@@ -310,6 +309,19 @@ class Program:
                 self._drop_graphs()
         except Exception:
             pass
+
+    def mark(self) -> int:
+        """Number of recorded ops; truncate(mark) forgets everything recorded since (planner rollbacks)."""
+        return self.n_ops
+
+    def truncate(self, n: int):
+        if n >= self.n_ops:
+            return
+        del self._chunks[n:], self.op_names[n:], self.ops[n:]
+        self.n_ops = n
+        self._buf = None
+        if self._graphs:
+            self._drop_graphs()
 
     def add(self, opcode: int, desc, name: str = ""):
         raw = bytes(desc)

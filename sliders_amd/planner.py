@@ -116,14 +116,6 @@ def provision_splitk(plan, d, name: str):
     tiles) per K slice
     (each slice writes its own, the last slice of a tile to arrive adds them in slice order inside the launch - bit-reproducible) and, with a
     fused adapter, two [M][ld_t] slabs per slice for T.  Fixes d.tile for untuned shapes."""
-    if d.tile and (d.tile >> 20) & 1:
-        # stream-K (an opt-in tile, never in the tuned tables): one 64 KB partial tile and one flag per workgroup (= per CU)
-        ncu = torch.cuda.get_device_properties(torch.cuda.current_device()).multi_processor_count if torch.cuda.is_available() else 256
-        slab = ((d.M + 255) // 256 * 256) * ((d.N + 127) // 128 * 128)
-        d.splitk_slabs = (ncu * 128 * 128 + slab - 1) // slab
-        d.splitk_c32 = plan.arena.alloc((d.splitk_slabs, slab), torch.float32, name + ".streamk").ptr
-        d.splitk_ticket = _plan_tickets(plan, ncu)
-        return
     if not splitk_wanted(d):
         return
     if not d.tile and d.M * d.N <= (1 << 20):      # the untuned default only for the small products it was measured on
@@ -145,36 +137,6 @@ def provision_splitk(plan, d, name: str):
 
 PREFETCH_MIN_BYTES = int(os.environ.get("SLIDERS_PREFETCH_MIN", str(6 << 20)))
 PREFETCH_MAX_BYTES = 96 << 20
-PREFETCH_AHEAD = int(os.environ.get("SLIDERS_PREFETCH_AHEAD", "0"))     # side-stream touches: measured slower, off (see below)
-
-
-def with_weight_prefetch(prog: "lib.Program") -> "lib.Program":
-    """A UNet pass streams every frozen matrix once (5 GB for SDXL), so each is HBM-cold when its product starts, and the big ones
-    cost their launch 2-9 us of first-touch misses (profiles/r04_weight_prefetch.txt).  For every GEMM whose packed weights are
-    6-96 MB a touch of those bytes (SLH_OP_PREFETCH: a side-stream kernel beside the launches that follow) is recorded
-    PREFETCH_AHEAD ops earlier: by the time the product runs its weights sit in the 256 MB memory-side cache.
-    MEASURED SLOWER (profiles/r04_weight_prefetch.txt): 218 side-stream kernels with an event fork each cost the SDXL 1024^2 pass
-    +0.9 ms as plain launches and +2.7 ms as a replayed graph (24.7 -> 25.6 / 27.4 ms) - the fork / join edges, not the loads.
-    Off by default (SLIDERS_PREFETCH_AHEAD=n turns it on for experiments); the product path touches weights from idle
-    workgroup slots of the launches themselves (slh_gemm_desc.pf_*)."""
-    if os.environ.get("SLIDERS_NO_PREFETCH") is not None or PREFETCH_AHEAD <= 0:
-        return prog
-    ins: Dict[int, list] = {}
-    for i, ((op, d), nm) in enumerate(zip(prog.ops, prog.op_names)):
-        if op != lib.OP_GEMM or d.w_layout != 1:
-            continue
-        nb = (d.N + 63) // 64 * 64 * d.K * 2
-        if PREFETCH_MIN_BYTES <= nb <= PREFETCH_MAX_BYTES:
-            ins.setdefault(max(1, i - PREFETCH_AHEAD), []).append((d.w, nb, nm + ".prefetch"))
-    if not ins:
-        return prog
-    out = lib.Program()
-    for i, ((op, d), nm) in enumerate(zip(prog.ops, prog.op_names)):
-        for ptr, nb, pn in ins.get(i, ()):
-            out.add(lib.OP_PREFETCH, lib.PrefetchDesc(ptr=ptr, nbytes=nb), pn)
-        out.add(op, d, nm)
-    return out
-
 
 TOUCH_WINDOW = 6      # ops a weight touch may ride ahead of the product that needs the weights
 
@@ -251,7 +213,7 @@ class UNetPlan:
             head.add(lib.OP_LORA_LN_FOLD, lib.LoraLnFoldDesc(items=self._lnfold_table.data_ptr(), n=len(self.lnfold_items)),
                      "lora_ln_fold")
         head.extend(self.prog)
-        self.prog = with_weight_prefetch(attach_weight_touch(head))
+        self.prog = attach_weight_touch(head)
         # The text K/V of every cross-attention block depend only on the prompt embeddings (and frozen weights): inside a
         # denoise loop (train_util.py:263-294: same embeddings for every timestep) steps 2.. replay the pass without
         # the batched K/V projection and its head transpose.  Valid only while no other plan ran in between (plans
@@ -261,7 +223,7 @@ class UNetPlan:
             skip = {"attn2_kv_all", "attn2_vt_all", "lora_ln_fold"}     # (the adapters do not change inside a denoise loop either)
             pc = lib.Program()
             for (op, d), nm in zip(self.prog.ops, self.prog.op_names):
-                if nm not in skip and not (nm.endswith(".prefetch") and nm[:-9] in skip):
+                if nm not in skip:
                     pc.add(op, d, nm)
             self.prog_text_cached = pc
 
@@ -506,25 +468,28 @@ class UNetPlan:
         if grp is not None and foldable and not self.train and not geglu and os.environ.get("SLIDERS_NO_LORA_LN_FOLD") is None:
             # adapter-carrying consumer (q|k|v under noxattn): the fold covers the adapter's down-projection too
             amark, nallocs, nitems = self.arena.mark(), len(self.arena.allocs), len(self.lnfold_items)
+            pmark = self.prog.mark()
             y = self.gemm(h, wname, N, wname, bias=False, lora_paths=lora_paths, vt_heads=vt_heads, ln_fold=h, ln_norm=norm)
             if y is not None:
                 return y
             self.arena.reset(amark)
             del self.arena.allocs[nallocs:]
             del self.lnfold_items[nitems:]
+            self.prog.truncate(pmark)             # (an unfused adapter's down-projection may have been recorded ahead of the refusal)
         if grp is None and foldable:
             if not self.train:
-                amark, nallocs = self.arena.mark(), len(self.arena.allocs)
+                amark, nallocs, pmark = self.arena.mark(), len(self.arena.allocs), self.prog.mark()
                 y = self.gemm(h, wname, N, wname, bias=False, geglu=geglu, vt_heads=vt_heads, ln_fold=h,
                               geglu16=geglu16 and self.w.has(wname + ".lnw16"), xattn=xattn)
                 if y is not None:
                     return y
                 self.arena.reset(amark)           # fold refused: the output it had reserved goes back
                 del self.arena.allocs[nallocs:]
+                self.prog.truncate(pmark)
             elif os.environ.get("SLIDERS_TRAIN_NO_LN_FOLD") is None:
                 # training pass: the same fold; the product also leaves (mean, rstd) per row for the LayerNorm backward, and the
                 # tape keeps the LayerNorm and the product as two records around a stand-in for the normalised tensor
-                amark, nallocs = self.arena.mark(), len(self.arena.allocs)
+                amark, nallocs, pmark = self.arena.mark(), len(self.arena.allocs), self.prog.mark()
                 mr = self.f32((h.M, 2), norm + ".mean_rstd")
                 stand_in = self.key_act(h.B, h.H, h.W, h.C, norm + ".unwritten")
                 mark = len(self.tape)
@@ -533,9 +498,10 @@ class UNetPlan:
                               geglu_pre=geglu_pre)
                 if y is not None:
                     return y
-                del self.tape[mark:]              # fold refused (split-K tile): nothing was emitted - give the arena back too
+                del self.tape[mark:]              # fold refused (split-K tile): give the arena back and drop anything recorded
                 self.arena.reset(amark)
                 del self.arena.allocs[nallocs:]
+                self.prog.truncate(pmark)
         n = self.layernorm(h, norm, norm)
         return self.gemm(n, wname, N, wname, bias=bias, lora_paths=lora_paths, geglu=geglu, vt_heads=vt_heads,
                          geglu_pre=geglu_pre, geglu16=geglu16 and geglu_pre is None and self.w.has(wname + ".w16"), xattn=xattn)
@@ -674,7 +640,9 @@ class UNetPlan:
         # no-grad passes, head dim 64, text keys, no adapter on to_q: the attention runs in the epilogue of the query projection
         xa = None
         D2 = C // heads
-        if not self.train and vt_pre is not None and D2 == 64 and self.ctx_len <= 96 and h.HW % 128 == 0 and \
+        # (the gate restates slh_gemm's own checks for xa_*: head dim 64 with whole 64-column heads, 65..96 keys - two 64-key V^T
+        # tiles are always staged, so xa_ldvt = roundup(ctx_len, 64) must reach 128 - and whole 128-row query tiles per sample)
+        if not self.train and vt_pre is not None and D2 == 64 and C % 64 == 0 and 64 < self.ctx_len <= 96 and h.HW % 128 == 0 and \
                 self._lora_group([a2 + ".to_q"]) is None and os.environ.get("SLIDERS_NO_FUSED_XATTN") is None:
             xa = dict(k=k2, vt_ptr=vt_pre[0], vt_heads=vt_pre[1], Tk=self.ctx_len, Tq=h.HW, scale=D2 ** -0.5,
                       ldvt=(self.ctx_len + 63) // 64 * 64)

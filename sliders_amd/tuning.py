@@ -32,8 +32,8 @@ def tile_ok(d, tile: int) -> bool:
     mi, ni, wm = (tile >> 4) & 15, tile & 15, (tile >> 12) & 15
     if getattr(d, "xa_k", None):                  # cross-attention in the epilogue: the 128 x 128 ring tile only
         return tile == 0x4412
-    if (tile >> 20) & 1:                          # stream-K: the dense 128 x 128 ring tile, bare or bias / residual epilogue
-        return (tile & 0xFFFFF) == 0x4412 and d.mode == 0 and not (d.lora_down or d.geglu or d.ln_in or d.ln_out or d.vt_out)
+    if tile >> 20:                                # bits 20+ are reserved (round 4's stream-K form lived there; removed)
+        return False
     if wm == 8 and (tile >> 16) & 15:             # split-K: the slabs of these tiles must fit the workspace contract
         bm, bn = (256, 256) if mi == 4 else (128 * mi, 64 * ni)
         r = lambda v, q: (v + q - 1) // q * q

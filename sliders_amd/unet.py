@@ -260,6 +260,7 @@ class _VirtualWeights:
         self.kv_all_vbase = w.kv_all_vbase
         self.gemm_shape = w.gemm_shape
         self.ln_fold = w.ln_fold
+        self.geglu16 = getattr(w, "geglu16", False)    # the dry run must plan GEGLU.proj on the tile the real plan will take
 
     def ptr(self, name):
         return 0x1000

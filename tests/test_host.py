@@ -97,11 +97,8 @@ def test_planner_static_invariants(name, hw, method):
     for mode in ("off", "on", "train"):
         va, vz = Arena(1 << 50, None), Arena(1 << 40, None)
         p = UNetPlan(cfg, _FakeWeights(cfg), va, vz, 2, hw, hw, 77, store if mode != "off" else None, mode, 0x10)
-        ops = [(o, d) for o, d in p.prog.ops if o != lib.OP_PREFETCH]        # (weight touches run on a side stream beside these)
+        ops = list(p.prog.ops)
         counts[mode] = len(ops)
-        # every big frozen matrix is touched ahead of the product that streams it, never after it
-        pos = {d.w: i for i, (o, d) in enumerate(p.prog.ops) if o == lib.OP_GEMM}
-        assert all(d.nbytes >= 6 << 20 for o, d in p.prog.ops if o == lib.OP_PREFETCH)
         # every allocation is 256-byte aligned and allocations never overlap
         spans = sorted((s, e) for s, e, _ in va.allocs)
         assert all(s % 256 == 0 for s, _ in spans)
@@ -149,13 +146,12 @@ def test_planner_fusions_of_the_no_grad_pass(name, hw):
     store.temb_tcol = torch.zeros(1, dtype=torch.int32)
     va, vz = Arena(1 << 50, None), Arena(1 << 40, None)
     p = UNetPlan(cfg, _FakeWeights(cfg), va, vz, 2, hw, hw, 77, store, "on", 0x10)
-    ops = [(o, d) for o, d in p.prog.ops if o != lib.OP_PREFETCH]
-    names = [n for (o, _), n in zip(p.prog.ops, p.prog.op_names) if o != lib.OP_PREFETCH]
+    ops = list(p.prog.ops)
+    names = list(p.prog.op_names)
     # weights of the big products (GEGLU.proj, ff.net.2, q|k|v of the 1280-channel level) are touched from the idle workgroup slots of
     # an earlier 160-tile launch (slh_gemm_desc.pf_*): every touch rides AHEAD of the product that streams those bytes, at most
-    # TOUCH_WINDOW ops ahead, and no side-stream touches (SLH_OP_PREFETCH, measured slower) are recorded by default
+    # TOUCH_WINDOW ops ahead
     from sliders_amd.planner import TOUCH_WINDOW
-    assert not any(o == lib.OP_PREFETCH for o, _ in p.prog.ops)
     wpos = {}
     for i, (o, d) in enumerate(ops):
         if o == lib.OP_GEMM:
@@ -610,7 +606,7 @@ def test_bench_pairs_counter_traffic_only_with_identical_kernel_sources(tmp_path
     import json
     import bench
     from sliders_amd import srchash
-    k = "gemm_kernel<1, 2, 0, 4, false, 4, false, false>"
+    k = "gemm_kernel<1, 2, 0, 4, false, 4, false>"
     here = srchash.file_hashes()
     assert set(srchash.kernel_files(k, here)) >= {"gemm.hip", "gemm_common.h", "common.h", "sliders_hip.h"} and \
         "attention.hip" not in srchash.kernel_files(k, here) and all(f in srchash.kernel_files(k, here) for f in here if f.endswith(".json"))
@@ -640,3 +636,87 @@ def test_bench_pairs_counter_traffic_only_with_identical_kernel_sources(tmp_path
     t, src = bench.pmc_traffic_for(k, str(prof))
     assert t is None and "re-run" in src
 
+
+
+def test_dry_run_plans_the_program_the_real_plan_runs(monkeypatch):
+    """UNetEngine sizes its arena by planning against _VirtualWeights (pointer-less).  The dry run must take the same branches as
+    the real plan - same launches, same tiles, same arena high-water mark - for every mode: a forgotten attribute (geglu16 in
+    round 4: the dry run planned GEGLU.proj on the 32 | 32 path, the real plan on the 16 | 16 path with other tile keys) makes them
+    two different programs and the sizing a guess."""
+    from sliders_amd.unet import _VirtualWeights
+    cfg = CONFIGS["sdxl"]()
+    store = LoraStore(cfg, train_method="noxattn", init="none")
+    store.temb_tcol = torch.zeros(1, dtype=torch.int32)
+    real = _FakeWeights(cfg)
+    for mode in ("off", "on", "train"):
+        plans = []
+        for w in (real, _VirtualWeights(real)):
+            va, vz = Arena(1 << 50, None), Arena(1 << 40, None)
+            p = UNetPlan(cfg, w, va, vz, 2, 128, 128, 77, store if mode != "off" else None, mode, 0x10)
+            plans.append((p, va))
+        (pr, ar), (pv, av) = plans
+        assert pv.prog.op_names == pr.prog.op_names, mode
+        assert [d.tile for o, d in pv.prog.ops if o == lib.OP_GEMM] == [d.tile for o, d in pr.prog.ops if o == lib.OP_GEMM], mode
+        assert [d.geglu for o, d in pv.prog.ops if o == lib.OP_GEMM] == [d.geglu for o, d in pr.prog.ops if o == lib.OP_GEMM], mode
+        assert av.high_water >= ar.high_water, mode
+
+
+def test_refused_layernorm_fold_leaves_nothing_in_the_program(monkeypatch):
+    """ln_gemm tries the folded product first and falls back to LayerNorm + product when gemm() refuses.  With SLIDERS_LORA_UNFUSED
+    the refusal comes AFTER the adapter's down-projection was recorded (round-4 advisor finding): the rollback must drop that
+    launch too, otherwise it writes T into arena bytes that were handed out again."""
+    cfg = CONFIGS["sdxl"]()
+    store = LoraStore(cfg, train_method="noxattn", init="none")
+    store.temb_tcol = torch.zeros(1, dtype=torch.int32)
+    monkeypatch.setenv("SLIDERS_LORA_UNFUSED", "1")
+    va, vz = Arena(1 << 50, None), Arena(1 << 40, None)
+    p = UNetPlan(cfg, _FakeWeights(cfg), va, vz, 2, 128, 128, 77, store, "on", 0x10)
+    names = p.prog.op_names
+    downs = [n for n in names if n.endswith(".lora_down")]
+    assert len(downs) == len(set(downs)), "a rolled-back fold must not leave its down-projection behind"
+    # every recorded skinny launch writes a buffer that no LATER allocation overlaps (the stale launch wrote into re-allocated bytes)
+    spans = sorted((s, e) for s, e, _ in va.allocs)
+    assert all(spans[i][1] <= spans[i + 1][0] for i in range(len(spans) - 1))
+    # Program.truncate itself
+    prog = lib.Program()
+    prog.memset(0x1000, 16, 0, "a")
+    m = prog.mark()
+    prog.memset(0x2000, 16, 0, "b")
+    prog.memset(0x3000, 16, 0, "c")
+    prog.truncate(m)
+    assert prog.n_ops == 1 and prog.op_names == ["a"] and len(prog.ops) == 1
+
+
+class _FakeWeightsKvAll(_FakeWeights):
+    """_FakeWeights plus the batched text K/V layout of WeightStore (weights.py: all attn2 K / V projections concatenated)."""
+
+    def __init__(self, cfg):
+        super().__init__(cfg)
+        paths = [n for n, m in build_tree(cfg).named_modules() if n.endswith(".attn2")]
+        widths = {}
+        for n, m in build_tree(cfg).named_modules():
+            if n.endswith(".attn2.to_k"):
+                widths[n[:-len(".to_k")]] = m.out_dim
+        self.kv_all_vbase = sum(widths[a] for a in paths)
+        row = 0
+        for a in paths:
+            self.kv_all_offset[a] = (row, self.kv_all_vbase + row)
+            row += widths[a]
+        self.gemm_shape["attn2_kv_all.w"] = (2 * self.kv_all_vbase, cfg.cross_attention_dim)
+
+
+@pytest.mark.parametrize("ctx_len,fused", [(77, True), (64, False), (48, False), (96, True), (97, False)])
+def test_fused_cross_attention_gate_matches_the_kernel_checks(ctx_len, fused):
+    """attn2.to_q carries the cross-attention in its epilogue only where slh_gemm accepts xa_*: two 64-key V^T tiles are always
+    staged, so the padded key count roundup(ctx_len, 64) must reach 128 (65..96 keys).  Shorter contexts keep the two launches
+    instead of failing inside slh_gemm (round-4 advisor finding)."""
+    cfg = CONFIGS["sdxl"]()
+    va, vz = Arena(1 << 50, None), Arena(1 << 40, None)
+    p = UNetPlan(cfg, _FakeWeightsKvAll(cfg), va, vz, 2, 128, 128, ctx_len, None, "off", 0x10)
+    assert p.kv_all is not None and p.vt_all is not None
+    xa = [d for o, d in p.prog.ops if o == lib.OP_GEMM and d.xa_k]
+    assert bool(xa) == fused
+    assert all(d.xa_ldvt >= 128 and d.xa_tk == ctx_len and d.N % 64 == 0 and (d.tile & 0xFFFFF) == 0x4412 for d in xa)
+    n_cross = sum(1 for n in p.prog.op_names if n.endswith("attn2.sdpa"))
+    n_blocks = sum(1 for n in p.prog.op_names if n.endswith("attn2.q"))
+    assert n_cross + len(xa) == n_blocks          # every block runs its cross-attention exactly once, one way or the other
