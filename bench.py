@@ -483,6 +483,40 @@ def cpu_baseline(model, hw):
                       f"UNet{note}"}
 
 
+def params_hash64(store) -> int:
+    """64-bit digest of the replicated adapter state (flat parameters + both moments): sum and xor-fold of the raw 16-bit words,
+    computed on the device, exact in int64.  Equal state -> equal digest; used to assert that the ranks still hold bit-identical
+    replicas after the timed region."""
+    h = 0
+    for i, t in enumerate((store.params, store.exp_avg, store.exp_avg_sq)):
+        if t is None:
+            continue
+        w = t.view(torch.int16).to(torch.int64) & 0xFFFF
+        idx = torch.arange(w.numel(), device=w.device, dtype=torch.int64)
+        h ^= (int((w * ((idx % 65521) + 1)).sum().item()) + (i + 1) * 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF
+    return h & 0x7FFFFFFFFFFFFFFF
+
+
+def dp_self_check(tr, store, dev, rank, world):
+    """After the timed region (N > 1, or N = 1 under torch.distributed.run): every rank contributes a digest of its adapter
+    replica and the mean event time of its gradient all-reduces; rank 0 asserts that all replicas are bit-identical (the data-parallel
+    contract: same all-reduced gradient, same fused optimizer step everywhere) and reports the compute / communication split."""
+    import torch.distributed as dist
+    ms = tr.allreduce_ms() if hasattr(tr, "allreduce_ms") else []
+    mine = torch.tensor([params_hash64(store), int(1e6 * (sum(ms) / len(ms))) if ms else -1, len(ms)], dtype=torch.int64, device=dev)
+    allv = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(allv, mine)
+    hashes = [int(v[0].item()) for v in allv]
+    ar_us = [v[1].item() / 1e3 for v in allv if v[1].item() >= 0]
+    same = len(set(hashes)) == 1
+    if not same:
+        raise RuntimeError(f"data-parallel replicas diverged: adapter-state digests per rank {[hex(h) for h in hashes]}")
+    return {"rccl_ranks_seen": len(hashes), "replicas_bit_identical": same, "adapter_state_digest": hex(hashes[0]),
+            "allreduce_us_mean_per_rank": [round(u, 1) for u in ar_us], "allreduces_timed_per_rank": int(allv[0][2].item()),
+            "allreduce_bytes": int(store.grads.numel() * 4),
+            "note": "HIP events around torch.distributed.all_reduce on the stream the backward ran on; the timed loop carries them"}
+
+
 def main():
     a = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -539,7 +573,9 @@ def run_config(a, dev, world, rank, main_line):
     eng = UNetEngine(cfg, random_state_dict(cfg, dev, a.seed), dev)
     torch.manual_seed(a.seed)   # identical adapter init on every rank (replicated parameters)
     store = LoraStore(cfg, rank=4, alpha=1.0, train_method="noxattn", device=dev)
-    tr = SliderTrainer(eng, store, hw, hw, batch_size=1, lr=2e-4)
+    # under torch.distributed.run (any N, including the N = 1 the GPU tests launch) the gradient exchange goes through RCCL
+    pg = torch.distributed.group.WORLD if (torch.distributed.is_available() and torch.distributed.is_initialized()) else None
+    tr = SliderTrainer(eng, store, hw, hw, batch_size=1, lr=2e-4, process_group=pg)
 
     # 4 prompts x 2 attributes = 8 PromptEmbedsPairs (BASELINE configs[2]); synthetic CLIP-shaped embeddings
     g = torch.Generator(device="cpu").manual_seed(1234)
@@ -570,7 +606,7 @@ def run_config(a, dev, world, rank, main_line):
         from sliders_amd.vae import VAE_SCALING, VaeEncoder, random_vae_state_dict
         vae_sd = random_vae_state_dict(device=dev, seed=a.seed)
         vae = VaeEncoder(vae_sd, dev, VAE_SCALING["sdxl" if cfg.is_xl else "sd1"], exact_fp32=not a.vae_split_bf16)
-        tri = ImageSliderTrainer(eng, store, vae, hw, hw, batch_size=1, lr=2e-4)
+        tri = ImageSliderTrainer(eng, store, vae, hw, hw, batch_size=1, lr=2e-4, process_group=pg)
         gi = torch.Generator().manual_seed(99 + rank)
         imgs = [VaeEncoder.preprocess(torch.randint(0, 256, (a.res, a.res, 3), generator=gi, dtype=torch.uint8)).to(dev)
                 for _ in range(4)]
@@ -593,6 +629,7 @@ def run_config(a, dev, world, rank, main_line):
     for i in range(a.warmup):
         one_step(i)
     barrier()
+    tr.time_allreduce = dist_on          # event pair around every gradient all-reduce (on the stream it is ordered on)
     t0 = time.time()
     unet_steps = 0
     for i in range(a.steps):
@@ -604,6 +641,7 @@ def run_config(a, dev, world, rank, main_line):
         torch.distributed.all_reduce(tdt, op=torch.distributed.ReduceOp.MAX)
         dt = float(tdt.item())
     loss = float(tr.loss_low.item() if a.workload == "image" else tr.loss.item())
+    dp_check = dp_self_check(tr, store, dev, rank, world) if dist_on else None
     value_no_dedup = None
     if a.workload == "text" and rank == 0 and world == 1 and main_line:
         # the headline counts the de-duplicated B=3 frozen pass as the 3 predictions the reference executes; the same loop
@@ -638,6 +676,8 @@ def run_config(a, dev, world, rank, main_line):
                    "parallelism": f"dp{world}", "final_loss": loss,
                    "steps_per_s_with_frozen_predictions_run_as_3_cfg_pairs": value_no_dedup},
     }
+    if dp_check is not None:
+        res["data_parallel"] = dp_check
     if rank == 0:
         print("[bench] timed region done: " + json.dumps({k: res[k] for k in ("value", "ms_per_step")}), file=sys.stderr, flush=True)
     if rank == 0 and not a.no_roofline:

@@ -466,13 +466,20 @@ typedef struct slh_temb_lora_bwd_desc {
 int slh_temb_lora_bwd(const slh_temb_lora_bwd_desc* d, slh_stream_t stream);
 
 /* flat AdamW over the packed LoRA parameter buffer (bf16 params and moments, torch.optim.AdamW op order
- * and bf16 rounding points; train_util.py:362-363, train_lora_xl.py:346). grads fp32. */
+ * and bf16 rounding points; train_util.py:362-363, train_lora_xl.py:346). grads fp32.
+ * f32_state = 1 (train.precision: float32 - the reference's weight_dtype applied to the network, train_lora_xl.py:60-61, 84-90): param,
+ * exp_avg and exp_avg_sq are fp32 arrays updated with the op order of torch.optim.AdamW on fp32 CUDA tensors (one fp32 rounding per
+ * foreach op), the gradient is used unrounded, and param_lo - the bf16 copy every kernel of the UNet pass reads - receives the
+ * rounded new parameters in the same launch. */
 typedef struct slh_adamw_desc {
     void* param; void* exp_avg; void* exp_avg_sq; const float* grad;
     int64_t n;
     double lr, beta1, beta2, eps, weight_decay;  /* python floats of torch.optim.AdamW */
     int32_t step;            /* 1-based */
     float grad_scale;        /* multiply grads first (1/world_size after all-reduce) */
+    void* param_lo;          /* f32_state only: bf16 [n], written */
+    int32_t f32_state;       /* 0: bf16 state (default), 1: fp32 state + param_lo */
+    int32_t pad_;
 } slh_adamw_desc;
 int slh_adamw(const slh_adamw_desc* d, slh_stream_t stream);
 

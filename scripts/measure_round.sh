@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round-4 measurement on the GPU box (gpurun -- 'TREE_HEAD=<git head> bash scripts/measure_round4.sh'): the contract bench line
+# Per-round measurement on the GPU box (gpurun -- 'RTAG=r05 TREE_HEAD=<git head> bash scripts/measure_round.sh'): the contract bench line
 # (with extra_configs), the rocprofv3 --kernel-trace --stats summary of the same bench command, kernel stats + idle gaps of
 # LoRA-on passes alone, the PMC passes (each in its own run, --kernel-trace only), iteration pieces.  Copy
 # gpurun_out/${RTAG}_* into profiles/ afterwards.

@@ -144,8 +144,13 @@ def optimizer_options(train_cfg) -> dict:
 def check_supported(config: config_util.RootConfig, image_slider: bool = False):
     """Reject, before any model is loaded, every config value the fused path would otherwise have to ignore."""
     t = config.train
-    if config_util.parse_precision(t.precision) != torch.bfloat16:
-        raise NotImplementedError(f"train.precision '{t.precision}': the MI355X hot path computes in bf16 (the reference's default)")
+    prec = config_util.parse_precision(t.precision)
+    if prec not in (torch.bfloat16, torch.float32):
+        raise NotImplementedError(f"train.precision '{t.precision}': bfloat16 (the reference's default) and float32 are implemented; "
+                                  f"the MFMA path has no fp16 arithmetic")
+    if prec == torch.float32 and t.optimizer.lower() not in ("adam", "adamw"):
+        raise NotImplementedError(f"train.precision float32 with optimizer '{t.optimizer}': the fp32 adapter state is kept by the fused "
+                                  f"adam / adamw kernel only")
     name = t.noise_scheduler.lower().replace(" ", "_")
     if name not in ("ddim", "ddpm", "lms", "euler_a"):            # model_util.py:230-277
         raise ValueError(f"Unknown scheduler name: {name}")
@@ -157,6 +162,18 @@ def check_supported(config: config_util.RootConfig, image_slider: bool = False):
                                   f"fused with the VAE encode) is built on the ddim / ddpm alpha table; text sliders also accept lms / euler_a")
     optimizer_options(t)
     LrSchedule(t.lr_scheduler, t.lr, t.iterations)
+
+
+def adapter_state_dtype(config: config_util.RootConfig, rank: int = 0) -> torch.dtype:
+    """train.precision as the reference applies it to the LoRA network (train_lora_xl.py:60-61, 84-90: weight_dtype): the dtype of the
+    adapter parameters, of the optimizer's moments and of the saved checkpoint.  With float32 the reference ALSO runs the frozen UNet in
+    fp32; here the frozen UNet and the activations stay bf16 on the MFMA path (said once at start-up) - what float32 buys is what it
+    buys in the reference's mixed-precision practice: updates of 2e-4 x O(1) no longer vanish below the bf16 spacing of the weights."""
+    dt = config_util.parse_precision(config.train.precision)
+    if dt == torch.float32 and rank == 0:
+        print("train.precision float32: adapter parameters, AdamW moments and the checkpoint are fp32 (fused optimizer on an fp32 master); "
+              "the frozen UNet and the activations are computed in bf16 on the MFMA path - narrower than the reference's all-fp32 run")
+    return dt
 
 
 def check_model_files(name_or_path: str):
@@ -191,7 +208,8 @@ def train(config: config_util.RootConfig, prompts, device: int, xl: bool, synthe
                              f"{eng.cfg.cross_attention_dim} (SD-2.x: 1024, SD-1.x: 768)")
     torch.manual_seed(seed)
     store = LoraStore(eng.cfg, rank=config.network.rank, alpha=config.network.alpha,
-                      train_method=config.network.training_method, network_type=config.network.type, device=dev)
+                      train_method=config.network.training_method, network_type=config.network.type, device=dev,
+                      state_dtype=adapter_state_dtype(config, rank))
     opt = optimizer_options(config.train)
     hw0 = prompts[0].resolution // 8
     tr = SliderTrainer(eng, store, hw0, hw0, batch_size=prompts[0].batch_size, lr=config.train.lr, betas=opt["betas"],

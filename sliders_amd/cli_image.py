@@ -21,7 +21,8 @@ import torch
 
 from . import config_util, prompt_util
 from .train_util import get_add_time_ids, get_random_resolution_in_bucket
-from .cli import LrSchedule, _encoded_pairs, _synthetic_pairs, check_model_files, check_supported, optimizer_options
+from .cli import (LrSchedule, _encoded_pairs, _synthetic_pairs, adapter_state_dtype, check_model_files, check_supported,
+                  optimizer_options)
 from .image_trainer import ImageSliderTrainer
 from .lora_store import LoraStore
 from .model_util import load_unet_engine, synthetic_engine
@@ -102,7 +103,7 @@ def train(config, prompts, device: int, xl: bool, folder_main: str, folders, sca
                       train_method=config.network.training_method,
                       # train_lora-scale-xl.py:61-63: conv targets only for network.type c3lier; imagesliders/lora.py's list
                       network_type="c3lier-image" if config.network.type == "c3lier" else "lierla", device=dev,
-                      kaiming_a=5 ** 0.5)
+                      kaiming_a=5 ** 0.5, state_dtype=adapter_state_dtype(config, rank))
     opt = optimizer_options(config.train)
     hw = size // 8
     tr = ImageSliderTrainer(eng, store, vae, hw, hw, batch_size=1, lr=config.train.lr, betas=opt["betas"], eps=opt["eps"],

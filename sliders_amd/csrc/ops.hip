@@ -290,6 +290,28 @@ __global__ __launch_bounds__(256) void adamw_kernel(const slh_adamw_desc d, floa
     P[i] = (__bf16)p; M1[i] = (__bf16)m; M2[i] = (__bf16)v;
 }
 
+// fp32 adapter state (slh_adamw_desc.f32_state): torch.optim.AdamW's foreach path on fp32 CUDA tensors - every foreach op is its own
+// kernel there, so every line below is one fp32 rounding; inside lerp / addcmul / addcdiv the multiply-add is contracted to an fma
+// exactly as hipcc contracts it in ATen's functors (self + weight * diff, input + value * (t1 * t2), input + value * (t1 / t2)).
+__global__ __launch_bounds__(256) void adamw_f32_kernel(const slh_adamw_desc d, float decay, float bc2_sqrt,
+                                                        float neg_step_size, float w1, float beta2, float w2, float eps) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= d.n) return;
+    float* P = (float*)d.param; float* M1 = (float*)d.exp_avg; float* M2 = (float*)d.exp_avg_sq;
+    const float g = d.grad_scale == 1.0f ? d.grad[i] : d.grad[i] * d.grad_scale;
+    float p = P[i] * decay;                                     // _foreach_mul_(params, 1 - lr * wd)
+    float m = M1[i];
+    m = __builtin_fmaf(w1, g - m, m);                           // _foreach_lerp_(exp_avgs, grads, 1 - beta1)   (weight < 0.5 branch)
+    float v = M2[i] * beta2;                                    // _foreach_mul_(exp_avg_sqs, beta2)
+    v = __builtin_fmaf(w2, g * g, v);                           // _foreach_addcmul_(exp_avg_sqs, grads, grads, 1 - beta2)
+    float den = __builtin_sqrtf(v);                             // _foreach_sqrt
+    den = den / bc2_sqrt;                                       // _foreach_div_(., bias_correction2_sqrt)
+    den = den + eps;                                            // _foreach_add_(., eps)
+    p = __builtin_fmaf(neg_step_size, m / den, p);              // _foreach_addcdiv_(params, exp_avgs, denom, -step_size)
+    P[i] = p; M1[i] = m; M2[i] = v;
+    ((__bf16*)d.param_lo)[i] = (__bf16)p;
+}
+
 // ---- Lion over the flat LoRA buffer: lion_pytorch 0.1.2 update_fn op order, bf16 state -------------------
 __global__ __launch_bounds__(256) void lion_kernel(const slh_lion_desc d, float decay, float b1, float w1, float b2,
                                                    float w2, float neg_lr) {
@@ -391,6 +413,13 @@ extern "C" int slh_adamw(const slh_adamw_desc* d, slh_stream_t stream) {
     const float step_size = (float)(d->lr / bc1);
     const float bc2_sqrt = (float)sqrt(bc2);
     const float decay = (float)(1.0 - d->lr * d->weight_decay);
+    if (d->f32_state) {
+        SLH_CHECK(d->param_lo && ((uintptr_t)d->param & 3) == 0, "slh_adamw: f32_state needs param_lo (the bf16 copy the kernels read)");
+        hipLaunchKernelGGL(adamw_f32_kernel, dim3((unsigned)((d->n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, *d,
+                           decay, bc2_sqrt, -step_size, (float)(1.0 - d->beta1), (float)d->beta2, (float)(1.0 - d->beta2), (float)d->eps);
+        SLH_LAUNCH_CHECK("slh_adamw (fp32 state)");
+        return 0;
+    }
     hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)((d->n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, *d,
                        decay, bc2_sqrt, step_size, (float)(1.0 - d->beta1), (float)d->beta2, (float)(1.0 - d->beta2),
                        (float)d->eps);

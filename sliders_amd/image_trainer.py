@@ -24,7 +24,6 @@ from typing import Optional, Tuple
 import torch
 
 from . import lib
-from .parallel import allreduce_sum_
 from .trainer import PairEmbeds, SliderTrainer, _stream
 from .vae import VaeEncoder
 
@@ -72,6 +71,5 @@ class ImageSliderTrainer(SliderTrainer):
         self._polarity(pair.ctx_neutral, pair.pooled_neutral, img_low, post_noise, noise, noise_bf16, coeff, t_cur,
                        -float(scale), self.loss_low)
         self.eng.set_lora(False)
-        self.grad_scale = allreduce_sum_(st.grads, self.pg)
-        self.optimizer_step()
+        self.reduce_and_step()
         return self.loss_high, self.loss_low

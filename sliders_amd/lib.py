@@ -77,7 +77,7 @@ WgradDesc = _struct("WgradDesc", _ptrs("z0", "z1", "v", "out", "scale")
                             "wo", "M", "R", "ldv", "ldo", "out_rmajor", "vgroup_cols") + _ptrs("slabs", "tickets"))
 AdamwDesc = _struct("AdamwDesc", _ptrs("param", "exp_avg", "exp_avg_sq", "grad") + [("n", c_i64)]
                     + [(n, c_f64) for n in ("lr", "beta1", "beta2", "eps", "weight_decay")]
-                    + _ints("step") + [("grad_scale", c_f32)])
+                    + _ints("step") + [("grad_scale", c_f32)] + _ptrs("param_lo") + _ints("f32_state", "pad_"))
 LionDesc = _struct("LionDesc", _ptrs("param", "exp_avg", "grad") + [("n", c_i64)]
                    + [(n, c_f64) for n in ("lr", "beta1", "beta2", "weight_decay")] + [("grad_scale", c_f32)] + _ints("pad_"))
 MemsetDesc = _struct("MemsetDesc", _ptrs("ptr") + [("nbytes", c_i64)] + _ints("value", "pad"))

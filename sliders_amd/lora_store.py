@@ -57,7 +57,16 @@ class LoraEntry:
 
 class LoraStore:
     def __init__(self, cfg: UNetConfig, rank: int = 4, alpha: float = 1.0, train_method: str = "noxattn",
-                 network_type: str = "c3lier", device="cpu", init: str = "reference", kaiming_a: float = 1.0):
+                 network_type: str = "c3lier", device="cpu", init: str = "reference", kaiming_a: float = 1.0,
+                 state_dtype: torch.dtype = torch.bfloat16):
+        """state_dtype: dtype of the adapter parameters and optimizer moments - the reference's weight_dtype as it is applied to the
+        network (train_lora_xl.py:60-61, 84-90: network.to(device, dtype=weight_dtype)).  bfloat16 (the reference's default): one flat
+        bf16 buffer is both the optimizer's state and what the kernels read.  float32: `master` (fp32 parameters) and fp32 moments are
+        the optimizer's state; `params` stays the bf16 buffer the UNet kernels read, rewritten from the master by the optimizer kernel
+        in the same launch."""
+        if state_dtype not in (torch.bfloat16, torch.float32):
+            raise NotImplementedError(f"adapter state dtype {state_dtype}: bfloat16 or float32")
+        self.state_dtype = state_dtype
         self.cfg = cfg
         self.rank = rank
         self.alpha = rank if alpha is None or alpha == 0 else alpha
@@ -76,8 +85,9 @@ class LoraStore:
         n = self.numel
         self.params = torch.zeros(n, dtype=torch.bfloat16, device=device)
         self.grads = torch.zeros(n, dtype=torch.float32, device=device)
-        self.exp_avg = torch.zeros(n, dtype=torch.bfloat16, device=device)
-        self.exp_avg_sq = torch.zeros(n, dtype=torch.bfloat16, device=device)
+        self.exp_avg = torch.zeros(n, dtype=state_dtype, device=device)
+        self.exp_avg_sq = torch.zeros(n, dtype=state_dtype, device=device)
+        self.master = torch.zeros(n, dtype=torch.float32, device=device) if state_dtype == torch.float32 else None
         self.opt_step = 0
         self._build_up_t()
         if init == "reference":
@@ -224,11 +234,22 @@ class LoraStore:
                 continue                       # constructed (RNG advanced) and discarded, like the reference
             e = self.by_name[t.lora_name]
             host[e.down_off:e.down_off + e.down_numel] = self._down_to_kernel(e, down.weight.detach())
-        self.params.copy_(host.to(torch.bfloat16))
+        self._set_params(host)
+
+    def _set_params(self, host_f32: torch.Tensor):
+        """New parameter values (fp32, host or device): the fp32 master when there is one, and the bf16 buffer the kernels read."""
+        if self.master is not None:
+            self.master.copy_(host_f32)
+        self.params.copy_(host_f32.to(torch.bfloat16))
+
+    def sync_master_from_params(self):
+        """After writing `params` directly (tests, tools): make the fp32 master agree with it."""
+        if self.master is not None:
+            self.master.copy_(self.params.float())
 
     def state_dict(self, dtype: Optional[torch.dtype] = None) -> "OrderedDict[str, torch.Tensor]":
         """Reference key order per module: `<name>.alpha`, `<name>.lora_down.weight`, `<name>.lora_up.weight`."""
-        host = self.params.detach().to("cpu")
+        host = (self.master if self.master is not None else self.params).detach().to("cpu")
         sd = OrderedDict()
         for e in self.entries:
             if not e.trainable:
@@ -244,7 +265,7 @@ class LoraStore:
         return sd
 
     def load_state_dict(self, sd: Dict[str, torch.Tensor], strict: bool = True):
-        host = self.params.detach().to("cpu").to(torch.float32)
+        host = (self.master if self.master is not None else self.params).detach().to("cpu").to(torch.float32)
         seen = set()
         for e in self.entries:
             kd, ku = f"{e.name}.lora_down.weight", f"{e.name}.lora_up.weight"
@@ -259,7 +280,7 @@ class LoraStore:
             extra = set(sd.keys()) - seen
             if extra:
                 raise KeyError(f"unexpected key(s): {sorted(extra)[:4]} ...")
-        self.params.copy_(host.to(torch.bfloat16))
+        self._set_params(host)
 
     def n_trainable(self) -> int:
         return sum(e.down_numel + e.up_numel for e in self.entries if e.trainable)

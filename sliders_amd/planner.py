@@ -717,6 +717,9 @@ class UNetPlan:
                                                      bias=self.w.ptr("conv_in.b"), y=h.ptr, batch=B,
                                                      cin=cfg.in_channels, h=H, wd=W, cout=boc[0], ldy=h.ld), "conv_in")
         skips = [h]
+        # block name -> the activation diffusers' block returns (after its down / upsampler): read by the parity tests' per-block
+        # error ledger after a pass (no buffer is reused inside a pass, so they are all still there); nothing else uses it
+        self.block_out: Dict[str, Act] = {}
         for i, t in enumerate(cfg.down_block_types):
             path = f"down_blocks.{i}"
             cout = boc[i]
@@ -731,10 +734,12 @@ class UNetPlan:
                 p = f"{path}.downsamplers.0.conv"
                 h = self.gemm(h, p, cout, p, conv={"stride": 2}, lora_paths=[p])
                 skips.append(h)
+            self.block_out[path] = h
         mp = "mid_block"
         h = self._resnet(h, mp + ".resnets.0", boc[-1])
         h = self._transformer(h, mp + ".attentions.0", cfg.transformer_layers_per_block[-1], cfg.attention_head_dim[-1])
         h = self._resnet(h, mp + ".resnets.1", boc[-1])
+        self.block_out[mp] = h
         rboc = tuple(reversed(boc))
         rheads = tuple(reversed(cfg.attention_head_dim))
         rtl = tuple(reversed(cfg.transformer_layers_per_block))
@@ -750,6 +755,7 @@ class UNetPlan:
             if not final:
                 p = f"{path}.upsamplers.0.conv"
                 h = self.gemm(h, p, cout, p, conv={"xform": 1}, lora_paths=[p])
+            self.block_out[path] = h
         assert not skips
         g = self.groupnorm(h, "conv_norm_out", cfg.norm_eps, 1, "conv_norm_out")
         self.skinny(g, self.w.ptr("conv_out.w"), cfg.out_channels, 9 * g.C, {}, g.M, g.H, g.W, "conv_out",

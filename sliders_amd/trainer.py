@@ -80,6 +80,9 @@ class SliderTrainer:
         if optimizer not in ("adamw", "adam", "lion", "prodigy"):
             raise NotImplementedError(f"optimizer '{optimizer}': fused flat kernels exist for adam / adamw (slh_adamw) and lion "
                                       f"(slh_lion); prodigy runs as sliders_amd.optim.Prodigy on the flat parameter buffer")
+        if getattr(store, "master", None) is not None and optimizer not in ("adamw", "adam"):
+            raise NotImplementedError(f"optimizer '{optimizer}' with fp32 adapter state (train.precision: float32): only the fused "
+                                      f"adam / adamw kernel keeps an fp32 master; use bfloat16 for lion / prodigy")
         self.optimizer = optimizer
         self.optimizer_kwargs = dict(optimizer_kwargs or {})
         self._prodigy = None
@@ -95,6 +98,8 @@ class SliderTrainer:
             self.sched_generator.manual_seed(int(scheduler_seed))
         self.pg = process_group
         self.rank, self.world = world_info(process_group)
+        self.time_allreduce = False          # bench.py: bracket every gradient all-reduce with events (reduce_and_step)
+        self._ar_events = []
         self.grad_scale = 1.0
         engine.attach_lora(store) if engine.lora is not store else None
         self.loss = torch.zeros(1, dtype=torch.float32, device=engine.device)
@@ -208,11 +213,14 @@ class SliderTrainer:
 
     # ---- one iteration ------------------------------------------------------------------------------
     def iteration(self, pair: PairEmbeds, k: int, noise: torch.Tensor, lr: Optional[float] = None,
-                  time_ids: Optional[torch.Tensor] = None) -> torch.Tensor:
+                  time_ids: Optional[torch.Tensor] = None, zero_grads: bool = True, step: bool = True) -> torch.Tensor:
         """noise: (bs,4,H,W) already scaled by the scheduler's init_noise_sigma (train_util.py:55; 1 for ddim / ddpm, the
         largest sigma for lms / euler_a: `trainer.sched.init_noise_sigma`); its shape selects the resolution and batch of
         this iteration.  lr: this step's learning rate (the host evaluates the LR schedule, train_lora_xl.py:346-347).
         time_ids: (2*bs, 6) SDXL micro-conditioning when it is not the default [H,W,0,0,H,W] (dynamic_crops).
+        zero_grads = False: this pair's gradient ADDS to what the flat buffer holds (gradient accumulation over pairs);
+        step = False: stop after the backward - no all-reduce, no optimizer step (the caller finishes with `reduce_and_step`;
+        this is also how tests run N data-parallel ranks in one process).
         Returns the device loss scalar."""
         self._use(noise.shape[0], noise.shape[2], noise.shape[3])
         if time_ids is not None:
@@ -283,11 +291,36 @@ class SliderTrainer:
                          erase=1 if pair.action == "erase" else 0, hw=self.H * self.W, nch=eng.cfg.out_channels)
         lib.call(lib.OP_LOSS, d, s)
         # 5. backward into the flat fp32 gradient buffer, (all-reduce,) AdamW
-        st.grads.zero_()
+        if zero_grads:
+            st.grads.zero_()
         bw.prog.run(s)
-        self.grad_scale = allreduce_sum_(st.grads, self.pg)     # ONE collective per optimizer step
-        self.optimizer_step()
+        if step:
+            self.reduce_and_step()
         return self.loss
+
+    def reduce_and_step(self, n_accumulated: int = 1):
+        """The exchange step of data parallelism and the optimizer: ONE sum all-reduce of the flat fp32 gradient buffer per
+        optimizer step, issued on the stream the backward ran on (the collective is ordered behind the last weight-gradient
+        launch and ahead of the optimizer kernel by stream order alone - no host synchronisation, no side stream), the mean over
+        ranks (x accumulated pairs) folded into the optimizer kernel.  With `time_allreduce` set the collective is bracketed by
+        two events on that stream; `allreduce_ms()` reads them back after the caller's synchronisation."""
+        st = self.store
+        cur = torch.cuda.current_stream()
+        timed = self.time_allreduce and (self.pg is not None or self.world > 1)
+        if timed:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(cur)
+        self.grad_scale = allreduce_sum_(st.grads, self.pg) / float(n_accumulated)
+        if timed:
+            e1.record(cur)
+            self._ar_events.append((e0, e1))
+        self.optimizer_step()
+
+    def allreduce_ms(self):
+        """Event times of the all-reduces since the last call (ms each); call after a device synchronisation."""
+        out = [a.elapsed_time(b) for a, b in self._ar_events]
+        self._ar_events = []
+        return out
 
     def optimizer_step(self):
         st = self.store
@@ -311,7 +344,9 @@ class SliderTrainer:
                              grad_scale=self.grad_scale)
             lib.call(lib.OP_LION, d, _stream())
             return
-        d = lib.AdamwDesc(param=st.params.data_ptr(), exp_avg=st.exp_avg.data_ptr(), exp_avg_sq=st.exp_avg_sq.data_ptr(),
-                          grad=st.grads.data_ptr(), n=st.numel, lr=self.lr, beta1=self.betas[0], beta2=self.betas[1],
-                          eps=self.eps, weight_decay=self.wd, step=st.opt_step, grad_scale=self.grad_scale)
+        f32 = st.master is not None          # train.precision float32: fp32 master + moments, bf16 copy rewritten in the same launch
+        d = lib.AdamwDesc(param=(st.master if f32 else st.params).data_ptr(), exp_avg=st.exp_avg.data_ptr(),
+                          exp_avg_sq=st.exp_avg_sq.data_ptr(), grad=st.grads.data_ptr(), n=st.numel, lr=self.lr, beta1=self.betas[0],
+                          beta2=self.betas[1], eps=self.eps, weight_decay=self.wd, step=st.opt_step, grad_scale=self.grad_scale,
+                          param_lo=st.params.data_ptr() if f32 else 0, f32_state=1 if f32 else 0)
         lib.call(lib.OP_ADAMW, d, _stream())

@@ -40,7 +40,8 @@ def _cpu_threads():
 # run first and the tests that build multi-GB fp32 oracles last (round 2: a flaky bound in the first heavy file kept the
 # whole VAE / image-slider / sampler file from running).
 _GPU_ORDER = ["test_kernels_gpu", "test_graph_gpu", "test_vae_gpu", "test_schedulers_gpu", "test_loader_gpu", "test_trainer_gpu", "test_cli_gpu",
-              "test_seam_gpu", "test_rccl_gpu", "test_backward_gpu", "test_unet_gpu", "test_bench_config_gpu"]
+              "test_seam_gpu", "test_rccl_gpu", "test_dp_sim_gpu", "test_backward_gpu", "test_unet_gpu", "test_parity_r04_gpu",
+              "test_bench_config_gpu", "test_parity_r05_gpu"]
 
 
 def pytest_collection_modifyitems(session, config, items):

@@ -23,7 +23,7 @@ network:
   alpha: 1.0
   training_method: "noxattn"
 train:
-  precision: "bfloat16"
+  precision: "{prec}"
   noise_scheduler: "{sched}"
   iterations: {iters}
   lr: 0.0002
@@ -70,16 +70,19 @@ def _run(script, args, tmp_path, timeout=500):
 
 
 @pytest.mark.timeout(600)
-@pytest.mark.parametrize("sched,opt,lrs,dyn", [("ddim", "AdamW", "constant", "true"), ("euler_a", "lion", "cosine", "false")])
-def test_text_slider_cli_end_to_end(dev, tmp_path, sched, opt, lrs, dyn):
+@pytest.mark.parametrize("sched,opt,lrs,dyn,prec", [("ddim", "AdamW", "constant", "true", "bfloat16"),
+                                                    ("euler_a", "lion", "cosine", "false", "bfloat16"),
+                                                    # train.precision float32 (config_util.py:75-83): fp32 adapter state + fp32 checkpoint
+                                                    ("ddim", "AdamW", "constant", "false", "float32")])
+def test_text_slider_cli_end_to_end(dev, tmp_path, sched, opt, lrs, dyn, prec):
     """train_lora.py on the SD-1.x architecture: two prompt pairs (enhance / erase), dynamic_resolution on one of them (a new
     (H, W) bucket almost every iteration: the plan cache and the zero-init arena are exercised the way a real run does),
     a non-default scheduler / optimizer / LR schedule in the second case; the saved file has the reference's keys."""
     prompts = tmp_path / "prompts.yaml"
     prompts.write_text(PROMPTS.format(dyn=dyn))
     cfg = tmp_path / "config.yaml"
-    cfg.write_text(CONFIG.format(prompts=prompts, sched=sched, iters=6, opt=opt, lrs=lrs, name="cli", out=tmp_path / "models"))
-    _run("trainscripts/textsliders/train_lora.py", ["--config_file", str(cfg), "--synthetic", "--name", "clitest"], tmp_path)
+    cfg.write_text(CONFIG.format(prompts=prompts, sched=sched, iters=6, opt=opt, lrs=lrs, name="cli", out=tmp_path / "models", prec=prec))
+    r = _run("trainscripts/textsliders/train_lora.py", ["--config_file", str(cfg), "--synthetic", "--name", "clitest"], tmp_path)
     files = [os.path.join(dp, f) for dp, _, fs in os.walk(tmp_path / "models") for f in fs if f.endswith(".pt")]
     assert files, "no checkpoint written"
     sd = torch.load(files[0], map_location="cpu")
@@ -90,6 +93,13 @@ def test_text_slider_cli_end_to_end(dev, tmp_path, sched, opt, lrs, dyn):
     assert all(sd[k].shape == ref[k].shape for k in ref)
     ups = [v.float() for k, v in sd.items() if k.endswith("lora_up.weight")]
     assert all(torch.isfinite(u).all() for u in ups) and any(float(u.abs().max()) > 0 for u in ups), "the adapters did not train"
+    want = torch.float32 if prec == "float32" else torch.bfloat16        # the reference saves in train.precision (quirk D.7)
+    assert all(v.dtype == want for v in sd.values())
+    if prec == "float32":
+        assert "adapter parameters, AdamW moments and the checkpoint are fp32" in r.stdout
+        # after 6 steps of lr 2e-4 the fp32 master holds updates a bf16 parameter could not represent: the saved up matrices are not
+        # bf16-representable numbers
+        assert any((u != u.to(torch.bfloat16).float()).any() for u in ups)
 
 
 @pytest.mark.timeout(600)
@@ -106,7 +116,8 @@ def test_image_slider_cli_end_to_end(dev, tmp_path):
     prompts = tmp_path / "prompts.yaml"
     prompts.write_text(PROMPTS.format(dyn="false"))
     cfg = tmp_path / "config.yaml"
-    cfg.write_text(CONFIG.format(prompts=prompts, sched="ddim", iters=4, opt="AdamW", lrs="constant", name="img", out=tmp_path / "models"))
+    cfg.write_text(CONFIG.format(prompts=prompts, sched="ddim", iters=4, opt="AdamW", lrs="constant", name="img", out=tmp_path / "models",
+                                 prec="bfloat16"))
     _run("trainscripts/imagesliders/train_lora-scale.py",
          ["--config_file", str(cfg), "--synthetic", "--alpha", "1.0", "--name", "imgtest", "--folder_main", str(tmp_path / "imgs"),
           "--folders", "low, high", "--scales", "-1, 1"], tmp_path)

@@ -419,9 +419,14 @@ def test_optimizer_options_and_rejections():
     for bad in (dict(optimizer="lion", optimizer_args="eps=1e-6"), dict(optimizer="lion", optimizer_args="use_triton=True"),
                 dict(optimizer="prodigy", optimizer_args="amsgrad=True"), dict(optimizer="adam8bit"), dict(optimizer="dadaptlion"),
                 dict(optimizer="adam", optimizer_args="weight_decay=0.01"), dict(optimizer_args="amsgrad=True"),
-                dict(precision="float32"), dict(precision="fp16"), dict(lr_scheduler="linear")):
+                dict(precision="fp16"), dict(precision="float32", optimizer="lion"), dict(lr_scheduler="linear")):
         with pytest.raises(NotImplementedError):
             check_supported(_cfg(**bad))
+    # train.precision float32 (config_util.py:75-83 -> weight_dtype, train_lora_xl.py:60-61, 84-90): fp32 adapter state with adam / adamw
+    from sliders_amd.cli import adapter_state_dtype
+    check_supported(_cfg(precision="float32"))
+    check_supported(_cfg(precision="fp32", optimizer="adam"))
+    assert adapter_state_dtype(_cfg(precision="float32"), rank=1) == torch.float32 and adapter_state_dtype(_cfg()) == torch.bfloat16
     # prodigyopt.Prodigy's arguments and defaults (requirements.txt: prodigyopt==1.0), lr = 1 is the user's business
     o = optimizer_options(_cfg(optimizer="Prodigy", optimizer_args="weight_decay=0.01 d_coef=2.0 safeguard_warmup=True").train)
     assert o["name"] == "prodigy" and o["weight_decay"] == 0.01 and o["d_coef"] == 2.0 and o["safeguard_warmup"] is True
@@ -720,3 +725,28 @@ def test_fused_cross_attention_gate_matches_the_kernel_checks(ctx_len, fused):
     n_cross = sum(1 for n in p.prog.op_names if n.endswith("attn2.sdpa"))
     n_blocks = sum(1 for n in p.prog.op_names if n.endswith("attn2.q"))
     assert n_cross + len(xa) == n_blocks          # every block runs its cross-attention exactly once, one way or the other
+
+
+def test_fp32_adapter_state_store_layout_and_checkpoint(tmp_path):
+    """train.precision float32: LoraStore keeps an fp32 master + fp32 moments next to the bf16 buffer the kernels read; the reference
+    draws of the initialisation land in both; the checkpoint is written from the master in fp32 (the reference saves in train.precision,
+    quirk D.7) and strict-loads back without loss; a bf16 store has no master at all."""
+    cfg = CONFIGS["tiny_sdxl"]()
+    torch.manual_seed(4)
+    s32 = LoraStore(cfg, rank=4, alpha=1.0, train_method="noxattn", state_dtype=torch.float32)
+    torch.manual_seed(4)
+    s16 = LoraStore(cfg, rank=4, alpha=1.0, train_method="noxattn")
+    assert s16.master is None and s16.exp_avg.dtype == torch.bfloat16
+    assert s32.master.dtype == s32.exp_avg.dtype == s32.exp_avg_sq.dtype == torch.float32 and s32.params.dtype == torch.bfloat16
+    assert torch.equal(s32.params, s16.params) and torch.equal(s32.master.to(torch.bfloat16), s32.params)
+    assert (s32.master != s32.params.float()).any(), "the master keeps the bits bf16 drops"
+    g = torch.Generator().manual_seed(1)
+    s32.master.add_(torch.randn(s32.numel, generator=g) * 1e-3)
+    sd = s32.state_dict(torch.float32)
+    assert all(v.dtype == torch.float32 for v in sd.values())
+    torch.save(sd, tmp_path / "a.pt")
+    t = LoraStore(cfg, rank=4, alpha=1.0, train_method="noxattn", state_dtype=torch.float32, init="none")
+    t.load_state_dict(torch.load(tmp_path / "a.pt"), strict=True)
+    assert torch.equal(t.master, s32.master) and torch.equal(t.params, s32.master.to(torch.bfloat16))
+    with pytest.raises(NotImplementedError):
+        LoraStore(cfg, state_dtype=torch.float16)

@@ -937,6 +937,48 @@ def test_adamw_bit_exact(dev):
     assert mism == 0, "AdamW not bit-exact"
 
 
+def test_adamw_fp32_state_bit_exact(dev):
+    """slh_adamw with f32_state (train.precision: float32 - fp32 adapter parameters and moments, train_lora_xl.py:60-61, 84-90): the
+    fp32 master and both moments against torch.optim.AdamW stepping fp32 tensors ON THE DEVICE (the reference trains on the GPU:
+    the default foreach path), ten steps with weight decay and a changing lr; the bf16 copy the UNet kernels read is the rounded
+    master.  Exactness is reported per step; the assertion allows the last fp32 bit on a small fraction (an fma contracted
+    differently inside one of torch's foreach functors would show exactly there) and nothing else."""
+    torch.manual_seed(14)
+    n = 10007
+    p0 = torch.randn(n) * 0.05
+    param = torch.nn.Parameter(p0.clone().to(dev))
+    opt = torch.optim.AdamW([param], lr=2e-4, weight_decay=0.01)
+    master = p0.clone().to(dev)
+    lo = torch.zeros(n, device=dev, dtype=torch.bfloat16)
+    m = torch.zeros(n, device=dev)
+    v = torch.zeros(n, device=dev)
+    worst = 0
+    for step in range(1, 11):
+        lr = 2e-4 * (1.0 - 0.05 * step)
+        for grp in opt.param_groups:
+            grp["lr"] = lr
+        g = (torch.randn(n) * 1e-3).to(dev)
+        param.grad = g.clone()
+        opt.step()
+        d = lib.AdamwDesc(param=p(master), exp_avg=p(m), exp_avg_sq=p(v), grad=p(g), n=n, lr=lr, beta1=0.9, beta2=0.999,
+                          eps=1e-8, weight_decay=0.01, step=step, grad_scale=1.0, param_lo=p(lo), f32_state=1)
+        lib.call(lib.OP_ADAMW, d, stream())
+        torch.cuda.synchronize()
+        st = opt.state[param]
+        diffs = {}
+        for nm, a, b in (("param", master, param.data), ("exp_avg", m, st["exp_avg"]), ("exp_avg_sq", v, st["exp_avg_sq"])):
+            ulps = (a.view(torch.int32).long() - b.view(torch.int32).long()).abs()
+            diffs[nm] = (int((ulps > 0).sum()), int(ulps.max()))
+        print(f"[parity] adamw fp32 state step {step}: (elements differing, worst fp32 ulp) vs torch.optim.AdamW(fp32, cuda) = {diffs}")
+        worst = max(worst, max(w for _, w in diffs.values()))
+        assert torch.equal(lo, master.to(torch.bfloat16)), "param_lo is the rounded master"
+        assert all(cnt <= n // 50 and w <= 2 for cnt, w in diffs.values()), diffs
+    d.param_lo = 0
+    with pytest.raises(lib.SlidersHipError, match="param_lo"):
+        lib.call(lib.OP_ADAMW, d, stream())
+    print(f"[parity] adamw fp32 state: worst difference over 10 steps {worst} fp32 ulp")
+
+
 def test_lion_bit_exact(dev):
     """slh_lion against the oracle's restatement of lion_pytorch 0.1.2, five steps with weight decay, including exact-zero
     updates (sign(0) = 0).  The oracle's tensor ops run ON THE GPU here: the reference trains on cuda, where

@@ -99,3 +99,9 @@ def test_bench_under_torchrun_one_rank(dev):
     assert cfg_["unet_denoise_steps_timed"] % world == 0 and cfg_["unet_denoise_steps_timed"] >= world * res["steps"] * 5
     assert abs(res["value"] - cfg_["unet_denoise_steps_timed"] / (res["ms_per_step"] * 1e-3 * res["steps"])) < 0.02 * res["value"]
     assert abs(cfg_["iterations_per_s"] - world * 1e3 / res["ms_per_step"]) < 0.02 * cfg_["iterations_per_s"]
+    # round 5: the run checks itself - every rank's adapter replica digest is all-gathered after the timed region and must be equal,
+    # and every gradient all-reduce of the timed loop is bracketed by events on the stream it is ordered on (compute / comm split)
+    dp = res["data_parallel"]
+    assert dp["rccl_ranks_seen"] == world and dp["replicas_bit_identical"] is True and dp["adapter_state_digest"].startswith("0x")
+    assert dp["allreduces_timed_per_rank"] == res["steps"] and len(dp["allreduce_us_mean_per_rank"]) == world
+    assert 0 < dp["allreduce_us_mean_per_rank"][0] < 5e4 and dp["allreduce_bytes"] > 0
