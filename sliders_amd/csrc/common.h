@@ -76,6 +76,27 @@ __device__ __forceinline__ unsigned lds_addr_of(const void* p) {
     return (unsigned)(uintptr_t)(const __attribute__((address_space(3))) char*)p;
 }
 
+// ---- write-through result stores (round 5) ------------------------------------------------------------------------------------
+// A kernel's results are consumed by the NEXT launch, on other XCDs as much as on this one: the per-XCD L2s are not coherent, so
+// the end of every kernel writes this XCD's dirty lines back (the implicit release) before the next dispatch may start.  Stored
+// write-through (sc0 sc1), the bytes leave for the memory side while the kernel is still busy and the end-of-kernel write-back finds
+// nothing to do: -0.5 us per launch on the 128 x 128 GEMM tile (2048 x 1280 x 64: 8.4 -> 7.9 us), SDXL 1024^2 pass 24.02 -> 23.82 ms
+// with the GEMM row stores and the GroupNorm / LayerNorm stores in this form (same box, three alternations:
+// profiles/r05_write_through_stores.txt); the consumer reads from the memory-side cache either way.  16-BYTE STORES ONLY: written
+// through, the 8-byte quads of the GEGLU epilogue cost the pass +0.65 ms and those of the attention kernels +0.3 ms (a scalar
+// write-through store is one fabric write each) - they stay plain.  nt measured neutral, sc1 alone slightly behind sc0 sc1.
+// SLH_WT_MASK (A/B builds, scripts/build_variant_all.sh): bit 0 GEMM row stores, bit 3 GroupNorm / LayerNorm; 0 = all plain.
+#ifndef SLH_WT_MASK
+#define SLH_WT_MASK 9
+#endif
+constexpr int SLH_WT_AUX = 17;     // sc0 | sc1
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t wt_rsrc(const void* base) {       // base: wave-uniform
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, 0x7FFFFFF0, 0x00020000);
+}
+__device__ __forceinline__ void wt_store16(const __amdgpu_buffer_rsrc_t r, const long byte_off, const bf16x8 v) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, (unsigned)byte_off, 0, SLH_WT_AUX);
+}
+
 // ---- fixed-order cross-workgroup reductions -----------------------------------------------------------------------
 // Every reduction whose result feeds bf16 activations (GroupNorm statistics, split-K partial sums) is done in a fixed
 // order: fp32 atomics commit in arrival order, the last bits of the sum then differ from run to run, a bf16 rounding

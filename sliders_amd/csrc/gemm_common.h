@@ -396,15 +396,23 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, char* smem, f32
     if (p.geglu == 3) {
         // GEGLU, 32-row weight blocks [16 value rows | 16 gate rows] (slh_gemm_desc.geglu = 3; any NI): inside one 32 x 32
         // accumulator block the quads q = 0, 1 are values and q = 2, 3 the gates of the same 16 output columns, in the same lane.
+        // The results leave like those of the ordinary path: through a wave-private staging patch as whole 16-byte row segments,
+        // written through (round 5; the 8-byte quad per lane and row - 32 cache lines per store instruction - measured +2..3 us per
+        // launch of GEGLU.proj and cannot be written through: common.h).  SLH_GEGLU_STORE8 (A/B builds) keeps the quads.
         __syncthreads();
+        constexpr int SG = 2 * NI;               // 16-byte slots of a staged output row: 16 output columns per 32 x 32 block
+        constexpr int GROW = SG * 16 + 16;       // patch row stride; + 16: the rows of one quad write fall on distinct banks
+        static_assert(32 * GROW <= 32 * S * 16, "the GEGLU staging patch lives inside the wave's store patch");
+        char* sG = smem + wave * (32 * S * 16);
+        const __amdgpu_buffer_rsrc_t g_rsrc = wt_rsrc(p.c);
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
-            const int m = m0 + wm * (32 * MI) + i * 32 + lrow;
-            if (m >= p.M) continue;
+            const int mbase = m0 + wm * (32 * MI) + i * 32;
+            const int m = mbase + lrow;
 #pragma unroll
             for (int j = 0; j < NI; ++j) {
                 const int nb = n0 + wn * (32 * NI) + j * 32;               // first weight row of the block
-                if (nb >= p.N) continue;                                    // N % 32 == 0: blocks are whole
+                if (nb >= p.N) continue;                                    // N % 32 == 0: blocks are whole (wave-uniform)
 #pragma unroll
                 for (int q = 0; q < 2; ++q) {
                     const int cl = nb - n0 + q * 8 + lhi * 4;               // tile column of the value quad (gate: + 16)
@@ -431,9 +439,34 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, char* smem, f32
                         const float av = round_bf16(a[e]), gv = round_bf16(g[e]);   // the reference rounds proj(x) to bf16 before chunk / gelu
                         o[e] = (__bf16)(av * round_bf16(gelu_erf_f(gv)));
                     }
-                    *(bf16x4*)(p.c + (long)m * p.ldc + (nb >> 1) + q * 8 + lhi * 4) = o;
+#ifdef SLH_GEGLU_STORE8
+                    if (m < p.M) *(bf16x4*)(p.c + (long)m * p.ldc + (nb >> 1) + q * 8 + lhi * 4) = o;
+#else
+                    *(bf16x4*)(sG + lrow * GROW + j * 32 + q * 16 + lhi * 8) = o;
+#endif
                 }
             }
+#ifndef SLH_GEGLU_STORE8
+            __builtin_amdgcn_wave_barrier();       // same-wave LDS ops retire in order; only the compiler must not reorder
+#pragma unroll
+            for (int it = 0; it < SG / 2; ++it) {
+                const int idx = it * 64 + lane;
+                const int row = idx / SG, slot = idx - row * SG;
+                const bf16x8 t8 = *(const bf16x8*)(sG + row * GROW + slot * 16);
+                const int m2 = mbase + row;
+                const int nblk = n0 + wn * (32 * NI) + (slot >> 1) * 32;               // the weight-row block this slot came from
+                const long off = (long)m2 * p.ldc + ((n0 + wn * (32 * NI)) >> 1) + slot * 8;
+                if (m2 < p.M && nblk < p.N) {
+                    if (p.store16) {
+                        wt_store16(g_rsrc, off * 2, t8);
+                    } else {
+                        *(bf16x4*)(p.c + off) = __builtin_shufflevector(t8, t8, 0, 1, 2, 3);
+                        *(bf16x4*)(p.c + off + 4) = __builtin_shufflevector(t8, t8, 4, 5, 6, 7);
+                    }
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+#endif
         }
         return;
     }
@@ -666,6 +699,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, char* smem, f32
         }
     }
     const bool epi_ln = ln_on && !xa && !ln_done, epi_bias = p.bias != nullptr && !xa;     // (consumed above where xa / ln_done)
+    const __amdgpu_buffer_rsrc_t c_rsrc = wt_rsrc(p.c);
     char* sE = smem + wave * (32 * S * 16);
     const float lscale = (LORA || p.lora_t != nullptr) ? *p.lora_scale : 0.f;
     const int ncol0 = n0 + wn * (32 * NI);
@@ -884,7 +918,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, char* smem, f32
                 __bf16* dst = p.c + (long)m2 * p.ldc + n2;
                 if (n2 + 8 <= p.N) {
                     if (p.store16) {
-                        *(bf16x8*)dst = t8;
+                        if constexpr (SLH_WT_MASK & 1) wt_store16(c_rsrc, ((long)m2 * p.ldc + n2) * 2, t8);   // write-through (common.h)
+                        else *(bf16x8*)dst = t8;
                     } else {
                         *(bf16x4*)dst = __builtin_shufflevector(t8, t8, 0, 1, 2, 3);
                         *(bf16x4*)(dst + 4) = __builtin_shufflevector(t8, t8, 4, 5, 6, 7);

@@ -178,7 +178,8 @@ __global__ void gn_apply_kernel(const slh_gn_desc d, int nchunk, int rpi, int ro
             if (d.act == 1) y = silu_f(round_bf16(y));  // reference rounds the GroupNorm output to bf16 before SiLU
             o[e] = (__bf16)y;
         }
-        *(bf16x8*)((__bf16*)d.y + row * d.ldy + c) = o;
+        if constexpr (SLH_WT_MASK & 8) wt_store16(wt_rsrc(d.y), (row * d.ldy + c) * 2, o);      // write-through (common.h)
+        else *(bf16x8*)((__bf16*)d.y + row * d.ldy + c) = o;
     }
 }
 
@@ -457,7 +458,8 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const slh_ln_desc d) {
             bf16x8 o;
 #pragma unroll
             for (int e = 0; e < 8; ++e) o[e] = (__bf16)((v[j][e] - mean) * rstd * (float)gv[j][e] + (float)bv[j][e]);
-            *(bf16x8*)(y + c) = o;
+            if constexpr (SLH_WT_MASK & 8) wt_store16(wt_rsrc(d.y), ((long)m * d.ldy + c) * 2, o);
+            else *(bf16x8*)(y + c) = o;
         }
     }
 }
