@@ -31,6 +31,5 @@ timeout 300 python scripts/time_train_iter.py --breakdown > $O/${RTAG}_iteration
 timeout 200 python scripts/probe_gn.py > $O/${RTAG}_probe_gn.txt 2>&1
 timeout 200 python scripts/probe_attn.py > $O/${RTAG}_probe_attn.txt 2>&1
 cut -c1-220 $O/${RTAG}_bench_line.json; cat $O/${RTAG}_fwd_kernel_gaps.txt | tail -3; head -4 $O/${RTAG}_pmc_mfma_busy_fwd_lora_on.csv | cut -c1-200
-# frozen B=3 pass beside the training forward on a second stream (the default) against back to back (SLIDERS_OVERLAP_FROZEN=0): same-box A/B
-SLIDERS_OVERLAP_FROZEN=0 timeout 300 python bench.py --no-cpu-baseline --no-extra > $O/${RTAG}_bench_no_overlap_frozen.json 2> $O/${RTAG}_bench_no_overlap_frozen.err
-cut -c1-200 $O/${RTAG}_bench_no_overlap_frozen.json
+timeout 300 python scripts/insitu_gemms.py > $O/${RTAG}_insitu_gemm_shapes.txt 2>&1
+tail -45 $O/${RTAG}_insitu_gemm_shapes.txt | cut -c1-160
