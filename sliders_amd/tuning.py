@@ -34,6 +34,11 @@ def tile_ok(d, tile: int) -> bool:
         return tile == 0x4412
     if tile >> 20:                                # bits 20+ are reserved (round 4's stream-K form lived there; removed)
         return False
+    if getattr(d, "ln_in", None) and d.lora_down:     # LayerNorm fold + fused adapter: ping-pong 128 x 192 / 128 x 256, no split-K
+        return wm == 8 and mi == 1 and ni in (3, 4) and not (tile >> 16) & 15 and \
+            (not d.vt_out or (ni == 4 and d.mode == 0))
+    if getattr(d, "ln_in", None) and (tile >> 16) & 15 > 1:      # a folded LayerNorm excludes split-K
+        return False
     if wm == 8 and (tile >> 16) & 15:             # split-K: the slabs of these tiles must fit the workspace contract
         bm, bn = (256, 256) if mi == 4 else (128 * mi, 64 * ni)
         r = lambda v, q: (v + q - 1) // q * q

@@ -95,7 +95,7 @@ def test_engine_matches_reference_fixture_directly(dev, key):
     assert abs(eff_hip - eff) < 0.25 * eff + 2e-3
     # bf16 storage of a unit-variance epsilon resolves 2^-9 relative per element (rel-L2 floor ~2.3e-3 for ONE rounding); the tiny
     # nets' bf16 chains measure 0.8-1.6e-2 against fp32 for the torch-bf16 arm as well (tests/test_unet_gpu.py).  Bounds = 1.3 x the
-    # values measured on MI355X (profiles/r04_parity_lines.txt); guidance 3 amplifies the CFG difference by 3.
+    # values measured on MI355X (profiles/r05_parity_lines.txt: every [parity] line of the GPU suite); guidance 3 amplifies the CFG difference by 3.
     assert out["eps_on"][0] < 2.0e-2 and out["eps_off"][0] < 2.0e-2
     assert out["pred_on_g3"][0] < 4.6e-2
     assert out["denoised_3"][0] < 1.5e-2
@@ -316,7 +316,7 @@ def test_full_width_iteration_sdxl_512(dev):
     print(f"[parity] full-width SDXL 512^2 iteration (k={k}): denoised rel_l2={r_den:.3e} target-eps rel_l2={r_tgt:.3e} "
           f"loss {loss_e:.5e} vs fp32 {loss.item():.5e} ({abs(loss_e - loss.item()) / loss.item():.2e}) grad cosine {cos:.5f} "
           f"grad rel_l2={rel_err(g_e, g32):.3e}  [{time.time() - t0:.0f} s]")
-    # measured on MI355X: 3.6e-3 / 9.0e-3 / 0.56 % / cosine 1.0000 / gradient rel-L2 1.6e-2 (profiles/r04_parity_lines.txt); bounds 1.3 x
+    # measured on MI355X: 3.6e-3 / 9.0e-3 / 0.56 % / cosine 1.0000 / gradient rel-L2 1.6e-2 (profiles/r05_parity_lines.txt: every [parity] line of the GPU suite); bounds 1.3 x
     assert r_den < 5e-3 and r_tgt < 1.2e-2
     assert abs(loss_e - loss.item()) < 0.015 * loss.item()
     assert cos > 0.998 and rel_err(g_e, g32) < 2.5e-2

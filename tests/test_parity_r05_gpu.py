@@ -12,6 +12,9 @@ adapters off / on at B = 2 only.  This file widens it:
      M = 3072 tile-table entries and attention grids).
   3. `test_bench_config_train_plan_and_backward`: the `train` plan (geglu_pre, ln_mr_out, vt_also_c, tape) + backward (split-M
      weight-gradient slabs) at latent 128x128 against fp32 autograd.
+  4. `test_trained_slider_moves_epsilon_along_the_guidance_direction`: the offline proxy for "trained sliders reproduce the
+     reference's CLIP-score direction" stated on what a trained slider DOES at inference (effect of scale +1 vs -1 on a held-out
+     latent), for a slider trained by the HIP trainer and one trained by the reference loop on the oracle.
 
 Truth for these is the fp32 oracle executed with torch ops ON THE GPU (MIOpen off: convolution = im2col + GEMM; fp32 GEMMs are
 exact fp32 on gfx950, there is no TF32) - 25 full-size fp32 passes on the host cores would take half an hour.  The host-core fp32
@@ -218,3 +221,82 @@ def test_bench_config_train_plan_and_backward(dev):
     assert torch.isfinite(got).all()
     assert cos >= 0.999, f"gradient direction off: cos={cos}"
     assert r_eng <= r_ref + 2e-3, f"engine {r_eng:.3e} vs reference-precision arm {r_ref:.3e}"
+
+
+@pytest.mark.parametrize("action", ["enhance", "erase"])
+def test_trained_slider_moves_epsilon_along_the_guidance_direction(dev, action):
+    """The offline proxy for north_star's "trained slider weights reproduce the reference's CLIP-score direction" (the acceptance the
+    reference measures with eval-scripts/clip_score.py:24-72 over images generated at slider scales; no checkpoint, CLIP weights or
+    image decoder exist here): WHAT a trained slider does to the prediction, not what its weights look like.
+
+    Train 30 iterations with the fused HIP trainer and, in parallel, with the reference loop + torch.optim.AdamW on the fp32 oracle
+    (same pair, noises and k).  Then, on a HELD-OUT latent and timestep, the slider's effect at inference
+        effect = eps(x, t, target | slider scale +1) - eps(x, t, target | slider scale -1)        (XL notebook cell 6: +- scales)
+    is compared between the two trained sliders and with the direction the guidance loss trains toward,
+        dir = eps_frozen(positive) - eps_frozen(unconditional)          (prompt_util.py:108-148; sign flipped for `erase`).
+    Asserted: both sliders push epsilon the way the loss asks (positive projection on dir - the mechanism by which the attribute's
+    CLIP score rises with the slider scale), the engine-trained slider's effect points where the reference-trained one's does, with
+    the same strength."""
+    from tests.test_parity_r04_gpu import _oracle_with_lora, _pair, _ref_iteration, _setup
+    from oracle.unet_oracle import build_unet
+    from sliders_amd.trainer import SliderTrainer
+    name, hw, gs, steps, lr = "tiny_sdxl", 16, 4.0, 30, 2e-3
+    cfg, emb, pool, _, g = _setup(name, seed=33)
+    store = LoraStore(cfg, rank=4, alpha=1.0, train_method="noxattn", device=dev)        # the reference's init: lora_up = 0
+    sd0 = store.state_dict()
+    noises = [torch.randn(1, 4, hw, hw, generator=g) for _ in range(steps)]
+    ks = [1 + (i % 4) for i in range(steps)]
+    eng = UNetEngine(cfg, build_unet(name, seed=0).state_dict(), dev)
+    tr = SliderTrainer(eng, store, hw, hw, lr=lr)
+    pair = _pair(emb, pool, dev, action, gs)
+    for i in range(steps):
+        tr.iteration(pair, ks[i], noises[i].to(dev))
+    torch.cuda.synchronize()
+    net, nw = _oracle_with_lora(name, sd0, torch.float32)
+    opt = torch.optim.AdamW(nw.prepare_optimizer_params() if hasattr(nw, "prepare_optimizer_params") else nw.parameters(), lr=lr)
+    for i in range(steps):
+        opt.zero_grad()
+        _ref_iteration(net, nw, cfg, emb, pool, noises[i], ks[i], action, gs, torch.float32, hw)
+        opt.step()
+    # held-out probe
+    xp = torch.randn(1, 4, hw, hw, generator=g).to(torch.bfloat16).float()
+    t_probe = 441
+    tid = torch.tensor([[hw * 8.0, hw * 8.0, 0, 0, hw * 8.0, hw * 8.0]])
+    r = lambda a: a.to(torch.bfloat16).float()
+
+    def oracle_eps(which, scale):
+        kw = {"text_embeds": r(pool[which]), "time_ids": tid} if cfg.is_xl else None
+        with torch.no_grad():
+            if scale is None:
+                return net(xp, torch.tensor(t_probe), r(emb[which]), kw).sample
+            nw.set_lora_slider(scale)
+            with nw:
+                return net(xp, torch.tensor(t_probe), r(emb[which]), kw).sample
+
+    def engine_eps(which, scale):
+        kw = {"text_embeds": pool[which].to(dev), "time_ids": tid.to(dev)} if cfg.is_xl else None
+        if scale is None:
+            eng.set_lora(False)
+            out = eng(xp.to(dev), torch.tensor(t_probe), emb[which].to(dev), kw, mode="off").sample
+        else:
+            eng.set_lora(True, scale)
+            out = eng(xp.to(dev), torch.tensor(t_probe), emb[which].to(dev), kw, mode="on").sample
+        torch.cuda.synchronize()
+        return out.float().cpu()
+
+    sign = 1.0 if action == "enhance" else -1.0
+    res = {}
+    for tag, f in (("engine", engine_eps), ("oracle", oracle_eps)):
+        effect = (f("target", 1.0) - f("target", -1.0)).flatten()
+        direction = sign * (f("positive", None) - f("uncond", None)).flatten()
+        res[tag] = (effect, direction, torch.dot(effect, direction).item() / direction.norm().item())
+    (ee, de, pe), (eo, do, po) = res["engine"], res["oracle"]
+    cos_eff = F.cosine_similarity(ee, eo, dim=0).item()
+    cos_dir_e, cos_dir_o = F.cosine_similarity(ee, de, dim=0).item(), F.cosine_similarity(eo, do, dim=0).item()
+    print(f"[parity] slider effect ({action}, {steps} steps): |effect| engine {ee.norm():.4e} oracle {eo.norm():.4e}, cosine(engine effect, oracle "
+          f"effect) {cos_eff:.4f}; projection on the guidance direction engine {pe:.4e} oracle {po:.4e}; cosine(effect, direction) engine "
+          f"{cos_dir_e:.4f} oracle {cos_dir_o:.4f}")
+    assert ee.norm() > 1e-3 and eo.norm() > 1e-3, "the sliders learned something"
+    assert pe > 0 and po > 0, "both trained sliders move epsilon the way the guidance loss asks"
+    assert cos_eff > 0.9, "the engine-trained slider does what the reference-trained slider does"
+    assert 0.75 < ee.norm().item() / eo.norm().item() < 1.33 and 0.7 < pe / po < 1.4
