@@ -85,3 +85,20 @@ def test_row_kernels_issue_their_loads_together():
         sites, loads = chk.serial_load_sites(body)
         assert loads >= 9 and sites == 0, (name, sites, loads)
     assert seen == 2
+
+
+@pytest.mark.skipif(shutil.which("hipcc") is None, reason="hipcc not on PATH")
+@pytest.mark.parametrize("src", sorted(f for f in os.listdir(CSRC) if f.endswith(".hip")))
+def test_no_kernel_waits_on_another_workgroup(src):
+    """The rule since round 5 (round 4's stream-K tile polled flags of other workgroups and could hang two concurrent launches): no
+    kernel of the library waits for another workgroup.  Every cross-workgroup reduction is the last-arriver form - one relaxed
+    fetch-add on a ticket, whoever draws the last ticket does the combining, nobody polls.  Two cheap guards against the pattern
+    coming back: the compiled code of every kernel is free of `s_sleep` (what a polite polling loop is made of), and no source
+    loop has an atomic load in its condition."""
+    import re
+    for name, body in chk.kernels(_asm(src)):
+        assert "s_sleep" not in body, f"{name}: s_sleep (a polling wait?)"
+    text = open(os.path.join(CSRC, src)).read() + "".join(open(os.path.join(CSRC, h)).read() for h in ("common.h", "gemm_common.h"))
+    text = re.sub(r"//[^\n]*", "", text)
+    assert not re.search(r"\bwhile\s*\([^;{]*__hip_atomic_load", text), f"{src}: a loop polls an atomic"
+    assert "__builtin_amdgcn_s_sleep" not in text
