@@ -93,3 +93,77 @@ class ProdigyF64:
         d = min(self.d_max, d * self.growth)
         self.x = self.x * (1 - self.wd * dlr) - dlr * self.m / (np.sqrt(self.v) + d * self.eps)
         self.d, self.k = d, self.k + 1
+
+
+class DAdaptAdamF64:
+    """float64 numpy evaluation of D-Adapt Adam as released in dadaptation 3.1 (train_util.py:339-344; package absent ->
+    PARITY UNPINNED), written from Defazio & Mishchenko 2023 (Alg. 5, "Adam with D-Adaptation") in the release-3
+    parameterisation, independently of sliders_amd/optim.py (no torch, one flat vector).  With b = sqrt(beta2) and
+    lambda_k = d_k * lr * [bias correction]:
+
+        r_{k+1}  = b r_k + (1 - b) lambda_k <g_k, s_k / (sqrt(v_k) + eps)>          (s_k, v_k: before this step)
+        m_{k+1}  = beta1 m_k + (1 - beta1) lambda_k g_k ;   v_{k+1} = beta2 v_k + (1 - beta2) g_k^2
+        s_{k+1}  = b s_k + (1 - b) lambda_k g_k
+        d_{k+1}  = max(d_k, min(r_{k+1} / ((1 - b) ||s_{k+1}||_1), growth d_k))
+        x_{k+1}  = x_k [1 - wd lambda_k  if decoupled] - m_{k+1} / (sqrt(v_{k+1}) + eps)
+    (coupled decay adds wd x_k to g_k first.)"""
+
+    def __init__(self, x0, lr=1.0, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0, decouple=False, use_bias_correction=False,
+                 d0=1e-6, growth_rate=float("inf")):
+        import numpy as np
+        self.np = np
+        self.x = np.array(x0, dtype=np.float64)
+        self.m, self.v, self.s = np.zeros_like(self.x), np.zeros_like(self.x), np.zeros_like(self.x)
+        self.lr, self.b1, self.b2, self.eps, self.wd = lr, betas[0], betas[1], eps, weight_decay
+        self.decouple, self.ubc, self.d, self.growth, self.r, self.k = decouple, use_bias_correction, d0, growth_rate, 0.0, 0
+
+    def step(self, g):
+        np = self.np
+        g = np.asarray(g, dtype=np.float64)
+        if self.wd and not self.decouple:
+            g = g + self.wd * self.x
+        b = self.b2 ** 0.5
+        lam = self.d * self.lr * ((1 - self.b2 ** (self.k + 1)) ** 0.5 / (1 - self.b1 ** (self.k + 1)) if self.ubc else 1.0)
+        self.r = b * self.r + (1 - b) * lam * float(g @ (self.s / (np.sqrt(self.v) + self.eps)))
+        self.m = self.b1 * self.m + (1 - self.b1) * lam * g
+        self.v = self.b2 * self.v + (1 - self.b2) * g * g
+        self.s = b * self.s + (1 - b) * lam * g
+        l1 = float(np.abs(self.s).sum())
+        if l1 == 0:
+            return
+        self.d = max(self.d, min(self.r / ((1 - b) * l1), self.d * self.growth))
+        if self.wd and self.decouple:
+            self.x = self.x * (1 - self.wd * lam)
+        self.x = self.x - self.m / (np.sqrt(self.v) + self.eps)
+        self.k += 1
+
+
+class DAdaptLionF64:
+    """float64 numpy evaluation of D-Adapt Lion as released in dadaptation 3.1 (train_util.py:345-346; PARITY UNPINNED): Lion's
+    sign update u_k = sign(beta1 m_k + (1 - beta1) g_k) with step lambda_k = d_k lr, the moment carrying lambda_k, and the
+    estimate of D-Adaptation driven by u_k instead of g_k (b = sqrt(beta2)):
+
+        x_{k+1} = x_k (1 - lambda_k wd) - lambda_k u_k ;  m_{k+1} = beta2 m_k + (1 - beta2) lambda_k g_k
+        r_{k+1} = b r_k + (1 - b) lambda_k <u_k, s_k> ;   s_{k+1} = b s_k + (1 - b) lambda_k u_k
+        d_{k+1} = max(d_k, r_{k+1} / ((1 - b) ||s_{k+1}||_1))"""
+
+    def __init__(self, x0, lr=1.0, betas=(0.9, 0.999), weight_decay=0.0, d0=1e-6):
+        import numpy as np
+        self.np = np
+        self.x = np.array(x0, dtype=np.float64)
+        self.m, self.s = np.zeros_like(self.x), np.zeros_like(self.x)
+        self.lr, self.b1, self.b2, self.wd, self.d, self.r = lr, betas[0], betas[1], weight_decay, d0, 0.0
+
+    def step(self, g):
+        np = self.np
+        g = np.asarray(g, dtype=np.float64)
+        b, lam = self.b2 ** 0.5, self.d * self.lr
+        u = np.sign(self.b1 * self.m + (1 - self.b1) * g)
+        self.x = self.x * (1 - lam * self.wd) - lam * u
+        self.m = self.b2 * self.m + (1 - self.b2) * lam * g
+        self.r = b * self.r + (1 - b) * lam * float(u @ self.s)
+        self.s = b * self.s + (1 - b) * lam * u
+        l1 = float(np.abs(self.s).sum())
+        if l1 == 0:
+            return
+        self.d = max(self.d, self.r / ((1 - b) * l1))

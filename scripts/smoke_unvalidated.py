@@ -39,7 +39,7 @@ for sched, opt, lr in (("ddpm", "adamw", 2e-4), ("euler_a", "adamw", 2e-4), ("lm
         losses.append(float(tr.iteration(pair, 2 + it, noise.to(dev)).item()))
     torch.cuda.synchronize()
     moved = float((store.params.float() - p0.float()).abs().max())
-    extra = f" d={tr._prodigy.param_groups[0]['d']:.3e}" if opt == "prodigy" else ""
+    extra = f" d={tr._tensor_opt.param_groups[0]['d']:.3e}" if opt == "prodigy" else ""
     print(f"{sched:8s} {opt:8s}: losses {['%.4e' % l for l in losses]} finite={all(l == l and abs(l) < 1e9 for l in losses)} "
           f"max |dparam| {moved:.3e}{extra}", flush=True)
 store = LoraStore(cfg, rank=4, alpha=1.0, train_method="noxattn", device=dev)

@@ -111,10 +111,10 @@ def optimizer_options(train_cfg) -> dict:
     optimizer kernels (slh_adamw for adam / adamw, slh_lion for lion).  Anything those kernels do not implement is an error,
     never silently ignored."""
     name = (train_cfg.optimizer or "adamw").lower()
-    if name not in ("adamw", "adam", "lion", "prodigy"):
+    if name not in ("adamw", "adam", "lion", "prodigy", "dadaptadam", "dadaptlion"):
         raise NotImplementedError(f"train.optimizer '{train_cfg.optimizer}': implemented are adam / adamw / lion (fused kernels) and "
-                                  f"prodigy (sliders_amd.optim.Prodigy); dadapt* and *8bit belong to packages that are not in this "
-                                  f"image (dadaptation, bitsandbytes - the latter CUDA-only)")
+                                  f"prodigy / dadaptadam / dadaptlion (sliders_amd.optim); *8bit belongs to bitsandbytes (CUDA-only, "
+                                  f"not in this image)")
     kw = {}
     if train_cfg.optimizer_args:
         for arg in train_cfg.optimizer_args.split(" "):
@@ -125,6 +125,11 @@ def optimizer_options(train_cfg) -> dict:
     if name == "prodigy":   # prodigyopt.Prodigy's own arguments and defaults (requirements.txt: prodigyopt==1.0)
         out = {"betas": (0.9, 0.999), "beta3": None, "eps": 1e-8, "weight_decay": 0.0, "decouple": True,
                "use_bias_correction": False, "safeguard_warmup": False, "d0": 1e-6, "d_coef": 1.0, "growth_rate": float("inf")}
+    elif name == "dadaptadam":   # dadaptation.DAdaptAdam's own arguments and defaults (requirements.txt: dadaptation==3.1)
+        out = {"betas": (0.9, 0.999), "eps": 1e-8, "weight_decay": 0.0, "decouple": False, "use_bias_correction": False,
+               "d0": 1e-6, "growth_rate": float("inf"), "log_every": 0}
+    elif name == "dadaptlion":   # dadaptation.DAdaptLion
+        out = {"betas": (0.9, 0.999), "weight_decay": 0.0, "d0": 1e-6, "log_every": 0}
     elif name == "lion":    # lion_pytorch.Lion defaults (requirements.txt:5)
         out = {"betas": (0.9, 0.99), "weight_decay": 0.0}
     else:

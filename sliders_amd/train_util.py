@@ -138,8 +138,15 @@ def get_optimizer(name: str):
     if name == "prodigy":
         from .optim import Prodigy     # prodigyopt.Prodigy's interface, tensor ops on the parameter's device
         return Prodigy
-    if name.startswith("dadapt") or name.endswith("8bit"):
-        raise ValueError(f"optimizer {name} needs a package that is not installed in this image (dadaptation / bitsandbytes)")
+    if name.startswith("dadapt"):      # dadaptation 3.1's two classes (train_util.py:339-346), same interface, tensor ops
+        from .optim import DAdaptAdam, DAdaptLion
+        if name == "dadaptadam":
+            return DAdaptAdam
+        if name == "dadaptlion":
+            return DAdaptLion
+        raise ValueError("DAdapt optimizer must be dadaptadam or dadaptlion")
+    if name.endswith("8bit"):
+        raise ValueError(f"optimizer {name} needs a package that is not installed in this image (bitsandbytes)")
     if name == "adam":
         return torch.optim.Adam
     if name == "adamw":

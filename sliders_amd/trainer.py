@@ -33,6 +33,9 @@ from .lora_store import LoraStore
 from .parallel import allreduce_sum_, world_info
 from .unet import UNetEngine
 
+# train.optimizer values that step the flat parameter buffer with tensor ops (sliders_amd/optim.py) instead of one fused kernel
+TENSOR_OP_OPTIMIZERS = ("prodigy", "dadaptadam", "dadaptlion")
+
 
 @dataclass
 class PairEmbeds:
@@ -77,15 +80,16 @@ class SliderTrainer:
                  noise_scheduler: str = "ddim", scheduler_seed: int = 0, optimizer_kwargs: Optional[dict] = None):
         self.eng, self.store = engine, store
         self.lr, self.betas, self.eps, self.wd = lr, betas, eps, weight_decay
-        if optimizer not in ("adamw", "adam", "lion", "prodigy"):
+        if optimizer not in ("adamw", "adam", "lion") + TENSOR_OP_OPTIMIZERS:
             raise NotImplementedError(f"optimizer '{optimizer}': fused flat kernels exist for adam / adamw (slh_adamw) and lion "
-                                      f"(slh_lion); prodigy runs as sliders_amd.optim.Prodigy on the flat parameter buffer")
+                                      f"(slh_lion); prodigy / dadaptadam / dadaptlion run as sliders_amd.optim classes on the flat "
+                                      f"parameter buffer")
         if getattr(store, "master", None) is not None and optimizer not in ("adamw", "adam"):
             raise NotImplementedError(f"optimizer '{optimizer}' with fp32 adapter state (train.precision: float32): only the fused "
-                                      f"adam / adamw kernel keeps an fp32 master; use bfloat16 for lion / prodigy")
+                                      f"adam / adamw kernel keeps an fp32 master; use bfloat16 for lion / prodigy / dadapt*")
         self.optimizer = optimizer
         self.optimizer_kwargs = dict(optimizer_kwargs or {})
-        self._prodigy = None
+        self._tensor_opt = None
         self.nsteps = max_denoising_steps
         self.denoise_guidance = denoise_guidance
         # train.noise_scheduler (model_util.py:230-277); v_prediction: pretrained_model.v_pred (model_util.py:126)
@@ -325,17 +329,19 @@ class SliderTrainer:
     def optimizer_step(self):
         st = self.store
         st.opt_step += 1
-        if self.optimizer == "prodigy":     # prodigyopt 1.0 over the flat bf16 parameter buffer (train_util.py:369-372)
-            if self._prodigy is None:
-                from .optim import Prodigy
+        if self.optimizer in TENSOR_OP_OPTIMIZERS:
+            # prodigyopt 1.0 / dadaptation 3.1 over the flat bf16 parameter buffer (train_util.py:339-346, 369-372)
+            if self._tensor_opt is None:
+                from . import optim
+                cls = {"prodigy": optim.Prodigy, "dadaptadam": optim.DAdaptAdam, "dadaptlion": optim.DAdaptLion}[self.optimizer]
                 kw = {k: v for k, v in self.optimizer_kwargs.items()}
-                if self.eps:
+                if self.eps and self.optimizer != "dadaptlion":
                     kw.setdefault("eps", self.eps)
-                self._prodigy = Prodigy([st.params], lr=self.lr, betas=self.betas, weight_decay=self.wd, **kw)
-            self._prodigy.param_groups[0]["lr"] = self.lr
+                self._tensor_opt = cls([st.params], lr=self.lr, betas=self.betas, weight_decay=self.wd, **kw)
+            self._tensor_opt.param_groups[0]["lr"] = self.lr
             # the reference's gradients have the parameter dtype (bf16); grad_scale carries the 1/world of the all-reduce
             st.params.grad = (st.grads * self.grad_scale).to(st.params.dtype)
-            self._prodigy.step()
+            self._tensor_opt.step()
             st.params.grad = None
             return
         if self.optimizer == "lion":        # one moment (store.exp_avg); lion_pytorch 0.1.2 op order

@@ -417,7 +417,7 @@ def test_optimizer_options_and_rejections():
     assert optimizer_options(_cfg(optimizer="Lion").train) == {"betas": (0.9, 0.99), "weight_decay": 0.0, "eps": 0.0, "name": "lion"}
     assert optimizer_options(_cfg(optimizer="lion", optimizer_args="weight_decay=0.02 betas=(0.95,0.98)").train)["betas"] == (0.95, 0.98)
     for bad in (dict(optimizer="lion", optimizer_args="eps=1e-6"), dict(optimizer="lion", optimizer_args="use_triton=True"),
-                dict(optimizer="prodigy", optimizer_args="amsgrad=True"), dict(optimizer="adam8bit"), dict(optimizer="dadaptlion"),
+                dict(optimizer="prodigy", optimizer_args="amsgrad=True"), dict(optimizer="adam8bit"), dict(optimizer="dadaptsgd"), dict(optimizer="dadaptlion", optimizer_args="eps=1e-6"),
                 dict(optimizer="adam", optimizer_args="weight_decay=0.01"), dict(optimizer_args="amsgrad=True"),
                 dict(precision="fp16"), dict(precision="float32", optimizer="lion"), dict(lr_scheduler="linear")):
         with pytest.raises(NotImplementedError):
@@ -431,6 +431,12 @@ def test_optimizer_options_and_rejections():
     o = optimizer_options(_cfg(optimizer="Prodigy", optimizer_args="weight_decay=0.01 d_coef=2.0 safeguard_warmup=True").train)
     assert o["name"] == "prodigy" and o["weight_decay"] == 0.01 and o["d_coef"] == 2.0 and o["safeguard_warmup"] is True
     assert o["d0"] == 1e-6 and o["betas"] == (0.9, 0.999) and o["decouple"] is True and o["growth_rate"] == float("inf")
+    # dadaptation 3.1's two classes with their own arguments and defaults (train_util.py:339-346)
+    o = optimizer_options(_cfg(optimizer="DAdaptAdam", optimizer_args="decouple=True weight_decay=0.01 growth_rate=1.02").train)
+    assert o["name"] == "dadaptadam" and o["decouple"] is True and o["weight_decay"] == 0.01 and o["growth_rate"] == 1.02
+    assert o["d0"] == 1e-6 and o["eps"] == 1e-8 and o["use_bias_correction"] is False
+    o = optimizer_options(_cfg(optimizer="dadaptlion").train)
+    assert o["name"] == "dadaptlion" and o["betas"] == (0.9, 0.999) and o["weight_decay"] == 0.0
     for name in ("ddim", "ddpm", "lms", "euler_a"):      # model_util.py:230-277: all four for text sliders
         check_supported(_cfg(noise_scheduler=name))
     check_supported(_cfg(), image_slider=True)

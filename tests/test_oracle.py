@@ -308,9 +308,98 @@ def test_prodigy_argument_checks_and_get_optimizer():
     for bad in (dict(d0=0.0), dict(lr=0.0), dict(eps=0.0), dict(betas=(1.0, 0.9))):
         with pytest.raises(ValueError):
             Prodigy([torch.zeros(2)], **bad)
-    for name in ("dadaptadam", "adam8bit"):
+    for name in ("dadaptsgd", "adam8bit"):
         with pytest.raises(ValueError):
             get_optimizer(name)
+
+
+# ---- D-Adaptation (train.optimizer: dadaptadam / dadaptlion, train_util.py:339-346; dadaptation==3.1 absent -> parity unpinned) ----
+@pytest.mark.parametrize("kw", [dict(), dict(weight_decay=0.01), dict(weight_decay=0.01, decouple=True),
+                                dict(use_bias_correction=True), dict(growth_rate=1.2, betas=(0.8, 0.99), eps=1e-6)])
+def test_dadapt_adam_matches_float64_oracle_and_estimates_the_distance(kw):
+    """product (torch ops, float64 parameter) against the independent numpy restatement over 300 steps of a quadratic, plus
+    what the method promises: d never decreases, grows by orders of magnitude from d0 without exceeding the distance to the
+    solution by more than a small factor, and the iterates converge with lr = 1"""
+    import numpy as np
+    from oracle.optim_oracle import DAdaptAdamF64
+    from sliders_amd.optim import DAdaptAdam
+    a, t, x0 = _quadratic()
+    p = torch.tensor(x0, dtype=torch.float64)
+    opt, orc = DAdaptAdam([p], lr=1.0, **kw), DAdaptAdamF64(x0, lr=1.0, **kw)
+    ds = []
+    for _ in range(300):
+        p.grad = torch.tensor(a) * (p - torch.tensor(t))
+        opt.step()
+        orc.step(a * (orc.x - t))
+        ds.append(opt.param_groups[0]["d"])
+    np.testing.assert_allclose(p.numpy(), orc.x, rtol=1e-6, atol=1e-6)
+    assert abs(ds[-1] - orc.d) < 1e-8 * orc.d and opt.param_groups[0]["k"] == 300 == opt.state[p]["step"]
+    D = float(np.linalg.norm(x0 - t, ord=np.inf))       # Adam's geometry: the estimate tracks the l-infinity distance
+    assert all(b >= a_ for a_, b in zip(ds, ds[1:])) and 1e-2 * D < ds[-1] < 10 * D
+    if "growth_rate" in kw:
+        assert all(b <= a_ * kw["growth_rate"] * (1 + 1e-12) for a_, b in zip(ds, ds[1:]))
+    if not kw.get("weight_decay"):
+        assert float((p - torch.tensor(t)).norm()) < 0.2 * float(np.linalg.norm(x0 - t))
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(weight_decay=0.01), dict(betas=(0.95, 0.98))])
+def test_dadapt_lion_matches_float64_oracle(kw):
+    import numpy as np
+    from oracle.optim_oracle import DAdaptLionF64
+    from sliders_amd.optim import DAdaptLion
+    a, t, x0 = _quadratic()
+    p = torch.tensor(x0, dtype=torch.float64)
+    opt, orc = DAdaptLion([p], lr=1.0, **kw), DAdaptLionF64(x0, lr=1.0, **kw)
+    ds = []
+    for _ in range(300):
+        p.grad = torch.tensor(a) * (p - torch.tensor(t))
+        opt.step()
+        orc.step(a * (orc.x - t))
+        ds.append(opt.param_groups[0]["d"])
+    np.testing.assert_allclose(p.numpy(), orc.x, rtol=1e-7, atol=1e-7)
+    assert abs(ds[-1] - orc.d) < 1e-8 * orc.d
+    assert all(b >= a_ for a_, b in zip(ds, ds[1:])) and ds[-1] > 1e3 * 1e-6
+    # the loss went down without any learning rate being tuned
+    f0, f1 = float((a * (x0 - t) ** 2).sum()), float((a * (p.numpy() - t) ** 2).sum())
+    assert f1 < 0.5 * f0
+
+
+def test_dadapt_bf16_flat_buffer_and_interface():
+    """bf16 parameter / states as the trainer uses them (fp32-accumulated reductions), two parameter groups sharing one d, the
+    package's argument checks, and get_optimizer's names (train_util.py:339-349)"""
+    import numpy as np
+    from oracle.optim_oracle import DAdaptAdamF64
+    from sliders_amd.optim import DAdaptAdam, DAdaptLion
+    from sliders_amd.train_util import get_optimizer
+    assert get_optimizer("DAdaptAdam") is DAdaptAdam and get_optimizer("dadaptlion") is DAdaptLion
+    a, t, x0 = _quadratic(256, 3)
+    x0[::2] = 0.0
+    p = torch.tensor(x0, dtype=torch.bfloat16)
+    orc = DAdaptAdamF64(p.double().numpy().copy(), lr=1.0)
+    opt = DAdaptAdam([p], lr=1.0)
+    for _ in range(60):
+        p.grad = torch.tensor(a * (p.double().numpy() - t)).to(torch.bfloat16)
+        opt.step()
+        orc.step(a * (orc.x - t))
+    assert all(opt.state[p][k].dtype == torch.bfloat16 for k in ("s", "exp_avg", "exp_avg_sq"))
+    assert 0.2 < opt.param_groups[0]["d"] / orc.d < 5.0 and torch.isfinite(p.float()).all()
+    q1, q2 = torch.randn(8, dtype=torch.float64), torch.randn(8, dtype=torch.float64)
+    for cls in (DAdaptAdam, DAdaptLion):
+        o = cls([{"params": [q1]}, {"params": [q2], "lr": 0.0}], lr=1.0)
+        q2_before = q2.clone()
+        q1.grad, q2.grad = torch.randn(8, dtype=torch.float64), torch.randn(8, dtype=torch.float64)
+        o.step(); o.step()
+        assert torch.equal(q2, q2_before) and o.param_groups[0]["d"] == o.param_groups[1]["d"]
+        o.param_groups[1]["lr"] = 0.5
+        with pytest.raises(RuntimeError):
+            o.step()
+        for bad in (dict(d0=0.0), dict(lr=0.0), dict(betas=(1.0, 0.9)), dict(betas=(0.9, 1.0))):
+            with pytest.raises(ValueError):
+                cls([torch.zeros(2)], **bad)
+        with pytest.raises(NotImplementedError):
+            cls([torch.zeros(2)], fsdp_in_use=True)
+    with pytest.raises(ValueError):
+        DAdaptAdam([torch.zeros(2)], eps=0.0)
 
 
 @pytest.mark.parametrize("name", ["tiny_sdxl", "tiny_sd1"])

@@ -146,7 +146,7 @@ def test_prodigy_on_the_device_buffer(dev):
             mv = first != x0.double().numpy()
             assert mv.any() and (np.sign(first[mv] - x0.double().numpy()[mv]) == np.sign(orc.x[mv] - x0.double().numpy()[mv])).all()
     torch.cuda.synchronize()
-    d_dev, d_host = tr._prodigy.param_groups[0]["d"], hopt.param_groups[0]["d"]
+    d_dev, d_host = tr._tensor_opt.param_groups[0]["d"], hopt.param_groups[0]["d"]
     x = store.params.detach().float().cpu()
     diff = (x - host.float()).abs()
     upd = float((x - host.float()).norm() / (host.float() - x0.float()).norm())
