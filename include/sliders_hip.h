@@ -229,9 +229,12 @@ int slh_gn_apply(const slh_gn_desc* d, slh_stream_t stream);
 /* workgroups per sample of slh_gn_stats / slh_gn_bwd_stats, and the clusters they form; -1 for an unsupported shape */
 int slh_gn_row_blocks(int channels, int hw, int groups);
 int slh_gn_clusters(int row_blocks);
-/* Tiny tensors (8x8 latents: a sample's group slab is a few KB): statistics AND normalisation in one launch, one read
- * of x; also writes stats for the backward.  partial / ticket unused.  (Measured: loses at 32x32, ties at 16x16.)
- * slh_gn_fused_ok(channels, hw, groups) = 1 where it applies. */
+/* Statistics AND normalisation in one launch; also writes stats for the backward.  partial / ticket unused; y must not alias x.
+ * slh_gn_fused_ok(channels, hw, groups) = 0 where it does not apply (use the two launches above),
+ *   1: tiny tensors (8x8 latents: a sample's group slab is a few KB) - one workgroup per group set keeps the slab in registers;
+ *   2: cache-resident slabs (hw <= 4096, hw * channels / groups <= 81920: the 32x32 level and the 640-channel tensors of the 64x64 level of SDXL at 1024^2) -
+ *      S = 1..8 sibling workgroups per (sample, group), each of which reduces the WHOLE slab in the same fixed order (identical
+ *      statistics, nothing exchanged, nothing waited for) and normalises its own 1/S of it. */
 int slh_gn_fused_ok(int channels, int hw, int groups);
 int slh_gn_fused(const slh_gn_desc* d, slh_stream_t stream);
 

@@ -613,7 +613,7 @@ int launch_fwd(const slh_attn_desc* d, hipStream_t s) {
     static const int knob_ks = getenv("SLH_ATTN_KS") ? atoi(getenv("SLH_ATTN_KS")) : 1;        // A/B: 0 = never
     const long blocks2 = (long)(d->Tq / 64) * d->H * d->B;
     if (DT == 1 && !tail && knob_ks && (d->D == 0 || d->D == 64) && d->Tq % 64 == 0 && d->Tk % 128 == 0 && d->Tk >= 256 &&
-        blocks4 < 512 && blocks2 > 128 && blocks2 <= 768) {
+        ((blocks4 < 512 && blocks2 > 128 && blocks2 <= 768) || knob_ks == 2)) {      // 2 = whenever the shape allows (A/B)
         hipLaunchKernelGGL(attn_fwd_ks_kernel, dim3((unsigned)blocks2), dim3(256), 0, s, *d);
         SLH_LAUNCH_CHECK("slh_attn_fwd (key split)");
         return 0;

@@ -302,6 +302,128 @@ __global__ __launch_bounds__(256) void gn_fused_kernel(const slh_gn_desc d, int 
     }
 }
 
+// ---- one launch for slabs that stay cache-resident (round 5) ---------------------------------------------------------
+// The two-launch form costs a kernel boundary, a ticket tail and a partial-sum prologue per GroupNorm - 12 + 12 us in situ on
+// tensors whose traffic is worth 2 us (profiles/r05_probe_gn.txt).  Here S sibling workgroups serve one (sample, group): EVERY
+// sibling reduces the whole slab (hw rows x cg channels: 80-320 KB, the siblings' reads meet in L2) in the same fixed order -
+// identical statistics in all of them, no partials, no tickets, nothing to wait for - and then normalises its own 1/S of the slab's
+// chunks, which it reads a second time (L2 hits).  Redundant arithmetic instead of a second launch: the statistics cost 2.75 VALU
+// slots per element (packed fp32), the SiLU epilogue ~15, so S = 4 adds < 20 % arithmetic; it only pays while the slab is small:
+// every sibling walks the whole slab, latency-bound, so the time grows with the slab while the two-launch form spreads it over the
+// chip.  Measured (scripts/probe_gn.py, B = 2, us, one-launch vs stats + apply): 16x16 x 1280: 5.3 vs 14.0; 32x32 x 640 / 1280 /
+// 2560: 7.9 / 9.7 / 12.4 vs 14.8 / 16.3 / 20.3; 64x64 x 640: 17.6 vs 20.6; 64x64 x 1280 / 1920: 30.9 / 35.9 vs 27.9 / 31.7 (loses:
+// GN1_MAX_ELEMS).  V = elements per access: 8 / 4 / 2 by the alignment of cg and c0.
+constexpr int GN1_MAX_ELEMS = 4096 * 20;     // slab elements (hw * cg): 64x64 x 640 channels, 32x32 x 2560 (measured: scripts/probe_gn.py)
+constexpr int GN1_MAX_HW = 4096;
+constexpr int GN1_U = 8;                      // accesses in flight per thread and loop trip
+
+__device__ __forceinline__ float silu_rcp_f(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }   // 1 ulp rcp: no IEEE division sequence
+
+struct GnOneGeom { int V, nch, threads; bool ok; };
+__host__ __device__ inline GnOneGeom gn_one_geom(int c0, int c1, int hw, int groups) {
+    GnOneGeom g;
+    const int C = c0 + c1, cg = C / groups;
+    g.V = (cg % 8 == 0) ? 8 : (cg % 4 == 0 && c0 % 4 == 0) ? 4 : 2;
+    g.nch = cg / g.V;
+    const int total = hw * g.nch;
+    g.threads = total >= 4096 ? 1024 : total >= 1024 ? 512 : 256;
+    g.ok = cg % 2 == 0 && c0 % 2 == 0 && total >= 256;
+    return g;
+}
+// size limits of the one-launch form; SLH_GN1_MAX_HW / SLH_GN1_MAX_ELEMS override them for measurements (scripts/probe_gn.py)
+static bool gn_one_fits(int channels, int hw, int groups) {
+    static const int max_hw = getenv("SLH_GN1_MAX_HW") ? atoi(getenv("SLH_GN1_MAX_HW")) : GN1_MAX_HW;
+    static const long max_elems = getenv("SLH_GN1_MAX_ELEMS") ? atol(getenv("SLH_GN1_MAX_ELEMS")) : (long)GN1_MAX_ELEMS;
+    return hw <= max_hw && (long)hw * (channels / groups) <= max_elems;
+}
+static int gn_one_siblings(int batch, int groups, int total_chunks, int threads) {
+    int S = 1;
+    while (S < 8 && 2 * S * batch * groups <= 320 && total_chunks / (2 * S) >= threads / 4) S *= 2;
+    return S;
+}
+
+template <int V>
+__global__ __launch_bounds__(1024) void gn_one_kernel(const slh_gn_desc d, int cg, int nch, unsigned long long magic, int S, int per) {
+    typedef __attribute__((ext_vector_type(V))) __bf16 vec_t;
+    typedef __attribute__((ext_vector_type(V / 2))) unsigned int raw_t;
+    __shared__ float red[16][2];
+    __shared__ float fin[2];
+    const int tid = threadIdx.x, nt = blockDim.x, lane = tid & 63, wave = tid >> 6;
+    // Work item w = ((sample * groups + group) * S + sibling).  Workgroup n of a launch runs on XCD n % 8: handing XCD x the
+    // contiguous run w in [x * nblk / 8, (x + 1) * nblk / 8) puts the siblings of a group AND the neighbouring groups (whose
+    // 20-160-byte row segments share cache lines with it) behind ONE L2 - the tensor leaves HBM once, not S times (measured
+    // without it, 64x64 x 1280 channels: 42.9 us for 21 MB, i.e. the 4 siblings each pulled their slab's lines from memory).
+    const int nblk = gridDim.x, n = blockIdx.x;
+    const int w = (nblk & 7) == 0 ? (n & 7) * (nblk >> 3) + (n >> 3) : n;
+    const int gs = d.groups * S;
+    const int b = w / gs, g = (w - b * gs) / S, sib = w - b * gs - g * S;
+    const int c_base = g * cg;
+    const int total = d.hw * nch;
+    const long row0 = (long)b * d.hw;
+    const __bf16 kb = *gn_src(d, row0, c_base);          // the pivot of the shifted sums (see gn_stats_kernel)
+    const float k = (float)kb;
+    const unsigned kraw = (unsigned)__builtin_bit_cast(unsigned short, kb) * 0x10001u;
+    const f32x2 k2 = {k, k};
+    f32x2 s2 = {0.f, 0.f}, q2 = {0.f, 0.f};
+    for (int i0 = tid; i0 < total; i0 += GN1_U * nt) {
+        raw_t v[GN1_U];
+#pragma unroll
+        for (int u = 0; u < GN1_U; ++u) {                // unconditional loads at clamped indices: all in flight together
+            const int idx = min(i0 + u * nt, total - 1);
+            const int r = gnf_div(idx, magic), ch = idx - r * nch;
+            v[u] = *(const raw_t*)gn_src(d, row0 + r, c_base + ch * V);
+        }
+#pragma unroll
+        for (int u = 0; u < GN1_U; ++u) {
+            const bool in = i0 + u * nt < total;
+#pragma unroll
+            for (int e = 0; e < V / 2; ++e) {
+                const unsigned w = in ? v[u][e] : kraw;  // out of range: the pivot itself, (x - k) = 0 exactly
+                const f32x2 x2 = {__builtin_bit_cast(float, w << 16), __builtin_bit_cast(float, w & 0xffff0000u)};
+                const f32x2 f2 = x2 - k2;
+                s2 += f2;
+                q2 = __builtin_elementwise_fma(f2, f2, q2);
+            }
+        }
+    }
+    // fixed order: (even + odd lanes' slots) -> wave shuffle tree -> waves in index order, in double
+    const float s = wave_sum(s2[0] + s2[1]), q = wave_sum(q2[0] + q2[1]);
+    if (lane == 0) { red[wave][0] = s; red[wave][1] = q; }
+    __syncthreads();
+    if (tid == 0) {
+        double S_ = 0.0, Q_ = 0.0;
+        for (int w = 0; w < (nt >> 6); ++w) { S_ += (double)red[w][0]; Q_ += (double)red[w][1]; }
+        const double n = (double)d.hw * (double)cg;
+        const double m = S_ / n;
+        const double var = fmax(Q_ / n - m * m, 0.0);
+        const float mean = (float)((double)k + m);
+        const float rstd = (float)(1.0 / sqrt(var + (double)d.eps));
+        fin[0] = mean; fin[1] = rstd;
+        if (sib == 0) *(f32x2*)(d.stats + ((long)b * d.groups + g) * 2) = f32x2{mean, rstd};      // for the backward
+    }
+    __syncthreads();
+    const float mean = fin[0], rstd = fin[1];
+    const int lo = sib * per, hi = min(total, lo + per);
+    for (int idx = lo + tid; idx < hi; idx += nt) {
+        const int r = gnf_div(idx, magic), ch = idx - r * nch;
+        const int c = c_base + ch * V;
+        const vec_t xv = *(const vec_t*)gn_src(d, row0 + r, c);
+        const vec_t gm = *(const vec_t*)((const __bf16*)d.gamma + c);
+        const vec_t bt = *(const vec_t*)((const __bf16*)d.beta + c);
+        vec_t o;
+#pragma unroll
+        for (int e = 0; e < V; ++e) {
+            const float a = rstd * (float)gm[e];
+            float y = (float)xv[e] * a + ((float)bt[e] - mean * a);
+            if (d.act == 1) y = silu_rcp_f(round_bf16(y));      // reference rounds the GroupNorm output to bf16 before SiLU
+            o[e] = (__bf16)y;
+        }
+        __bf16* yp = (__bf16*)d.y + (row0 + r) * d.ldy + c;
+        if constexpr (V == 8 && (SLH_WT_MASK & 8)) wt_store16(wt_rsrc(d.y), ((row0 + r) * d.ldy + c) * 2, o);
+        else *(vec_t*)yp = o;
+    }
+}
+
 // ---- backward -------------------------------------------------------------------------------------
 __device__ __forceinline__ const __bf16* gnb_src(const slh_gn_bwd_desc& d, long row, int c) {
     return c < d.c0 ? (const __bf16*)d.x0 + row * d.ldx0 + c : (const __bf16*)d.x1 + row * d.ldx1 + (c - d.c0);
@@ -543,7 +665,8 @@ extern "C" int slh_gn_stats(const slh_gn_desc* d, slh_stream_t stream) {
 
 extern "C" int slh_gn_fused_ok(int channels, int hw, int groups) {
     if (channels <= 0 || channels % 8 || hw <= 0 || groups <= 0 || channels % groups) return 0;
-    return gn_fused_geom(channels, hw, groups).ok ? 1 : 0;
+    if (gn_fused_geom(channels, hw, groups).ok) return 1;                 // tiny tensors: the register-resident kernel
+    return gn_one_geom(channels, 0, hw, groups).ok && gn_one_fits(channels, hw, groups) ? 2 : 0;     // cache-resident slabs: sibling workgroups
 }
 
 extern "C" int slh_gn_fused(const slh_gn_desc* d, slh_stream_t stream) {
@@ -551,7 +674,22 @@ extern "C" int slh_gn_fused(const slh_gn_desc* d, slh_stream_t stream) {
     if (gn_check("slh_gn_fused", d->c0, d->c1, d->groups, d->ldx0, d->ldx1, d->x1)) return -1;
     SLH_CHECK(d->ldy % 8 == 0, "slh_gn_fused: ldy");
     const GnFusedGeom g = gn_fused_geom(d->c0 + d->c1, d->hw, d->groups);
-    SLH_CHECK(g.ok, "slh_gn_fused: shape C=%d hw=%d is not a small-tensor case (slh_gn_fused_ok)", d->c0 + d->c1, d->hw);
+    if (!g.ok) {
+        const GnOneGeom o = gn_one_geom(d->c0, d->c1, d->hw, d->groups);
+        SLH_CHECK(o.ok && gn_one_fits(d->c0 + d->c1, d->hw, d->groups), "slh_gn_fused: shape C=%d hw=%d is not a one-launch case (slh_gn_fused_ok)",
+                  d->c0 + d->c1, d->hw);
+        SLH_CHECK(d->y != d->x0 && (!d->x1 || d->y != d->x1), "slh_gn_fused: y must not alias x0 / x1 (sibling workgroups re-read the slab)");
+        const int cg = (d->c0 + d->c1) / d->groups, total = d->hw * o.nch;
+        const int S = gn_one_siblings(d->batch, d->groups, total, o.threads);
+        const int per = (total + S - 1) / S;
+        const unsigned long long magic = (0x100000000ull + o.nch - 1) / o.nch;
+        const dim3 grid(d->groups * S * d->batch), block(o.threads);
+        if (o.V == 8) hipLaunchKernelGGL(gn_one_kernel<8>, grid, block, 0, (hipStream_t)stream, *d, cg, o.nch, magic, S, per);
+        else if (o.V == 4) hipLaunchKernelGGL(gn_one_kernel<4>, grid, block, 0, (hipStream_t)stream, *d, cg, o.nch, magic, S, per);
+        else hipLaunchKernelGGL(gn_one_kernel<2>, grid, block, 0, (hipStream_t)stream, *d, cg, o.nch, magic, S, per);
+        SLH_LAUNCH_CHECK("slh_gn_fused");
+        return 0;
+    }
     hipLaunchKernelGGL(gn_fused_kernel, dim3(d->groups / g.gq, d->batch), dim3(256), 0, (hipStream_t)stream, *d,
                        (d->c0 + d->c1) / d->groups, g.gq, g.nch, (0x100000000ull + g.nch - 1) / g.nch);       // 2^32 itself for nch = 1: 64-bit
     SLH_LAUNCH_CHECK("slh_gn_fused");

@@ -211,9 +211,10 @@ def gn_workspace(channels: int, hw: int, groups: int):
     return r + c, 1 + c
 
 
-def gn_fused_ok(channels: int, hw: int, groups: int) -> bool:
-    """slh_gn_fused (statistics + normalisation in one launch) applies to this shape"""
-    return bool(load().slh_gn_fused_ok(channels, hw, groups))
+def gn_fused_ok(channels: int, hw: int, groups: int) -> int:
+    """slh_gn_fused (statistics + normalisation in one launch) applies to this shape: 0 no, 1 the register-resident kernel for
+    tiny tensors, 2 sibling workgroups over a cache-resident slab"""
+    return int(load().slh_gn_fused_ok(channels, hw, groups))
 
 
 def gn32_workspace(hw: int):

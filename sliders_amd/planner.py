@@ -438,8 +438,11 @@ class UNetPlan:
         d = lib.GnDesc(x0=x0.ptr, x1=x1.ptr if x1 else 0, gamma=self.w.ptr(wname + ".g"), beta=self.w.ptr(wname + ".b"),
                        stats=stats.ptr, y=y.ptr, ldx0=x0.ld, ldx1=x1.ld if x1 else 0, c0=x0.C, c1=x1.C if x1 else 0,
                        batch=B, hw=H * W, groups=G, ldy=y.ld, eps=eps, act=act, partial=part.ptr, ticket=ticket.ptr)
-        if lib.gn_fused_ok(C, H * W, G) and os.environ.get("SLIDERS_GN_TWO_LAUNCH") is None:
-            self.prog.add(lib.OP_GN_FUSED, d, name + ".fused")       # small tensor: one workgroup per group set, one launch
+        one = lib.gn_fused_ok(C, H * W, G)      # 1: tiny tensor, one workgroup per group set; 2: cache-resident slab, sibling workgroups
+        if one == 2 and os.environ.get("SLIDERS_GN_ONE", "1") == "0":
+            one = 0
+        if one and os.environ.get("SLIDERS_GN_TWO_LAUNCH") is None:
+            self.prog.add(lib.OP_GN_FUSED, d, name + ".fused")
         else:
             self.prog.add(lib.OP_GN_STATS, d, name + ".stats")
             self.prog.add(lib.OP_GN_APPLY, d, name + ".apply")

@@ -656,6 +656,32 @@ def test_gemv(dev):
     report("gemv", y, ref, TOL)
 
 
+@pytest.mark.parametrize("B,C,HW", [(1, 1280, 1024), (3, 1280, 1024), (5, 640, 1024), (1, 320, 4096), (3, 1920, 256), (16, 1280, 1024)])
+def test_groupnorm_one_launch_sibling_counts(dev, B, C, HW):
+    """slh_gn_fused on cache-resident slabs: 8 / 4 / 2 / 1 sibling workgroups per (sample, group) by the batch size - every
+    sibling reduces the whole slab in the same order, so the output must not depend on the split: compared with the two-launch
+    form (same tolerance as the one-launch test above) and with float64."""
+    torch.manual_seed(11)
+    assert lib.gn_fused_ok(C, HW, 32) == 2
+    x = bf(torch.randn(B * HW, C, device=dev) * 1.5 + 3.0)
+    g, bta = bf(torch.randn(C, device=dev)), bf(torch.randn(C, device=dev))
+    st1, st2 = torch.full((B, 32, 2), float("nan"), device=dev), torch.full((B, 32, 2), float("nan"), device=dev)
+    y1, y2 = torch.zeros_like(x), torch.zeros_like(x)
+    part, ticket = _gn_workspace(dev, B, C, HW)
+    d1 = lib.GnDesc(x0=p(x), gamma=p(g), beta=p(bta), stats=p(st1), y=p(y1), ldx0=C, c0=C, batch=B, hw=HW, groups=32, ldy=C, eps=1e-6, act=1)
+    d2 = lib.GnDesc(x0=p(x), gamma=p(g), beta=p(bta), stats=p(st2), y=p(y2), ldx0=C, c0=C, batch=B, hw=HW, groups=32, ldy=C, eps=1e-6, act=1,
+                    partial=p(part), ticket=p(ticket))
+    lib.call(lib.OP_GN_FUSED, d1, stream())
+    lib.call(lib.OP_GN_STATS, d2, stream())
+    lib.call(lib.OP_GN_APPLY, d2, stream())
+    torch.cuda.synchronize()
+    ximg = x.float().view(B, HW, C).permute(0, 2, 1)
+    ref = F.silu(bf(F.group_norm(ximg.double(), 32, g.double(), bta.double(), 1e-6).float()).float()).permute(0, 2, 1).reshape(B * HW, C)
+    report(f"groupnorm one-launch B{B} C{C} hw{HW}", y1, ref, TOL)
+    assert torch.allclose(st1, st2, rtol=1e-5, atol=1e-6)
+    assert float((y1.float() - y2.float()).abs().max()) <= 2.0 ** -7 * float(ref.abs().max())
+
+
 def _gn_workspace(dev, B, C, HW, G=32):
     """Partial-sum scratch (deliberately filled with garbage: the kernel must not depend on its contents) + zeroed tickets."""
     prow, ntick = lib.gn_workspace(C, HW, G)
@@ -668,7 +694,11 @@ def _gn_workspace(dev, B, C, HW, G=32):
                                                 # E[x^2] - E[x]^2 in fp32 loses the variance here (bf16 spacing at 50 is 0.25, at 256 is 2)
                                                 (320, 0, 1, 50.0, 1.0, 300), (640, 0, 0, 256.0, 4.0, 300), (1280, 640, 1, -50.0, 1.0, 300),
                                                 # 8x8 latents: the one-launch form (slh_gn_fused) is what the planner emits
-                                                (1280, 0, 1, 0.5, 2.0, 64), (2560, 0, 1, 30.0, 1.0, 64), (1280, 1280, 0, 0.5, 2.0, 64)])
+                                                (1280, 0, 1, 0.5, 2.0, 64), (2560, 0, 1, 30.0, 1.0, 64), (1280, 1280, 0, 0.5, 2.0, 64),
+                                                # cache-resident slabs (32x32 / 64x64 latents): sibling workgroups, one launch (round 5):
+                                                # 16- / 8- / 4-byte accesses by the alignment of a group, a group straddling the concat
+                                                (1280, 0, 1, 0.5, 2.0, 1024), (1280, 640, 1, -50.0, 1.0, 1024), (640, 320, 0, 0.5, 2.0, 1024),
+                                                (640, 0, 1, 256.0, 4.0, 4096), (320, 0, 1, 50.0, 1.0, 1024), (1280, 1280, 1, 0.5, 2.0, 1024)])
 def test_groupnorm(dev, C0, C1, act, mean, std, HW):
     torch.manual_seed(7)
     B = 2
@@ -729,8 +759,13 @@ def test_groupnorm(dev, C0, C1, act, mean, std, HW):
         torch.cuda.synchronize()
         assert torch.equal(yf, y1)
     else:
-        with pytest.raises(lib.SlidersHipError, match="small-tensor"):
+        with pytest.raises(lib.SlidersHipError, match="one-launch"):
             lib.call(lib.OP_GN_FUSED, d, stream())
+        # the one-launch form has no in-place variant either (sibling workgroups re-read the slab)
+        if C1 == 0 and lib.gn_fused_ok(C, HW, 32) == 2:
+            with pytest.raises(lib.SlidersHipError, match="alias"):
+                lib.call(lib.OP_GN_FUSED, lib.GnDesc(x0=p(x0), gamma=p(g), beta=p(bta), stats=p(sf), y=p(x0), ldx0=C0, c0=C0, batch=B,
+                                                     hw=HW, groups=32, ldy=C, eps=1e-5, act=act), stream())
     # backward (dx only)
     dy = bf(torch.randn(B * HW, C, device=dev))
     bst = torch.full((B, 32, 2), float("nan"), device=dev)
