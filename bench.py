@@ -122,6 +122,8 @@ def measure_roofline(eng, plan):
             one.run(s)
 
     def name(d):     # template arguments exactly as rocprofv3 prints them
+        if (d.tile >> 12) & 15 == 5:             # the 64 x 160 tile (csrc/gemm5.hip)
+            return f"gemm5_kernel<{'true' if d.lora_down else 'false'}>"
         v = lib.gemm_variant(d)
         st = (d.tile >> 8) & 15
         stages = st if st in (3, 4) else 2

@@ -115,7 +115,8 @@ typedef struct slh_gemm_desc {
      *   producer (the GEMM that writes the tensor LayerNorm reads): ln_out [N/64][M][2] fp32 (chunk-major: a wave's 32 rows
      *     are contiguous for both sides) receives (mean, M2) of every 64-column chunk of every row of the bf16 result;
      *     needs a 128-column tile, no GEGLU / vt_out.
-     *   consumer (dense, single source, K = LayerNorm width <= 1280): ln_in = the producer's ln_out, ln_in_chunks = K/64;
+     *   consumer (dense, single source, K = LayerNorm width <= 1280): ln_in = the producer's ln_out, ln_in_chunks = K/64 (K/80
+     *     behind a producer on the 64 x 160 tile: equal-sized chunks of either width merge the same way);
      *     w must hold W * gamma, ln_s [N] fp32 its row sums, ln_b [N] fp32 = bias + W . beta (bias must be NULL):
      *     c = rstd_m * (a . w^T - mean_m * ln_s) + ln_b, the row's mean / rstd merged from the chunks in a fixed order. */
     float* ln_out;
@@ -159,6 +160,11 @@ int slh_gemm(const slh_gemm_desc* d, slh_stream_t stream);
 /* (WM<<12)|(MI<<8)|(NI<<4)|mode of the kernel instantiation gemm_kernel<MI,NI,mode,..,WM> slh_gemm would launch for d
  * (used by bench.py to attribute measured time and algorithmic FLOPs to one profiled kernel name). */
 int slh_gemm_variant(const slh_gemm_desc* d);
+/* The 64 x 160 tile (tile code bits 12-15 = 5, e.g. 0x5425; csrc/gemm5.hip): 4 waves of 32 x 80 on the 16 x 16 x 32 MFMA, 4-slot LDS
+ * ring - the M = 2048, N = 1280 products as 256 workgroups = one full round of the chip.  Dense single-source products with packed
+ * weights (w_layout = 1), M % 64 == 0, N % 160 == 0; epilogue: bias, residual, ln_out - whose chunks are then 80 COLUMNS wide:
+ * ln_out [N/80][M][2], and the consumer's ln_in_chunks = K / 80.  slh_gemm5_ok(d) = 1 where it can run the descriptor. */
+int slh_gemm5_ok(const slh_gemm_desc* d);
 
 /* ------------------------------------------------------------------------------------------------
  * slh_skinny: T[M][R] = A[M][K] . Wd[R][K]^T (+bias), R <= 16, same A addressing as slh_gemm.

@@ -530,6 +530,8 @@ int launch_gemm(const GemmArgs& a, int mode, int stages, hipStream_t s) {
 
 }  // namespace
 
+int slh_gemm5_launch(const slh_gemm_desc* d, slh_stream_t stream);      // gemm5.hip
+
 static int slh_ncu() {
     static const int ncu = [] {
         int dev = 0;
@@ -649,6 +651,7 @@ extern "C" int slh_gemm(const slh_gemm_desc* d, slh_stream_t stream) {
                   "slh_gemm: geglu = 3 (16 | 16 weight blocks) needs N %% 32 == 0 and excludes adapters, residual, row bias, geglu_pre, vt_out, ln_out");
     SLH_CHECK(d->geglu >= 0 && d->geglu <= 3, "slh_gemm: geglu is 0, 1 / 3 (forward epilogue, 32 | 32 or 16 | 16 weight blocks) or 2 (backward form)");
 
+    if (((d->tile >> 12) & 15) == 5) return slh_gemm5_launch(d, stream);      // the 64 x 160 tile (gemm5.hip): its own descriptor checks
     int MI = 2, NI = 2, WM = 2;
     pick_tile(d, MI, NI, WM);
     if (WM == 8) {
@@ -701,8 +704,9 @@ extern "C" int slh_gemm(const slh_gemm_desc* d, slh_stream_t stream) {
                           ((d->tile >> 16) & 15) <= 1,
                       "slh_gemm: ln_in with a fused adapter runs on the ping-pong 128 x 192 / 128 x 256 tiles (0x8013, 0x8014) and needs "
                       "ln_lora_s / ln_lora_c (lora_down = A . gamma); forward form, no split-K");
-        SLH_CHECK(d->ln_in_chunks >= 1 && d->ln_in_chunks <= 20 && d->K == 64 * d->ln_in_chunks,
-                  "slh_gemm: ln_in_chunks must be K / 64 (<= 20)");
+        SLH_CHECK(d->ln_in_chunks >= 1 && d->ln_in_chunks <= 20 && d->K % d->ln_in_chunks == 0 &&
+                      (d->K == 64 * d->ln_in_chunks || d->K == 80 * d->ln_in_chunks),
+                  "slh_gemm: ln_in_chunks must be K / 64 (producer on a 64 / 128-column tile) or K / 80 (producer on the 64 x 160 tile), <= 20");
         SLH_CHECK(((uintptr_t)d->ln_in & 7) == 0 && ((uintptr_t)d->ln_s & 15) == 0 && ((uintptr_t)d->ln_b & 15) == 0,
                   "slh_gemm: ln_in / ln_s / ln_b alignment");
     }

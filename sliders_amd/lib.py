@@ -141,7 +141,7 @@ _ENTRY = {
 }
 
 EXPORTS = ["slh_version", "slh_last_error", "slh_run_program", "slh_desc_sizes", "slh_graph_capture", "slh_graph_launch",
-           "slh_graph_destroy", "slh_gemm_variant", "slh_gn_row_blocks", "slh_gn_clusters", "slh_gn32_row_blocks",
+           "slh_graph_destroy", "slh_gemm_variant", "slh_gemm5_ok", "slh_gn_row_blocks", "slh_gn_clusters", "slh_gn32_row_blocks",
            "slh_lora_wgrad_blocks", "slh_lora_wgrad_single_blocks", "slh_transpose_heads_blocks", "slh_gn_fused_ok"] + [v[0] for v in _ENTRY.values()]
 
 
@@ -209,6 +209,17 @@ def gn_workspace(channels: int, hw: int, groups: int):
         raise SlidersHipError(f"slh_gn_row_blocks({channels}, {hw}, {groups}): unsupported shape")
     c = l.slh_gn_clusters(r)
     return r + c, 1 + c
+
+
+TILE_64x160 = 0x5425      # the 64 x 160 tile of csrc/gemm5.hip (bits 12-15 = 5: family; 4 ring slots; 2 x 5 blocks of 16 x 16 per wave)
+
+
+def gemm5_ok(desc) -> bool:
+    """slh_gemm5_ok: the 64 x 160 tile can run this descriptor (dense, packed weights, M % 64 == 0, N % 160 == 0, bias / residual / ln_out)"""
+    lib = load()
+    lib.slh_gemm5_ok.argtypes = [C.POINTER(GemmDesc)]
+    lib.slh_gemm5_ok.restype = c_i32
+    return bool(lib.slh_gemm5_ok(C.byref(desc)))
 
 
 def gn_fused_ok(channels: int, hw: int, groups: int) -> int:

@@ -400,7 +400,11 @@ class UNetPlan:
         if geglu_pre is not None:
             assert geglu and geglu_pre.C == N
             d.geglu_pre, d.ld_pre = geglu_pre.ptr, geglu_pre.ld
-        if want_ln_out and not d.splitk_c32 and (lib.gemm_variant(d) >> 4) & 15 == 2 and \
+        if want_ln_out and (d.tile >> 12) & 15 == 5:
+            st = self.f32((N // 80, M, 2), name + ".ln_chunks")      # the 64 x 160 tile leaves 80-column chunks (a wave's columns)
+            d.ln_out = st.ptr
+            out.ln = (st, N // 80)
+        elif want_ln_out and not d.splitk_c32 and (lib.gemm_variant(d) >> 4) & 15 == 2 and \
                 ((d.tile >> 12) & 15 != 8 or (d.tile >> 4) & 15 == 4):
             st = self.f32((N // 64, M, 2), name + ".ln_chunks")
             d.ln_out = st.ptr

@@ -34,6 +34,9 @@ def tile_ok(d, tile: int) -> bool:
         return tile == 0x4412
     if tile >> 20:                                # bits 20+ are reserved (round 4's stream-K form lived there; removed)
         return False
+    if wm == 5:                                   # the 64 x 160 tile (csrc/gemm5.hip): the library's own rule
+        from . import lib
+        return not (tile >> 16) & 15 and lib.gemm5_ok(d)
     if getattr(d, "ln_in", None) and d.lora_down:     # LayerNorm fold + fused adapter: ping-pong 128 x 192 / 128 x 256, no split-K
         return wm == 8 and mi == 1 and ni in (3, 4) and not (tile >> 16) & 15 and \
             (not d.vt_out or (ni == 4 and d.mode == 0))
@@ -93,7 +96,9 @@ def tuned_tile(d) -> int:
     if not t and d.lora_down:      # adapter fused in but only the plain product was measured (backward-data GEMMs): same tile
         t = tb.get(base[:-1] + "0", 0)
     if t and not tile_ok(d, t):
-        t = 0
+        # an entry for the 64 x 160 tile names a shape, not a feature set (the key does not see row bias, V^T stores, training outputs):
+        # where the launch needs more than that tile's epilogue offers, the 128 x 128 ring tile it replaced runs
+        t = 0x4412 if (t >> 12) & 15 == 5 and tile_ok(d, 0x4412) else 0
     force = os.environ.get("SLIDERS_FORCE_STAGES")     # experiment knob: 2 or 3 for every non-128x128 tile
     if force and t and (t & 0xFF) != 0x22:
         t = (t & 0xFF) | (int(force) << 8 if force == "3" else 0)

@@ -158,7 +158,10 @@ def test_planner_fusions_of_the_no_grad_pass(name, hw):
             wpos.setdefault(d.w, i)
     touches = [(i, d) for i, (o, d) in enumerate(ops) if o == lib.OP_GEMM and d.pf_ptr]
     if name == "sdxl":
-        assert len(touches) >= 150
+        # (round 5: attn2.to_out / proj_out / ff.net.2 of the 1280-channel level run on the 64 x 160 tile - 256 workgroups, no idle slots -
+        # so a block is left with two carriers, attn1.to_out and attn2.to_q, for its three big matrices: GEGLU.proj and ff.net.2 are
+        # touched, the next block's q|k|v is not; measured with this assignment)
+        assert len(touches) >= 120
     assert all((d.tile & 0xFFFFFF) == 0x4412 and d.pf_bytes >= 6 << 20 for _, d in touches)
     for j, dj in touches:       # the bytes a launch touches are the packed weights of a product at most TOUCH_WINDOW ops LATER
         later = [d for o, d in ops[j + 1:j + 1 + TOUCH_WINDOW] if o == lib.OP_GEMM and d.w == dj.pf_ptr]

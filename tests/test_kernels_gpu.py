@@ -432,6 +432,150 @@ def test_gemm_layernorm_folded(dev, C, offset):
         lib.call(lib.OP_GEMM, bad, stream())
 
 
+@pytest.mark.parametrize("M,N,K", [(64, 160, 64), (192, 320, 128), (256, 480, 192), (2048, 1280, 1280), (128, 160, 5120), (320, 1280, 320),
+                                   (64, 160, 256)])
+def test_gemm_tile_64x160(dev, M, N, K):
+    """The 64 x 160 tile (csrc/gemm5.hip, tile 0x5425: 4 waves of 32 x 80 on the 16 x 16 x 32 MFMA, 4-slot LDS ring): packed weights,
+    every K-loop length class of the ring (1, 2, 3, 4 and many K tiles), plain / bias / bias + residual, against fp32; bit-equal
+    between runs."""
+    from sliders_amd.weights import pack_gemm_w
+    torch.manual_seed(M + N + K)
+    x = bf(torch.randn(M, K, device=dev))
+    w = bf(torch.randn(N, K, device=dev) / math.sqrt(K))
+    bias = bf(torch.randn(N, device=dev))
+    res = bf(torch.randn(M, N, device=dev))
+    wp = pack_gemm_w(w)
+    for use_bias, use_res in ((False, False), (True, False), (True, True)):
+        c = torch.full((M, N), float("nan"), device=dev, dtype=torch.bfloat16)
+        d = lib.GemmDesc(a0=p(x), w=p(wp), bias=p(bias) if use_bias else 0, residual=p(res) if use_res else 0, c=p(c), lda0=K, ca0=K,
+                         mode=0, stride=1, ldw=0, M=M, N=N, K=K, ld_res=N, ldc=N, rows_per_sample=M, tile=lib.TILE_64x160, w_layout=1)
+        assert lib.gemm5_ok(d)
+        lib.call(lib.OP_GEMM, d, stream())
+        torch.cuda.synchronize()
+        ref = x.float() @ w.float().t() + (bias.float() if use_bias else 0) + (res.float() if use_res else 0)
+        report(f"gemm 64x160 M{M} N{N} K{K} bias{int(use_bias)} res{int(use_res)}", c, ref, TOL)
+        c2 = torch.zeros_like(c)
+        d.c = p(c2)
+        lib.call(lib.OP_GEMM, d, stream())
+        torch.cuda.synchronize()
+        assert torch.equal(c, c2)
+    # strided operands (a row slice of a wider activation, a wider output)
+    xa = bf(torch.randn(M, K + 64, device=dev))
+    cw = torch.zeros(M, N + 8, device=dev, dtype=torch.bfloat16)
+    d = lib.GemmDesc(a0=p(xa), w=p(wp), bias=p(bias), c=p(cw), lda0=K + 64, ca0=K, mode=0, stride=1, ldw=0, M=M, N=N, K=K, ldc=N + 8,
+                     rows_per_sample=M, tile=lib.TILE_64x160, w_layout=1)
+    lib.call(lib.OP_GEMM, d, stream())
+    torch.cuda.synchronize()
+    report(f"gemm 64x160 strided M{M} N{N} K{K}", cw[:, :N], xa[:, :K].float() @ w.float().t() + bias.float(), TOL)
+    assert float(cw[:, N:].float().abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("C,offset", [(320, 0.0), (640, 0.0), (1280, 0.0), (1280, 8.0)])
+def test_gemm_tile_64x160_layernorm_producer(dev, C, offset):
+    """ln_out on the 64 x 160 tile: (mean, M2) of every 80-COLUMN chunk of the stored rows, chunk-major [C/80][M][2]; a consumer on the
+    ordinary tiles merges them with ln_in_chunks = C / 80 (equal-sized chunks of either width merge the same way) and reproduces
+    Linear(LayerNorm(h)) of the reference's op sequence."""
+    from sliders_amd.weights import fold_layernorm, pack_gemm_w
+    torch.manual_seed(C + 5)
+    M = 320
+    o = bf(torch.randn(M, C, device=dev))
+    wo = bf(torch.randn(C, C, device=dev) / math.sqrt(C))
+    bo = bf(torch.randn(C, device=dev) + offset)
+    res = bf(torch.randn(M, C, device=dev) * 2)
+    gamma, beta = bf(torch.randn(C, device=dev) * 0.5 + 1.0), bf(torch.randn(C, device=dev) * 0.3)
+    h = torch.zeros(M, C, device=dev, dtype=torch.bfloat16)
+    chunks = torch.full((C // 80, M, 2), float("nan"), device=dev)
+    d = lib.GemmDesc(a0=p(o), w=p(pack_gemm_w(wo)), bias=p(bo), residual=p(res), c=p(h), lda0=C, ca0=C, mode=0, stride=1, ldw=0, M=M, N=C,
+                     K=C, ld_res=C, ldc=C, rows_per_sample=M, tile=lib.TILE_64x160, w_layout=1, ln_out=p(chunks))
+    lib.call(lib.OP_GEMM, d, stream())
+    torch.cuda.synchronize()
+    report(f"ln producer 64x160 C{C}", h, (o.float() @ wo.float().t() + bo.float() + res.float()), TOL)
+    hc = h.float().view(M, C // 80, 80).double()
+    mref = hc.mean(-1)
+    m2ref = ((hc - mref[..., None]) ** 2).sum(-1)
+    got = chunks.permute(1, 0, 2).double()
+    assert float((got[..., 0] - mref).abs().max()) < 1e-5 * max(1.0, float(mref.abs().max()))
+    assert float(((got[..., 1] - m2ref) / m2ref).abs().max()) < 1e-4
+    ln = bf(F.layer_norm(h.float(), (C,), gamma.float(), beta.float(), 1e-5))
+    N = 2 * C
+    w = bf(torch.randn(N, C, device=dev) / math.sqrt(C))
+    wf, sv, bp = fold_layernorm(w, None, gamma, beta)
+    for tile in (0x4412, 0x22, 0x8014, 0x8015):
+        c = torch.zeros(M, N, device=dev, dtype=torch.bfloat16)
+        mr = torch.full((M, 2), float("nan"), device=dev)
+        d = lib.GemmDesc(a0=p(h), w=p(wf), c=p(c), lda0=C, ca0=C, mode=0, stride=1, ldw=C, M=M, N=N, K=C, ldc=N, rows_per_sample=M, tile=tile,
+                         ln_in=p(chunks), ln_in_chunks=C // 80, ln_s=p(sv), ln_b=p(bp), ln_eps=1e-5, ln_mr_out=p(mr))
+        lib.call(lib.OP_GEMM, d, stream())
+        torch.cuda.synchronize()
+        report(f"ln consumer of 80-column chunks tile{tile:x} C{C} off{offset}", c, ln.float() @ w.float().t(), TOL)
+        hd = h.double()
+        assert float((mr[:, 0].double() - hd.mean(-1)).abs().max()) < 1e-5 * max(1.0, float(hd.mean(-1).abs().max()))
+        assert float((mr[:, 1].double() * torch.sqrt(hd.var(-1, unbiased=False) + 1e-5) - 1).abs().max()) < 1e-4
+
+
+@pytest.mark.parametrize("M,N,K", [(64, 160, 64), (192, 320, 192), (2048, 1280, 1280), (128, 160, 2560)])
+def test_gemm_tile_64x160_fused_adapter(dev, M, N, K):
+    """lora.py:108-112 inside the 64 x 160 tile: lora_down as 8 extra rows of the W tile, T = x . A^T by one MFMA per row block and
+    k-step, the up-projection as one MFMA per accumulator block; T written out (lora_t_out) for the backward.  Against fp32 with the
+    reference's rounding of the down-projection output, and against the 128 x 128 ring tile's fused form."""
+    from sliders_amd.weights import pack_gemm_w
+    torch.manual_seed(M + N + K + 1)
+    x = bf(torch.randn(M, K, device=dev))
+    w = bf(torch.randn(N, K, device=dev) / math.sqrt(K))
+    bias, res = bf(torch.randn(N, device=dev)), bf(torch.randn(M, N, device=dev))
+    A = bf(torch.randn(4, K, device=dev) / math.sqrt(K))
+    up = bf(torch.randn(N, 4, device=dev))
+    scale = torch.tensor([0.75], device=dev)
+    wp = pack_gemm_w(w)
+    outs = {}
+    for tile in (lib.TILE_64x160, 0x4412):
+        c = torch.full((M, N), float("nan"), device=dev, dtype=torch.bfloat16)
+        T = torch.full((M, 4), float("nan"), device=dev)
+        ch = torch.full((N // 80, M, 2), float("nan"), device=dev)
+        d = lib.GemmDesc(a0=p(x), w=p(wp), bias=p(bias), residual=p(res), c=p(c), lda0=K, ca0=K, mode=0, stride=1, ldw=0, M=M, N=N, K=K,
+                         ld_res=N, ldc=N, rows_per_sample=M, tile=tile, w_layout=1, lora_down=p(A), lora_up=p(up), lora_scale=p(scale),
+                         ld_t=4, lora_groups=1, lora_rank=4, lora_t_out=p(T))
+        if tile == lib.TILE_64x160:
+            d.ln_out = p(ch)
+            assert lib.gemm5_ok(d)
+        lib.call(lib.OP_GEMM, d, stream())
+        torch.cuda.synchronize()
+        t32 = x.float() @ A.float().t()
+        ref = x.float() @ w.float().t() + bias.float() + res.float() + bf(0.75 * t32).float() @ up.float().t()
+        report(f"gemm 64x160 fused adapter M{M} N{N} K{K} tile{tile:x}", c, ref, TOL)
+        assert float((T - t32).abs().max()) < 2e-3 * max(1.0, float(t32.abs().max()))
+        outs[tile] = c
+        if tile == lib.TILE_64x160:
+            hc = c.float().view(M, N // 80, 80).double()
+            got = ch.permute(1, 0, 2).double()
+            assert float((got[..., 0] - hc.mean(-1)).abs().max()) < 1e-5 * max(1.0, float(hc.mean(-1).abs().max()))
+    assert float((outs[lib.TILE_64x160].float() - outs[0x4412].float()).abs().max()) <= 2.0 ** -6 * float(outs[0x4412].float().abs().max())
+    # what the tile's adapter form does not cover is refused
+    for bad in (dict(lora_groups=3, lora_rank=12, ld_t=12), dict(lora_up_rmajor=1)):
+        d = lib.GemmDesc(**{**dict(a0=p(x), w=p(wp), c=p(outs[0x4412]), lda0=K, ca0=K, mode=0, stride=1, ldw=0, M=M, N=N, K=K, ldc=N,
+                                   rows_per_sample=M, tile=lib.TILE_64x160, w_layout=1, lora_down=p(A), lora_up=p(up), lora_scale=p(scale),
+                                   ld_t=4, lora_groups=1, lora_rank=4), **bad})
+        assert not lib.gemm5_ok(d)
+
+
+def test_gemm_tile_64x160_rejections(dev):
+    """what the tile cannot run is refused before any launch (and slh_gemm5_ok says so to the planner)"""
+    from sliders_amd.weights import pack_gemm_w
+    M, N, K = 128, 320, 128
+    x, w = bf(torch.randn(M, K, device=dev)), bf(torch.randn(N, K, device=dev))
+    c = torch.zeros(M, N, device=dev, dtype=torch.bfloat16)
+    base = dict(a0=p(x), w=p(pack_gemm_w(w)), c=p(c), lda0=K, ca0=K, mode=0, stride=1, ldw=0, M=M, N=N, K=K, ldc=N, rows_per_sample=M,
+                tile=lib.TILE_64x160, w_layout=1)
+    assert lib.gemm5_ok(lib.GemmDesc(**base))
+    for bad in (dict(N=256), dict(M=100), dict(w_layout=0, ldw=K), dict(geglu=1), dict(rowbias=p(c), ld_rowbias=N),
+                dict(ln_in=p(c), ln_in_chunks=2, ln_s=p(c), ln_b=p(c)), dict(tile=lib.TILE_64x160 | 0x20000)):
+        d = lib.GemmDesc(**{**base, **bad})
+        if "tile" not in bad:
+            assert not lib.gemm5_ok(d)
+        with pytest.raises(lib.SlidersHipError, match="64 x 160"):
+            lib.call(lib.OP_GEMM, d, stream())
+
+
 @pytest.mark.parametrize("tile", [0x8014, 0x8013])
 @pytest.mark.parametrize("offset", [0.0, 20.0])
 def test_gemm_layernorm_folded_with_fused_adapter(dev, tile, offset):
