@@ -21,7 +21,7 @@ using namespace slh_gemm_detail;
 
 namespace {
 
-constexpr int G5_BM = 64, G5_BN = 160, G5_S = 4;
+constexpr int G5_BM = 64, G5_BN = 160;
 constexpr int G5_WROWS = G5_BN + 8;                   // W tile rows in LDS: 160 + the adapter's 8 (rows 160-163 = lora_down, 164-167 zero)
 constexpr int G5_STAGE = (G5_BM + G5_WROWS) * 128;   // 29 KB per ring slot
 constexpr int G5_XI = 2, G5_WI = 5, G5_L = G5_XI + G5_WI;   // LDS-DMA instructions per wave per K tile (8 rows of 128 B each)
@@ -30,14 +30,15 @@ constexpr int G5_PATCH_LD = 176;                      // bytes per row of a wave
 struct G5Args {
     const __bf16* a; const __bf16* w; const __bf16* bias; const __bf16* residual; __bf16* c; float* ln_out;
     const __bf16* lora_down; const __bf16* lora_up; const float* lora_scale; float* lora_t_out;
-    int lda, ldc, ld_res, M, N, K, tiles_m, tiles_n, group_m, ld_t;
+    int lda, ldc, ld_res, M, N, K, tiles_m, tiles_n, group_m, ld_t, skew;
 };
 
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 
 // (built with -mllvm -amdgpu-mfma-vgpr-form, Makefile: one wave per SIMD gives hipcc a 512-register budget, and it then picks the
 // AGPR form of the MFMAs and copies every accumulator through VGPRs around them)
-template <bool LORA>
+// G5_S: ring slots (tile code bits 8-11: 4 = 116 KB of LDS, 5 = 145 KB: one more K tile of LDS-DMA in flight)
+template <bool LORA, int G5_S>
 __global__ __launch_bounds__(256) void gemm5_kernel(const G5Args p) {
     __shared__ __attribute__((aligned(16))) char smem[G5_S * G5_STAGE];
     char* sX = smem;                              // [S][64][128 B]
@@ -66,14 +67,24 @@ __global__ __launch_bounds__(256) void gemm5_kernel(const G5Args p) {
     const int frow = lane >> 3, fslot = lane & 7;
     const char* xsrc[G5_XI];
     const char* wsrc[G5_WI];
+    // Skew (p.skew): the workgroups that share an operand panel inside an XCD run in step, so without it they all ask the L2 for the
+    // SAME 1 KB piece at the same moment.  Row tile tm starts its walk over the W panel's 20 pieces at piece 4 * (tm % 5), column
+    // tile tn its walk over the X panel's 8 pieces at piece 4 * (tn % 2): same pieces per K tile, a different order per sibling.
+    const int wrot = p.skew ? 4 * (tile_m % 5) : 0, xrot = p.skew ? 4 * (tile_n & 1) : 0;
+    unsigned xdst[G5_XI], wdst[G5_WI];       // byte offset of the piece inside its ring slot's X / W tile
 #pragma unroll
     for (int i = 0; i < G5_XI; ++i) {
-        const int row = (wave + 4 * i) * 8 + frow;
+        const int pc = (wave + 4 * i + xrot) & 7;
+        const int row = pc * 8 + frow;
+        xdst[i] = pc * 1024;
         xsrc[i] = (const char*)(p.a + (long)(m0 + row) * p.lda + ((fslot ^ ((row >> 1) & 7)) << 3));
     }
 #pragma unroll
     for (int i = 0; i < G5_WI; ++i) {
-        const int n = n0 + (wave + 4 * i) * 8 + frow;       // (the swizzle key of a packed row has period 16: a tile may start at row 0 / 32 of a block)
+        int pc = wave + 4 * i + wrot;
+        pc = pc >= 20 ? pc - 20 : pc;
+        const int n = n0 + pc * 8 + frow;       // (the swizzle key of a packed row has period 16: a tile may start at row 0 / 32 of a block)
+        wdst[i] = pc * 1024;
         wsrc[i] = (const char*)(p.w + ((long)(n >> 6) * (p.K >> 6)) * 4096 + ((n & 63) << 6) + (fslot << 3));
     }
     // fused adapter: wave 3 stages one more piece per K tile, rows 160-167 of the W tile = lora_down[0..3][k tile] + 4 zero rows (its
@@ -88,11 +99,11 @@ __global__ __launch_bounds__(256) void gemm5_kernel(const G5Args p) {
     const unsigned lds0 = lds_addr_of(smem);
     auto piece = [&](const int j, const int slot) {
         if (j < G5_XI) {
-            glds16_hidden(xsrc[j], lds0 + slot * (G5_BM * 128) + (wave + 4 * j) * 1024);
+            glds16_hidden(xsrc[j], lds0 + slot * (G5_BM * 128) + xdst[j]);
             xsrc[j] += 128;
         } else if (j < G5_L) {
             const int i = j - G5_XI;
-            glds16_hidden(wsrc[i], lds0 + G5_S * G5_BM * 128 + slot * (G5_WROWS * 128) + (wave + 4 * i) * 1024);
+            glds16_hidden(wsrc[i], lds0 + G5_S * G5_BM * 128 + slot * (G5_WROWS * 128) + wdst[i]);
             wsrc[i] += 8192;
         } else {
             glds16_hidden(lsrc, lds0 + G5_S * G5_BM * 128 + slot * (G5_WROWS * 128) + G5_BN * 128);
@@ -167,7 +178,9 @@ __global__ __launch_bounds__(256) void gemm5_kernel(const G5Args p) {
     // and every wave is past its last read of tile g-1; k-step 1 = [fragment reads of (g+1, 0)] [MFMAs of (g, 1) with the LDS-DMA of
     // tile g+S-1 into the slot of tile g-1 dealt out between them].  MORE / ISSUE / KEEP are compile-time (see gemm.hip).
     auto body = [&](auto more_c, auto issue_c, auto keep_c) {
-        constexpr bool MORE = decltype(more_c)::value, ISSUE = decltype(issue_c)::value, KEEP = decltype(keep_c)::value;
+        // keep_c: K tiles beyond g+1 whose LDS-DMA has been issued and may stay in flight across the barrier (S-3 in the steady state)
+        constexpr bool MORE = decltype(more_c)::value, ISSUE = decltype(issue_c)::value;
+        constexpr int KEEP = decltype(keep_c)::value;
         const int nxt = cur == G5_S - 1 ? 0 : cur + 1;
         const int prv = cur == 0 ? G5_S - 1 : cur - 1;
         __builtin_amdgcn_sched_barrier(0);
@@ -176,12 +189,8 @@ __global__ __launch_bounds__(256) void gemm5_kernel(const G5Args p) {
         mfmas(0, false, 0);
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (MORE) {
-            if constexpr (KEEP) {
-                if (extra) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((G5_S - 3) * (G5_L + 1)) : "memory");
-                else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((G5_S - 3) * G5_L) : "memory");
-            } else {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            }
+            if (extra) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(KEEP * (G5_L + 1)) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(KEEP * G5_L) : "memory");
             __builtin_amdgcn_s_barrier();
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -198,10 +207,14 @@ __global__ __launch_bounds__(256) void gemm5_kernel(const G5Args p) {
     using T_ = std::true_type;
     using F_ = std::false_type;
     int g = 0;
-    for (; g + G5_S - 1 < nk; ++g) body(T_{}, T_{}, T_{});
-    if (g + 2 < nk) { body(T_{}, F_{}, T_{}); ++g; }
-    if (g + 1 < nk) { body(T_{}, F_{}, F_{}); ++g; }
-    if (g < nk) body(F_{}, F_{}, F_{});
+    for (; g + G5_S - 1 < nk; ++g) body(T_{}, T_{}, std::integral_constant<int, G5_S - 3>{});
+    // the tail: no tile left to stage; tile g+1 must have landed, the j tiles behind it that exist stay in flight
+    if constexpr (G5_S >= 5) {
+        if (g + 3 < nk) { body(T_{}, F_{}, std::integral_constant<int, 2>{}); ++g; }
+    }
+    if (g + 2 < nk) { body(T_{}, F_{}, std::integral_constant<int, 1>{}); ++g; }
+    if (g + 1 < nk) { body(T_{}, F_{}, std::integral_constant<int, 0>{}); ++g; }
+    if (g < nk) body(F_{}, F_{}, std::integral_constant<int, 0>{});
 
     // ---- epilogue ---------------------------------------------------------------------------------------------------------------
     // acc[i][j][e] = C[m = m0 + wm*32 + i*16 + r16][n = n0 + wn*80 + j*16 + 4*g4 + e]
@@ -334,8 +347,17 @@ int slh_gemm5_launch(const slh_gemm_desc* d, slh_stream_t stream) {
     a.lda = d->lda0; a.ldc = d->ldc; a.ld_res = d->ld_res; a.M = d->M; a.N = d->N; a.K = d->K;
     a.tiles_m = d->M / G5_BM; a.tiles_n = d->N / G5_BN;
     a.group_m = g5_group_m(a.tiles_m, a.tiles_n);
-    if (d->lora_down) hipLaunchKernelGGL(gemm5_kernel<true>, dim3(a.tiles_m * a.tiles_n), dim3(256), 0, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL(gemm5_kernel<false>, dim3(a.tiles_m * a.tiles_n), dim3(256), 0, (hipStream_t)stream, a);
+    static const int skew_knob = getenv("SLH_G5_SKEW") ? atoi(getenv("SLH_G5_SKEW")) : 1;      // A/B: 0 = every sibling walks its panels in the same order
+    a.skew = skew_knob;
+    const dim3 grid(a.tiles_m * a.tiles_n);
+    const hipStream_t st = (hipStream_t)stream;
+    if (((d->tile >> 8) & 15) == 5) {      // 5 ring slots
+        if (d->lora_down) hipLaunchKernelGGL((gemm5_kernel<true, 5>), grid, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((gemm5_kernel<false, 5>), grid, dim3(256), 0, st, a);
+    } else {
+        if (d->lora_down) hipLaunchKernelGGL((gemm5_kernel<true, 4>), grid, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((gemm5_kernel<false, 4>), grid, dim3(256), 0, st, a);
+    }
     SLH_LAUNCH_CHECK("slh_gemm (64 x 160 tile)");
     return 0;
 }

@@ -433,10 +433,11 @@ def test_gemm_layernorm_folded(dev, C, offset):
 
 
 @pytest.mark.parametrize("M,N,K", [(64, 160, 64), (192, 320, 128), (256, 480, 192), (2048, 1280, 1280), (128, 160, 5120), (320, 1280, 320),
-                                   (64, 160, 256)])
-def test_gemm_tile_64x160(dev, M, N, K):
+                                   (64, 160, 256), (128, 320, 384)])
+@pytest.mark.parametrize("tile", [0x5425, 0x5525])
+def test_gemm_tile_64x160(dev, M, N, K, tile):
     """The 64 x 160 tile (csrc/gemm5.hip, tile 0x5425: 4 waves of 32 x 80 on the 16 x 16 x 32 MFMA, 4-slot LDS ring): packed weights,
-    every K-loop length class of the ring (1, 2, 3, 4 and many K tiles), plain / bias / bias + residual, against fp32; bit-equal
+    every K-loop length class of the 4- and 5-slot rings (1, 2, 3, 4, 5 and many K tiles), plain / bias / bias + residual, against fp32; bit-equal
     between runs."""
     from sliders_amd.weights import pack_gemm_w
     torch.manual_seed(M + N + K)
@@ -448,7 +449,7 @@ def test_gemm_tile_64x160(dev, M, N, K):
     for use_bias, use_res in ((False, False), (True, False), (True, True)):
         c = torch.full((M, N), float("nan"), device=dev, dtype=torch.bfloat16)
         d = lib.GemmDesc(a0=p(x), w=p(wp), bias=p(bias) if use_bias else 0, residual=p(res) if use_res else 0, c=p(c), lda0=K, ca0=K,
-                         mode=0, stride=1, ldw=0, M=M, N=N, K=K, ld_res=N, ldc=N, rows_per_sample=M, tile=lib.TILE_64x160, w_layout=1)
+                         mode=0, stride=1, ldw=0, M=M, N=N, K=K, ld_res=N, ldc=N, rows_per_sample=M, tile=tile, w_layout=1)
         assert lib.gemm5_ok(d)
         lib.call(lib.OP_GEMM, d, stream())
         torch.cuda.synchronize()
@@ -463,7 +464,7 @@ def test_gemm_tile_64x160(dev, M, N, K):
     xa = bf(torch.randn(M, K + 64, device=dev))
     cw = torch.zeros(M, N + 8, device=dev, dtype=torch.bfloat16)
     d = lib.GemmDesc(a0=p(xa), w=p(wp), bias=p(bias), c=p(cw), lda0=K + 64, ca0=K, mode=0, stride=1, ldw=0, M=M, N=N, K=K, ldc=N + 8,
-                     rows_per_sample=M, tile=lib.TILE_64x160, w_layout=1)
+                     rows_per_sample=M, tile=tile, w_layout=1)
     lib.call(lib.OP_GEMM, d, stream())
     torch.cuda.synchronize()
     report(f"gemm 64x160 strided M{M} N{N} K{K}", cw[:, :N], xa[:, :K].float() @ w.float().t() + bias.float(), TOL)
@@ -528,14 +529,14 @@ def test_gemm_tile_64x160_fused_adapter(dev, M, N, K):
     scale = torch.tensor([0.75], device=dev)
     wp = pack_gemm_w(w)
     outs = {}
-    for tile in (lib.TILE_64x160, 0x4412):
+    for tile in (lib.TILE_64x160, 0x5525, 0x4412):
         c = torch.full((M, N), float("nan"), device=dev, dtype=torch.bfloat16)
         T = torch.full((M, 4), float("nan"), device=dev)
         ch = torch.full((N // 80, M, 2), float("nan"), device=dev)
         d = lib.GemmDesc(a0=p(x), w=p(wp), bias=p(bias), residual=p(res), c=p(c), lda0=K, ca0=K, mode=0, stride=1, ldw=0, M=M, N=N, K=K,
                          ld_res=N, ldc=N, rows_per_sample=M, tile=tile, w_layout=1, lora_down=p(A), lora_up=p(up), lora_scale=p(scale),
                          ld_t=4, lora_groups=1, lora_rank=4, lora_t_out=p(T))
-        if tile == lib.TILE_64x160:
+        if tile != 0x4412:
             d.ln_out = p(ch)
             assert lib.gemm5_ok(d)
         lib.call(lib.OP_GEMM, d, stream())
@@ -545,10 +546,11 @@ def test_gemm_tile_64x160_fused_adapter(dev, M, N, K):
         report(f"gemm 64x160 fused adapter M{M} N{N} K{K} tile{tile:x}", c, ref, TOL)
         assert float((T - t32).abs().max()) < 2e-3 * max(1.0, float(t32.abs().max()))
         outs[tile] = c
-        if tile == lib.TILE_64x160:
+        if tile != 0x4412:
             hc = c.float().view(M, N // 80, 80).double()
             got = ch.permute(1, 0, 2).double()
             assert float((got[..., 0] - hc.mean(-1)).abs().max()) < 1e-5 * max(1.0, float(hc.mean(-1).abs().max()))
+    assert torch.equal(outs[lib.TILE_64x160], outs[0x5525]), "the ring depth does not change the arithmetic"
     assert float((outs[lib.TILE_64x160].float() - outs[0x4412].float()).abs().max()) <= 2.0 ** -6 * float(outs[0x4412].float().abs().max())
     # what the tile's adapter form does not cover is refused
     for bad in (dict(lora_groups=3, lora_rank=12, ld_t=12), dict(lora_up_rmajor=1)):
