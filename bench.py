@@ -123,7 +123,7 @@ def measure_roofline(eng, plan):
 
     def name(d):     # template arguments exactly as rocprofv3 prints them
         if (d.tile >> 12) & 15 == 5:             # the 64 x 160 tile (csrc/gemm5.hip)
-            return f"gemm5_kernel<{'true' if d.lora_down else 'false'}>"
+            return f"gemm5_kernel<{'true' if d.lora_down else 'false'}, {5 if (d.tile >> 8) & 15 == 5 else 4}>"
         v = lib.gemm_variant(d)
         st = (d.tile >> 8) & 15
         stages = st if st in (3, 4) else 2

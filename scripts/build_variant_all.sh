@@ -7,8 +7,8 @@ root=$(cd "$(dirname "$0")/.." && pwd)
 src=$root/sliders_amd/csrc
 mkdir -p $src/build/var_$name
 objs=""
-for u in gemm gemm8p lora norm attention attention_bwd ops vae; do
-  extra=""; [ $u == attention ] && extra="-fno-slp-vectorize"
+for u in gemm gemm8p gemm5 lora norm attention attention_bwd ops vae; do
+  extra=""; [ $u == attention ] && extra="-fno-slp-vectorize"; [ $u == gemm5 ] && extra="-mllvm -amdgpu-mfma-vgpr-form"
   hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-result $extra "$@" -c $src/$u.hip -o $src/build/var_$name/$u.o &
   objs="$objs $src/build/var_$name/$u.o"
 done

@@ -33,6 +33,26 @@ __device__ __forceinline__ float round_bf16(float f) { return (float)((__bf16)f)
 
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
 __device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+// The same function, x * Phi(x), through erfc(z) = t * exp(-z^2 + P(t)), t = 1 / (1 + z / 2) (the classic Chebyshev fit: fractional
+// error < 1.2e-7 everywhere; against float64 the product is within 4.4e-6 for |x| < 6 and as good as an fp32 evaluation of the erf
+// form beyond) - 10 fma + v_rcp_f32 + v_exp_f32 instead of libm's erff (~50 VALU slots per element: the GEGLU epilogue of a
+// 128 x 320 tile spent ~7 us of each of its two rounds on it, one workgroup per CU).  Forward GEGLU only; its result is rounded to
+// bf16 next (the reference's gelu output is a bf16 tensor).  -DSLH_GELU_ERFF restores erff (A/B builds).
+__device__ __forceinline__ float gelu_erf_fast_f(float x) {
+#ifdef SLH_GELU_ERFF
+    return gelu_erf_f(x);
+#else
+    const float z = fabsf(x) * 0.70710678118654752f;
+    const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(0.5f, z, 1.0f));
+    float p = 0.17087277f;
+    p = __builtin_fmaf(p, t, -0.82215223f); p = __builtin_fmaf(p, t, 1.48851587f); p = __builtin_fmaf(p, t, -1.13520398f);
+    p = __builtin_fmaf(p, t, 0.27886807f); p = __builtin_fmaf(p, t, -0.18628806f); p = __builtin_fmaf(p, t, 0.09678418f);
+    p = __builtin_fmaf(p, t, 0.37409196f); p = __builtin_fmaf(p, t, 1.00002368f); p = __builtin_fmaf(p, t, -1.26551223f);
+    const float e = t * __expf(__builtin_fmaf(-z, z, p));          // erfc(|x| / sqrt 2)
+    const float h = 0.5f * e;
+    return x * (x >= 0.f ? 1.0f - h : h);
+#endif
+}
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

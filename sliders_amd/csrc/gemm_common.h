@@ -437,7 +437,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, char* smem, f32
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         const float av = round_bf16(a[e]), gv = round_bf16(g[e]);   // the reference rounds proj(x) to bf16 before chunk / gelu
-                        o[e] = (__bf16)(av * round_bf16(gelu_erf_f(gv)));
+                        o[e] = (__bf16)(av * round_bf16(gelu_erf_fast_f(gv)));
                     }
 #ifdef SLH_GEGLU_STORE8
                     if (m < p.M) *(bf16x4*)(p.c + (long)m * p.ldc + (nb >> 1) + q * 8 + lhi * 4) = o;
@@ -507,7 +507,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, char* smem, f32
                     for (int e = 0; e < 4; ++e) {
                         // reference rounds proj(x) to bf16 before chunk/gelu
                         const float av = round_bf16(a[e]), gv = round_bf16(g[e]);
-                        o[e] = (__bf16)(av * round_bf16(gelu_erf_f(gv)));
+                        o[e] = (__bf16)(av * round_bf16(gelu_erf_fast_f(gv)));
                     }
                     *(bf16x4*)(p.c + (long)m * p.ldc + nout) = o;
                     if (p.geglu_pre) {      // training: proj(x) itself, in the column order of this product, for the GEGLU backward

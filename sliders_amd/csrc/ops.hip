@@ -125,7 +125,7 @@ __global__ __launch_bounds__(256) void ew_kernel(const slh_ew_desc d) {
         if (d.op == SLH_EW_GEGLU_FWD) {
             bf16x8 o;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) o[e] = (__bf16)((float)hv[e] * round_bf16(gelu_erf_f((float)gv[e])));
+            for (int e = 0; e < 8; ++e) o[e] = (__bf16)((float)hv[e] * round_bf16(gelu_erf_fast_f((float)gv[e])));
             *(bf16x8*)(O + m * d.ldo + c) = o;
         } else {
             const bf16x8 dy = *(const bf16x8*)(B + m * d.ldb + c);

@@ -486,7 +486,8 @@ def test_gemm_tile_64x160_layernorm_producer(dev, C, offset):
     gamma, beta = bf(torch.randn(C, device=dev) * 0.5 + 1.0), bf(torch.randn(C, device=dev) * 0.3)
     h = torch.zeros(M, C, device=dev, dtype=torch.bfloat16)
     chunks = torch.full((C // 80, M, 2), float("nan"), device=dev)
-    d = lib.GemmDesc(a0=p(o), w=p(pack_gemm_w(wo)), bias=p(bo), residual=p(res), c=p(h), lda0=C, ca0=C, mode=0, stride=1, ldw=0, M=M, N=C,
+    wop = pack_gemm_w(wo)        # (kept in a variable: a temporary would be freed before the launch)
+    d = lib.GemmDesc(a0=p(o), w=p(wop), bias=p(bo), residual=p(res), c=p(h), lda0=C, ca0=C, mode=0, stride=1, ldw=0, M=M, N=C,
                      K=C, ld_res=C, ldc=C, rows_per_sample=M, tile=lib.TILE_64x160, w_layout=1, ln_out=p(chunks))
     lib.call(lib.OP_GEMM, d, stream())
     torch.cuda.synchronize()
@@ -566,7 +567,8 @@ def test_gemm_tile_64x160_rejections(dev):
     M, N, K = 128, 320, 128
     x, w = bf(torch.randn(M, K, device=dev)), bf(torch.randn(N, K, device=dev))
     c = torch.zeros(M, N, device=dev, dtype=torch.bfloat16)
-    base = dict(a0=p(x), w=p(pack_gemm_w(w)), c=p(c), lda0=K, ca0=K, mode=0, stride=1, ldw=0, M=M, N=N, K=K, ldc=N, rows_per_sample=M,
+    wp = pack_gemm_w(w)
+    base = dict(a0=p(x), w=p(wp), c=p(c), lda0=K, ca0=K, mode=0, stride=1, ldw=0, M=M, N=N, K=K, ldc=N, rows_per_sample=M,
                 tile=lib.TILE_64x160, w_layout=1)
     assert lib.gemm5_ok(lib.GemmDesc(**base))
     for bad in (dict(N=256), dict(M=100), dict(w_layout=0, ldw=K), dict(geglu=1), dict(rowbias=p(c), ld_rowbias=N),
