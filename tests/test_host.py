@@ -134,6 +134,42 @@ def test_planner_static_invariants(name, hw, method):
         assert counts["off"] < 1300     # one launch per fused op: ~1.15k for the whole SDXL UNet
 
 
+def test_tile_64x160_entries_and_fallback():
+    """The tuned table's entries for the 64 x 160 tile (csrc/gemm5.hip): every launch of the SDXL 1024^2 plans that is given that tile is
+    one the tile can run (slh_gemm5_ok, the library's own rule, also what tuning.tile_ok asks), its LayerNorm producers leave
+    80-column chunks and their consumers are told so; a launch of the same SHAPE that needs more than the tile's epilogue offers
+    falls back to the 128 x 128 ring tile, not to the untuned heuristic."""
+    from sliders_amd.tuning import tile_ok, tuned_tile
+    cfg = CONFIGS["sdxl"]()
+    store = LoraStore(cfg, train_method="noxattn", init="none")
+    store.temb_tcol = torch.zeros(1, dtype=torch.int32)
+    seen = 0
+    for mode, B in (("on", 2), ("train", 2), ("off", 3)):
+        va, vz = Arena(1 << 50, None), Arena(1 << 40, None)
+        p = UNetPlan(cfg, _FakeWeights(cfg), va, vz, B, 128, 128, 77, store if mode != "off" else None, mode, 0x10)
+        gemms = [d for o, d in p.prog.ops if o == lib.OP_GEMM]
+        g5 = [d for d in gemms if (d.tile >> 12) & 15 == 5]
+        assert all(lib.gemm5_ok(d) and tile_ok(d, d.tile) for d in g5)
+        assert all(d.M % 64 == 0 and d.N % 160 == 0 and not d.lora_down and not d.ln_in for d in g5)
+        if mode == "off":
+            assert not g5                      # M = 3072: 1.5 rounds of 64 x 160 tiles, measured slower - no entries
+            continue
+        assert len(g5) >= 150 and {d.tile for d in g5} == {0x5425, 0x5525}
+        seen += len(g5)
+        # chunk statistics: producers on the tile leave N / 80 chunks, and whoever folds that LayerNorm merges N / 80 chunks of it
+        prod = {d.ln_out: d.N // 80 for d in g5 if d.ln_out}
+        cons = [d for d in gemms if d.ln_in in prod]
+        assert prod and cons and all(d.ln_in_chunks == prod[d.ln_in] and d.K == 80 * d.ln_in_chunks for d in cons)
+        assert all(d.ln_in_chunks * 64 == d.K for d in gemms if d.ln_in and d.ln_in not in prod)
+    assert seen
+    # same key, a feature the tile has no epilogue for (a per-sample row bias): the ring tile it replaced runs
+    d = lib.GemmDesc(a0=0x1000, w=0x2000, c=0x3000, lda0=1280, ca0=1280, mode=0, stride=1, ldw=0, M=2048, N=1280, K=1280, ldc=1280,
+                     rows_per_sample=1024, w_layout=1)
+    assert tuned_tile(d) == 0x5425
+    d.rowbias, d.ld_rowbias = 0x4000, 1280
+    assert not lib.gemm5_ok(d) and tuned_tile(d) == 0x4412
+
+
 @pytest.mark.parametrize("name,hw", [("sdxl", 128), ("sd2", 64), ("sd1", 64)])
 def test_planner_fusions_of_the_no_grad_pass(name, hw):
     """Launch-count invariants of the adapters-on no-grad pass (the one the denoise loop replays): with 64-wide heads
