@@ -39,7 +39,9 @@ HBM_PEAK_GBS = 8000.0
 
 def parse():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=None,
+                    help="ranks of this node (one process per GPU).  N > 1 outside torch.distributed.run re-launches this script under it; "
+                         "default: WORLD_SIZE when launched by torch.distributed.run, else 1")
     ap.add_argument("--steps", type=int, default=6)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--model", default="sdxl")
@@ -97,7 +99,7 @@ def pmc_traffic_for(kname, profiles_dir=None):
             # a counter file of OTHER kernels is not evidence about these: say so instead of pairing the numbers silently
             tsrc = (f"none: profiles/{os.path.basename(tpath)} was taken on kernel sources / tile tables hash {there_hash or 'unrecorded'}, "
                     f"this tree hashes {here_hash}" + ("" if pm else f"; it has no row for {kname}") +
-                    " - re-run scripts/measure_round4.sh")
+                    " - re-run scripts/measure_round.sh <round tag>")
     return traffic, tsrc
 
 
@@ -121,23 +123,7 @@ def measure_roofline(eng, plan):
             one.add(opcode, d)
             one.run(s)
 
-    def name(d):     # template arguments exactly as rocprofv3 prints them
-        if (d.tile >> 12) & 15 == 5:             # the 64 x 160 tile (csrc/gemm5.hip)
-            return f"gemm5_kernel<{'true' if d.lora_down else 'false'}, {5 if (d.tile >> 8) & 15 == 5 else 4}>"
-        v = lib.gemm_variant(d)
-        st = (d.tile >> 8) & 15
-        stages = st if st in (3, 4) else 2
-        mi, ni, wm = (v >> 8) & 15, (v >> 4) & 15, v >> 12
-        stage_bytes = (32 * mi * wm + 64 * ni + (32 if d.lora_down else 0)) * 128
-        while stages > 2 and stages * stage_bytes > 160 * 1024:      # the launcher falls back to the deepest ring that fits
-            stages -= 1
-        if wm == 8:                              # ping-pong K loops (csrc/gemm8p.hip)
-            if mi == 4:
-                return f"gemm8p_kernel<{v & 15}, false>"
-            return f"gemm8pb_kernel<{mi}, {ni}, {v & 15}, {'true' if d.lora_down else 'false'}>"
-        # ... <MI, NI, MODE, STAGES, LORA, WM, XA (cross-attention in the epilogue)>
-        xa = "true" if d.xa_k else "false"
-        return f"gemm_kernel<{mi}, {ni}, {v & 15}, {stages}, {'true' if d.lora_down else 'false'}, {wm}, {xa}>"
+    name = lib.gemm_kernel_name     # the instantiation slh_gemm launches for a descriptor, as rocprofv3 prints it (asked of the library)
 
     for _ in range(2):
         plan.prog.run(s)                        # warm-up passes (also make every input of every op valid)
@@ -486,11 +472,11 @@ def cpu_baseline(model, hw):
 
 
 def params_hash64(store) -> int:
-    """64-bit digest of the replicated adapter state (flat parameters + both moments): sum and xor-fold of the raw 16-bit words,
-    computed on the device, exact in int64.  Equal state -> equal digest; used to assert that the ranks still hold bit-identical
-    replicas after the timed region."""
+    """64-bit digest of the replicated adapter state (flat parameters, both moments and - train.precision float32 - the fp32 master the
+    bf16 parameters are rounded from): sum and xor-fold of the raw 16-bit words, computed on the device, exact in int64.  Equal state ->
+    equal digest; used to assert that the ranks still hold bit-identical replicas after the timed region."""
     h = 0
-    for i, t in enumerate((store.params, store.exp_avg, store.exp_avg_sq)):
+    for i, t in enumerate((store.params, store.exp_avg, store.exp_avg_sq, getattr(store, "master", None))):
         if t is None:
             continue
         w = t.view(torch.int16).to(torch.int64) & 0xFFFF
@@ -519,9 +505,37 @@ def dp_self_check(tr, store, dev, rank, world):
             "note": "HIP events around torch.distributed.all_reduce on the stream the backward ran on; the timed loop carries them"}
 
 
+def multi_gpu_relaunch(gpus, argv, env, visible_devices):
+    """`python bench.py --gpus N` with N > 1 and no torch.distributed environment: the command line that runs this same script as N
+    ranks of one node (one process per GPU over RCCL, rendezvous on 127.0.0.1), or a SystemExit when this node cannot.  Never a
+    1-rank run labelled as N.  Returns None when nothing is to be re-launched (N = 1, or already under torch.distributed.run)."""
+    if gpus <= 1 or env.get("WORLD_SIZE"):
+        return None
+    if visible_devices < gpus:
+        raise SystemExit(f"bench.py: --gpus {gpus} requested but {visible_devices} GPU(s) are visible on this node; refusing to run "
+                         f"fewer ranks under that label (run `python bench.py --gpus {max(visible_devices, 1)}`)")
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}", "--master-addr", "127.0.0.1",
+            "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
 def main():
     a = parse()
+    if a.gpus is None:
+        a.gpus = int(os.environ.get("WORLD_SIZE", "1"))
+    cmd = multi_gpu_relaunch(a.gpus, sys.argv[1:], os.environ, torch.cuda.device_count())
+    if cmd is not None:
+        import subprocess
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        print("[bench] --gpus %d: re-launching as %s" % (a.gpus, " ".join(cmd)), file=sys.stderr, flush=True)
+        sys.exit(subprocess.call(cmd, env=env))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != a.gpus:
+        raise SystemExit(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {a.gpus} (or drop --gpus)")
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1 or os.environ.get("BENCH_FORCE_PROCESS_GROUP"):      # the second form: the torchrun path on one GPU (tests/test_rccl_gpu.py)

@@ -89,8 +89,7 @@ typedef struct slh_gemm_desc {
                                 streams them: [ceil(N/64)][K/64] blocks of 64 rows x 64 k (8 KB contiguous, rows past N
                                 zero), 16-byte slot s of row r stored at slot s ^ ((r>>1)&7) (the LDS swizzle applied
                                 in memory, so every LDS-DMA instruction reads 1 KB of consecutive addresses); ldw unused */
-    int32_t reserved_;       /* 0.  Non-zero values are profiling ablations (scripts/probe_gemm.py): 1 skip tile refills,
-                                2 skip MFMA work, 4 skip the epilogue, 8 skip the first fill, 16 return at once */
+    int32_t reserved_;       /* 0 (ignored; rounds 2-5 read ablation bits from it in probe builds - those builds are gone) */
     float* splitk_c32;       /* split-K workspace or NULL: splitk_slabs slabs of roundup(M, 256) * roundup(N, 128) floats each (the
                                 partial tiles are kept whole, in accumulator order), any contents.  With tile bits 16-19 =
                                 S > 1 the K range is cut into S slices; each slice's workgroups publish their partial tiles in
@@ -160,6 +159,12 @@ int slh_gemm(const slh_gemm_desc* d, slh_stream_t stream);
 /* (WM<<12)|(MI<<8)|(NI<<4)|mode of the kernel instantiation gemm_kernel<MI,NI,mode,..,WM> slh_gemm would launch for d
  * (used by bench.py to attribute measured time and algorithmic FLOPs to one profiled kernel name). */
 int slh_gemm_variant(const slh_gemm_desc* d);
+/* Name of the kernel instantiation slh_gemm would launch for d, as rocprofv3 --kernel-trace prints it without namespace and parameter
+ * list (e.g. "gemm8pb_kernel<1, 5, 0, false>", "gemm5_kernel<false, 4>"), written to buf (cap >= 16 bytes, NUL-terminated).  All of
+ * slh_gemm's checks and its dispatch run; the launch is replaced by a record of the selected template, so the name is exact for
+ * every present and future tile.  Needs no device and launches nothing.  0, or the status slh_gemm would return for d.
+ * (bench.py / scripts/make_pmc_traffic.py pair in-situ event times and PMC rows by this name.) */
+int slh_gemm_kernel_name(const slh_gemm_desc* d, char* buf, int cap);
 /* The 64 x 160 tile (tile code bits 12-15 = 5, e.g. 0x5425; csrc/gemm5.hip): 4 waves of 32 x 80 on the 16 x 16 x 32 MFMA, 4-slot LDS
  * ring - the M = 2048, N = 1280 products as 256 workgroups = one full round of the chip.  Dense single-source products with packed
  * weights (w_layout = 1), M % 64 == 0, N % 160 == 0; epilogue: bias, residual, ln_out - whose chunks are then 80 COLUMNS wide:

@@ -1,4 +1,5 @@
-"""Where the dispatcher puts the attention workgroups (development aid; GPU box): run with the SLH_ATTN_TRACE build
+"""(Round 6: the SLH_ATTN_TRACE branches this script reads were removed from csrc/attention.hip; build the variant from
+`git show 46d9a74:sliders_amd/csrc/attention.hip` to re-run it.)  Where the dispatcher puts the attention workgroups (development aid; GPU box): run with the SLH_ATTN_TRACE build
 (SLIDERS_HIP_LIB=.../libsliders_hip_trace.so), prints waves per SIMD / workgroups per CU histograms and the launch time.
 Knob of the launcher: SLH_ATTN_NW2=1 (64-query workgroups everywhere).  (SLH_ATTN_SPREAD, an LDS cap on workgroups per CU,
 was removed after this probe showed the placement is already even: profiles/r03_attn_variants.txt.)"""

@@ -1,4 +1,6 @@
-"""Ablation timing of one slh_gemm shape: which part of the K loop the time goes to (development aid)."""
+"""Ablation timing of one slh_gemm shape: which part of the K loop the time goes to (development aid).
+(Round 6: the -DSLH_GEMM_PROBE branches were removed from csrc/gemm.hip - the shipped library ignores reserved_; build the probe
+variant from `git show 46d9a74:sliders_amd/csrc/gemm.hip` to re-run the ablations recorded in profiles/r0[1-5]_*.txt.)"""
 import argparse
 import math
 import os

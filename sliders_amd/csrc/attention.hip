@@ -23,18 +23,11 @@ __device__ __forceinline__ int lds_off(int row, int slot) {
 // NW waves per workgroup: 4 (128 queries) or 2 (64 queries, used when the grid would not fill the chip)
 // TAIL: Tk is not a multiple of 64 (cross-attention, Tk = 77): the key columns past Tk of the last tile are masked.  A
 // template flag because hipcc if-converts the mask into ~50 selects per tile that every tile of every launch would execute.
-// SLH_ATTN_GROUPED (A/B build, scripts/probe_attn.py): all fragment reads of a phase issued ahead of its MFMAs - needs ~140
-// VGPRs (3 waves per SIMD instead of 4) and measured the same (412 vs 406 us over the pass shapes: co-resident waves already
-// hide the LDS latency hipcc leaves exposed in front of every MFMA)
-#if defined(SLH_ATTN_GROUPED) && (SLH_ATTN_GROUPED + 0 == 0)
-#undef SLH_ATTN_GROUPED
-#define SLH_ATTN_GROUPED 1
-#endif
-#if defined(SLH_ATTN_GROUPED) || defined(SLH_ATTN_SUMMFMA)
-constexpr int ATTN_OCC41 = 3;
-#else
+// (Measured and not adopted - the A/B branches were taken out of this file in round 6, `git show 46d9a74:sliders_amd/csrc/attention.hip`
+// has them: all fragment reads of a phase issued ahead of its MFMAs (~140 VGPRs, 3 waves per SIMD instead of 4: 412 vs 406 us over the
+// pass shapes - co-resident waves already hide the LDS latency in front of every MFMA), row sums on the MFMA, s_setprio around the score
+// MFMAs, packed fp32 softmax arithmetic; numbers in profiles/r03_attn_variants.txt and docs/ROUND_NOTES.md.)
 constexpr int ATTN_OCC41 = 4;
-#endif
 template <int NW, int DT, bool TAIL>
 __global__ __launch_bounds__(64 * NW, DT == 1 ? (NW == 4 ? ATTN_OCC41 : 3) : ((DT == 2 && NW == 4) ? 2 : 1)) void attn_fwd_kernel(const slh_attn_desc p) {
     __shared__ __attribute__((aligned(16))) char smem[4 * DT * 8192];
@@ -55,11 +48,6 @@ __global__ __launch_bounds__(64 * NW, DT == 1 ? (NW == 4 ? ATTN_OCC41 : 3) : ((D
         const int xcd = vb & 7, idx = vb >> 3;
         vb = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + idx;
     }
-#ifdef SLH_ATTN_TRACE
-    // placement probe (scripts/probe_attn_place.py): where and when every wave ran, written over the lse buffer
-    const unsigned trace_hw = __builtin_amdgcn_s_getreg((31 << 11) | 4), trace_xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20);
-    const unsigned long trace_t0 = __builtin_amdgcn_s_memrealtime();
-#endif
     const int nqb = (p.Tq + 32 * NW - 1) / (32 * NW);
     const int qb = vb % nqb, hb = vb / nqb;
     const int h = hb % p.H, b = hb / p.H;
@@ -147,27 +135,11 @@ __global__ __launch_bounds__(64 * NW, DT == 1 ? (NW == 4 ? ATTN_OCC41 : 3) : ((D
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[dd][r] = 0.f;
     float m_run = -1e30f, l_run = 0.f;
-#ifdef SLH_ATTN_SUMMFMA
-    f32x16 osum;
-    bf16x8 ones8;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) osum[r] = 0.f;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) ones8[e] = (__bf16)1.f;
-#endif
     const f32x16 kZero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     const float c = p.scale * 1.4426950408889634f;
     // permuted key row for the A operand of S^T (swap bits 2 and 3)
     const int prow = (lrow & 3) | (((lrow >> 3) & 1) << 2) | (((lrow >> 2) & 1) << 3) | (lrow & 16);
 
-#ifdef SLH_ATTN_TRACE
-    unsigned trace_ph[5] = {0, 0, 0, 0, 0};
-    unsigned long trace_ts;
-#define TRACE_STAMP(i) { __builtin_amdgcn_sched_barrier(0); const unsigned long now_ = __builtin_amdgcn_s_memtime(); \
-                         trace_ph[i] += (unsigned)(now_ - trace_ts); trace_ts = now_; __builtin_amdgcn_sched_barrier(0); }
-#else
-#define TRACE_STAMP(i)
-#endif
     stage(0, 0);
     if constexpr (!TAIL) {
         // make hipcc wait for the Q fragments HERE: the copies above are invisible to its counter model, so a Q load it
@@ -176,21 +148,12 @@ __global__ __launch_bounds__(64 * NW, DT == 1 ? (NW == 4 ? ATTN_OCC41 : 3) : ((D
 #pragma unroll
         for (int ks = 0; ks < DT * 4; ++ks) asm volatile("" ::"v"(qf[ks]));
     }
-#ifdef SLH_ATTN_TRACE
-    trace_ts = __builtin_amdgcn_s_memtime();
-#endif
     for (int t = 0; t < nt; ++t) {
         lds_dma_syncthreads();       // tile t landed (all waves), everybody is past tile t-1
-        TRACE_STAMP(0)
         if (t + 1 < nt) stage((t + 1) & 1, t + 1);
-        TRACE_STAMP(1)
         const char* cK = sK + (t & 1) * DT * 8192;
         const char* cV = sV + (t & 1) * DT * 8192;
         f32x16 s[2];
-#ifndef SLH_ATTN_GROUPED
-#ifdef SLH_ATTN_SETPRIO
-        __builtin_amdgcn_s_setprio(1);
-#endif
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt) {
 #pragma unroll
@@ -203,47 +166,6 @@ __global__ __launch_bounds__(64 * NW, DT == 1 ? (NW == 4 ? ATTN_OCC41 : 3) : ((D
                     else s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[dt * 4 + ks], s[kt], 0, 0, 0);
                 }
         }
-#ifdef SLH_ATTN_SETPRIO
-        __builtin_amdgcn_s_setprio(0);
-#endif
-#else
-        // all K fragments of a 32-key half are requested before its first MFMA (hipcc otherwise emits read -> wait -> MFMA
-        // eight times per tile: ~100 cycles of LDS latency exposed in front of every 32-cycle MFMA); with D <= 64 both
-        // halves' reads go out before any MFMA
-        bf16x8 kf[2][DT * 4];
-        auto read_k = [&](const int kt) {
-#pragma unroll
-            for (int dt = 0; dt < DT; ++dt)
-#pragma unroll
-                for (int ks = 0; ks < 4; ++ks)
-                    kf[kt][dt * 4 + ks] = *(const bf16x8*)(cK + dt * 8192 + lds_off(kt * 32 + prow, ks * 2 + lhi));
-        };
-        auto mma_k = [&](const int kt) {
-#pragma unroll
-            for (int i = 0; i < DT * 4; ++i) {
-                // first product of the tile takes a literal-zero C operand instead of 16 zeroed registers
-                if (i == 0) s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[kt][0], qf[0], kZero16, 0, 0, 0);
-                else s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[kt][i], qf[i], s[kt], 0, 0, 0);
-            }
-        };
-        read_k(0);
-        if (DT == 1) read_k(1);
-        __builtin_amdgcn_sched_barrier(0);
-        mma_k(0);
-        if (DT != 1) { read_k(1); __builtin_amdgcn_sched_barrier(0); }
-        mma_k(1);
-        // V fragments: the four of a 32-wide d block are requested together.  Level 2 (D <= 64): all eight go out here, behind
-        // the score MFMAs, and land while the softmax runs
-        bf16x8 vf[2][4];
-        auto read_v = [&](const int set, const int dd) {
-#pragma unroll
-            for (int kstep = 0; kstep < 4; ++kstep)
-                vf[set][kstep] = *(const bf16x8*)(cV + (dd >> 1) * 8192 + lds_off((dd & 1) * 32 + lrow, kstep * 2 + lhi));
-        };
-        constexpr bool kEarlyV = SLH_ATTN_GROUPED >= 2 && DT == 1;
-        if constexpr (kEarlyV) { read_v(0, 0); read_v(1, 1); __builtin_amdgcn_sched_barrier(0); }
-#endif
-        TRACE_STAMP(2)
         // s[kt][r] = S[q = lrow][kv = t*64 + kt*32 + 16*(r>>3) + 8*lhi + (r&7)]
         if (TAIL && t == nt - 1) {
 #pragma unroll
@@ -267,41 +189,18 @@ __global__ __launch_bounds__(64 * NW, DT == 1 ? (NW == 4 ? ATTN_OCC41 : 3) : ((D
         const float mc = m_new * c;
         m_run = m_new;
         bf16x8 pb[2][2];
-#ifdef SLH_ATTN_PK
-        f32x2 ps2 = {0.f, 0.f};
-        const f32x2 c2 = {c, c}, mc2 = {mc, mc};
-#pragma unroll
-        for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-            for (int r = 0; r < 16; r += 2) {
-                const f32x2 sv = {s[kt][r], s[kt][r + 1]};
-                const f32x2 e = sv * c2 - mc2;
-                const f32x2 pv = {__builtin_amdgcn_exp2f(e[0]), __builtin_amdgcn_exp2f(e[1])};
-#ifndef SLH_ATTN_SUMMFMA
-                ps2 += pv;
-#endif
-                pb[kt][r >> 3][r & 7] = (__bf16)pv[0];
-                pb[kt][r >> 3][(r & 7) + 1] = (__bf16)pv[1];
-            }
-        const float ps = ps2[0] + ps2[1];
-#else
         // scalar fp32 softmax arithmetic (this file is built with -fno-slp-vectorize): v_pk_fma/add/mul_f32 beside MFMAs cost more
-        // than the two plain instructions they replace (same-box A/B, T = 4096: 149.9 -> 141.0 us; SLH_ATTN_PK = packed form)
+        // than the two plain instructions they replace (same-box A/B, T = 4096: 149.9 -> 141.0 us)
         float ps = 0.f;
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const float pv = __builtin_amdgcn_exp2f(__builtin_fmaf(s[kt][r], c, -mc));
-#ifndef SLH_ATTN_SUMMFMA
                 ps += pv;
-#endif
                 pb[kt][r >> 3][r & 7] = (__bf16)pv;
             }
-#endif
-#ifndef SLH_ATTN_SUMMFMA
         l_run = l_run * alpha + ps;
-#endif
         // the running maximum settles after the first tiles: rescale the accumulators only when some row of the
         // wave actually moved (alpha == 1 exactly otherwise, so skipping is bit-identical)
         if (__builtin_amdgcn_ballot_w64(alpha != 1.f) != 0) {
@@ -309,20 +208,7 @@ __global__ __launch_bounds__(64 * NW, DT == 1 ? (NW == 4 ? ATTN_OCC41 : 3) : ((D
             for (int dd = 0; dd < 2 * DT; ++dd)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) o[dd][r] *= alpha;
-#ifdef SLH_ATTN_SUMMFMA
-#pragma unroll
-            for (int r = 0; r < 16; ++r) osum[r] *= alpha;
-#endif
         }
-#ifdef SLH_ATTN_SUMMFMA
-        // row sums of the (bf16-rounded) probabilities on the matrix pipe: a ones block as the A operand of four extra
-        // products per tile; every register of osum holds the complete sum of this lane's query
-#pragma unroll
-        for (int kstep = 0; kstep < 4; ++kstep)
-            osum = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones8, pb[kstep >> 1][kstep & 1], osum, 0, 0, 0);
-#endif
-        TRACE_STAMP(3)
-#ifndef SLH_ATTN_GROUPED
 #pragma unroll
         for (int dd = 0; dd < 2 * DT; ++dd)
 #pragma unroll
@@ -330,28 +216,8 @@ __global__ __launch_bounds__(64 * NW, DT == 1 ? (NW == 4 ? ATTN_OCC41 : 3) : ((D
                 const bf16x8 vf = *(const bf16x8*)(cV + (dd >> 1) * 8192 + lds_off((dd & 1) * 32 + lrow, kstep * 2 + lhi));
                 o[dd] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pb[kstep >> 1][kstep & 1], o[dd], 0, 0, 0);
             }
-#else
-        // the next block's fragments are requested before this block's MFMAs
-        if constexpr (!kEarlyV) read_v(0, 0);
-        else __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int dd = 0; dd < 2 * DT; ++dd) {
-            if constexpr (!kEarlyV) {
-                if (dd + 1 < 2 * DT) read_v((dd + 1) & 1, dd + 1);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-#pragma unroll
-            for (int kstep = 0; kstep < 4; ++kstep)
-                o[dd] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[dd & 1][kstep], pb[kstep >> 1][kstep & 1], o[dd], 0, 0, 0);
-        }
-#endif
-        TRACE_STAMP(4)
     }
-#ifdef SLH_ATTN_SUMMFMA
-    const float l_tot = osum[0];
-#else
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
-#endif
     const float inv = 1.f / l_tot;
     if (qvalid) {
         __bf16* O = (__bf16*)p.o + ((long)b * p.Tq + qrow) * p.ldo + h * D;
@@ -367,19 +233,8 @@ __global__ __launch_bounds__(64 * NW, DT == 1 ? (NW == 4 ? ATTN_OCC41 : 3) : ((D
                     *(bf16x4*)(O + dcol) = v;
                 }
             }
-#ifndef SLH_ATTN_TRACE
         if (p.lse && lhi == 0) p.lse[((long)b * p.H + h) * p.Tq + qrow] = m_run * c + log2f(l_tot);
-#endif
     }
-#ifdef SLH_ATTN_TRACE
-    if (p.lse && lane == 0) {
-        const unsigned long trace_t1 = __builtin_amdgcn_s_memrealtime();
-        unsigned* tr = (unsigned*)p.lse + ((long)blockIdx.x * NW + wave) * 16;
-        tr[0] = trace_hw; tr[1] = trace_xcc; tr[2] = (unsigned)trace_t0; tr[3] = (unsigned)(trace_t1 - trace_t0);
-#pragma unroll
-        for (int i = 0; i < 5; ++i) tr[4 + i] = trace_ph[i];
-    }
-#endif
 }
 
 // ---- key-split form for grids that do not fill the SIMDs evenly (D = 64, whole key tiles, Tk % 128 == 0) -----------------------

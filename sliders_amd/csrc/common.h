@@ -39,9 +39,6 @@ __device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f +
 // 128 x 320 tile spent ~7 us of each of its two rounds on it, one workgroup per CU).  Forward GEGLU only; its result is rounded to
 // bf16 next (the reference's gelu output is a bf16 tensor).  -DSLH_GELU_ERFF restores erff (A/B builds).
 __device__ __forceinline__ float gelu_erf_fast_f(float x) {
-#ifdef SLH_GELU_ERFF
-    return gelu_erf_f(x);
-#else
     const float z = fabsf(x) * 0.70710678118654752f;
     const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(0.5f, z, 1.0f));
     float p = 0.17087277f;
@@ -51,7 +48,6 @@ __device__ __forceinline__ float gelu_erf_fast_f(float x) {
     const float e = t * __expf(__builtin_fmaf(-z, z, p));          // erfc(|x| / sqrt 2)
     const float h = 0.5f * e;
     return x * (x >= 0.f ? 1.0f - h : h);
-#endif
 }
 
 __device__ __forceinline__ float wave_sum(float v) {
@@ -116,6 +112,9 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t wt_rsrc(const void* base) {   
 __device__ __forceinline__ void wt_store16(const __amdgpu_buffer_rsrc_t r, const long byte_off, const bf16x8 v) {
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, (unsigned)byte_off, 0, SLH_WT_AUX);
 }
+// The resource above spans 0x7FFFFFF0 bytes from the tensor's base and the offset is 32 bits: a row store beyond that is dropped by
+// the bounds check (silently).  Every entry point that stores this way refuses a result tensor that does not fit (host side):
+inline bool wt_span_ok(long rows, long ld, long cols) { return rows <= 0 || ((rows - 1) * ld + cols) * 2 < 0x7FFFFFF0L; }
 
 // ---- fixed-order cross-workgroup reductions -----------------------------------------------------------------------
 // Every reduction whose result feeds bf16 activations (GroupNorm statistics, split-K partial sums) is done in a fixed
@@ -253,8 +252,22 @@ void slh_set_error(const char* fmt, ...);
             return -1;                  \
         }                               \
     } while (0)
+// kernel-name query mode (error.cpp; slh_gemm_kernel_name): the dispatch code runs as for a launch, slh_launch records the chosen
+// instantiation instead of launching it, and the launch checks are skipped (no device is needed)
+bool slh_name_mode();
+void slh_name_record(const char* fmt, ...);
+void slh_name_sink_set(char* buf, int cap);
+inline const char* slh_tf(bool b) { return b ? "true" : "false"; }
+// fmt + args spell the instantiation's template arguments from the SAME constants the template is instantiated with, in the one
+// statement that launches it (hipcc's __PRETTY_FUNCTION__ drops the arguments of a function-template pointer, so they are not derived)
+template <auto Kern, class A, class... N>
+inline void slh_launch(int grid, int block, hipStream_t s, const A& a, const char* fmt, N... n) {
+    if (slh_name_mode()) { slh_name_record(fmt, n...); return; }
+    hipLaunchKernelGGL(Kern, dim3(grid), dim3(block), 0, s, a);
+}
 #define SLH_LAUNCH_CHECK(name)                                              \
     do {                                                                    \
+        if (slh_name_mode()) break;                                         \
         hipError_t e_ = hipGetLastError();                                  \
         if (e_ != hipSuccess) {                                             \
             slh_set_error("%s: launch failed: %s", name, hipGetErrorString(e_)); \

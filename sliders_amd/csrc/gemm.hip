@@ -37,23 +37,6 @@ constexpr int gemm_waves_per_simd(int MI, int NI, int STAGES, bool LORA, int WM)
 }
 
 
-// timing experiment (-DSLH_GEMM_M16, wrong numbers): the operand registers and FLOPs of one 32x32x16 MFMA as two 16x16x32 MFMAs
-// on quarters of the accumulator block (half the accumulator register traffic per FLOP)
-__device__ __forceinline__ f32x16 mfma_slot(const bf16x8 a, const bf16x8 b, f32x16 c, const int ks) {
-#ifdef SLH_GEMM_M16
-    const int k0 = ks & 3, k1 = (ks & 3) ^ 2;
-    f32x4 q0 = {c[k0 * 4], c[k0 * 4 + 1], c[k0 * 4 + 2], c[k0 * 4 + 3]};
-    f32x4 q1 = {c[k1 * 4], c[k1 * 4 + 1], c[k1 * 4 + 2], c[k1 * 4 + 3]};
-    q0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, q0, 0, 0, 0);
-    q1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, q1, 0, 0, 0);
-    c[k0 * 4] = q0[0]; c[k0 * 4 + 1] = q0[1]; c[k0 * 4 + 2] = q0[2]; c[k0 * 4 + 3] = q0[3];
-    c[k1 * 4] = q1[0]; c[k1 * 4 + 1] = q1[1]; c[k1 * 4 + 2] = q1[2]; c[k1 * 4 + 3] = q1[3];
-    return c;
-#else
-    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
-#endif
-}
-
 template <int MI, int NI, int MODE, int STAGES, bool LORA, int WM, bool XA = false>
 __global__ __launch_bounds__(128 * WM, gemm_waves_per_simd(MI, NI, STAGES, LORA, WM)) void gemm_kernel(const GemmArgs p) {
     constexpr int NW = 2 * WM;
@@ -73,9 +56,6 @@ __global__ __launch_bounds__(128 * WM, gemm_waves_per_simd(MI, NI, STAGES, LORA,
     char* sW = smem + STAGES * BM * 128;    // [STAGES][BN][128 B]
     char* sL = smem + STAGES * (BM + BN) * 128;   // [STAGES][32][128 B]
 
-#ifdef SLH_GEMM_PROBE
-    if (p.probe & 16) return;   // diagnostics: launch + dispatch cost only
-#endif
     // the last pf_blocks workgroups of the grid (slh_gemm_desc.pf_*); only in the ring tile's instantiations: slh_gemm gives the
     // hint to no other tile, and the 16 loads in flight per thread do not fit the 80-register budgets of the small tiles
     if constexpr (STAGES == 4 && WM == 4 && MI == 1 && NI == 2) {
@@ -133,19 +113,12 @@ __global__ __launch_bounds__(128 * WM, gemm_waves_per_simd(MI, NI, STAGES, LORA,
     }
     const int wkstep = p.w_packed ? 4096 : BK;   // elements between consecutive K tiles of one W row group
 
-    // 2-slot loop: compiler-visible LDS-DMA.  (Issued from inline asm like the deep ring - SLH_GEMM_HIDDEN_STAGE - hipcc counts
+    // 2-slot loop: compiler-visible LDS-DMA.  (Issued from inline asm like the deep ring, hipcc counts
     // lgkmcnt in front of the MFMAs instead of waiting lgkmcnt(0), but the pass time did not change in a same-box A/B, and the
     // compiler's own vmcnt(0) in front of the epilogue barriers, which scripts/check_lds_dma_waits.py relies on, goes away.)
     auto stage_copy = [&](const void* src, void* lds_dst) {
-#ifdef SLH_GEMM_HIDDEN_STAGE
-        glds16_hidden(src, lds_addr_of(lds_dst));
-#else
         glds16(src, lds_dst);
-#endif
     };
-#if defined(SLH_GEMM_PROBE_W)
-    bool probe_first_tile = true;
-#endif
     auto stage = [&](int buf, int kt) {
         const int k0 = kt * BK;
         char* dX = sX + buf * (BM * 128);
@@ -184,9 +157,6 @@ __global__ __launch_bounds__(128 * WM, gemm_waves_per_simd(MI, NI, STAGES, LORA,
         }
 #pragma unroll
         for (int i = 0; i < WI; ++i) {
-#ifdef SLH_GEMM_PROBE_W        // ablation build (scripts/build_variant.sh): probe bit 32 = no W refills after the first tile
-            if ((p.probe & 32) && !probe_first_tile) continue;
-#endif
             stage_copy(wptr[i] + (long)kt * wkstep, dW + (wave + NW * i) * 1024);
         }
         if (LORA) {
@@ -196,9 +166,6 @@ __global__ __launch_bounds__(128 * WM, gemm_waves_per_simd(MI, NI, STAGES, LORA,
                                     : (const __bf16*)slh_zero_page;
             stage_copy(src, sL + buf * (32 * 128) + (wave & 3) * 1024);
         }
-#ifdef SLH_GEMM_PROBE_W
-        probe_first_tile = false;
-#endif
     };
 
     f32x16 acc[MI][NI];
@@ -250,7 +217,7 @@ __global__ __launch_bounds__(128 * WM, gemm_waves_per_simd(MI, NI, STAGES, LORA,
             for (int i = 0; i < MI; ++i)
 #pragma unroll
                 for (int j = 0; j < NI; ++j)
-                    acc[i][j] = mfma_slot(wf[ks & 1][j], xf[ks & 1][i], acc[i][j], ks);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks & 1][j], xf[ks & 1][i], acc[i][j], 0, 0, 0);
             if (LORA && (ks & 1) == wn) {     // the two waves that share these rows split the adapter's K steps (see epilogue)
 #pragma unroll
                 for (int i = 0; i < MI; ++i)
@@ -260,25 +227,13 @@ __global__ __launch_bounds__(128 * WM, gemm_waves_per_simd(MI, NI, STAGES, LORA,
     };
 
     if constexpr (STAGES == 2) {
-#ifdef SLH_GEMM_PROBE          // ablation build (scripts/build_variant.sh <name> gemm.hip -DSLH_GEMM_PROBE): see GemmArgs.probe
-        if (!(p.probe & 8)) stage(0, kt_begin);
-#else
         stage(0, kt_begin);
-#endif
         ln_finish();
         for (int kt = 0; kt < nk; ++kt) {
             lds_dma_syncthreads();  // drains this wave's glds (explicit vmcnt(0)) and orders all waves
-#ifdef SLH_GEMM_PROBE
-            if (kt + 1 < nk && !(p.probe & 1)) stage((kt + 1) & 1, kt_begin + kt + 1);
-            if (!(p.probe & 2)) compute(kt & 1);
-#else
             if (kt + 1 < nk) stage((kt + 1) & 1, kt_begin + kt + 1);
             compute(kt & 1);
-#endif
         }
-#ifdef SLH_GEMM_PROBE
-        if (p.probe & 4) return;
-#endif
     } else {
         // ---- deep LDS ring (STAGES = 3 or 4 slots), for launches that leave ONE workgroup per CU -----------------
         // A CU with a single resident workgroup hides nothing behind other workgroups: with the 2-slot loop above
@@ -351,12 +306,6 @@ __global__ __launch_bounds__(128 * WM, gemm_waves_per_simd(MI, NI, STAGES, LORA,
         };
         // LDS-DMA piece j (order: X, W, LoRA) of K tile i_kt into ring slot `slot`
         auto piece = [&](const int j, const int slot) {
-#if defined(SLH_RING_PROBE) && (SLH_RING_PROBE & 1)
-            if (i_kt >= S - 1) return;                 // ablation: no LDS-DMA after the prologue
-#endif
-#ifdef SLH_GEMM_PROBE_W        // ablation build: probe bit 32 = no W pieces, bit 64 = no X pieces after the prologue
-            if (i_kt >= S - 1 && (((p.probe & 32) && j >= XI && j < XI + WI) || ((p.probe & 64) && j < XI))) return;
-#endif
             if (j < XI) {
                 glds16_hidden(xsrc[j], lds0 + slot * (BM * 128) + (wave + NW * j) * 1024);
                 xsrc[j] += xadv[j];
@@ -387,9 +336,6 @@ __global__ __launch_bounds__(128 * WM, gemm_waves_per_simd(MI, NI, STAGES, LORA,
 
         bf16x8 xf[2][MI], wf[2][NI], lf[2];
         auto load_frags = [&](const int set, const int slot, const int ks) {
-#if defined(SLH_RING_PROBE) && (SLH_RING_PROBE & 4)
-            return;                                    // ablation: no fragment reads
-#endif
             const char* cX = sX + slot * (BM * 128);
             const char* cW = sW + slot * (BN * 128);
             if (LORA && set == wn) lf[set] = *(const bf16x8*)(sL + slot * (32 * 128) + lds_off(lrow, ks * 2 + lhi));   // set == ks & 1
@@ -410,13 +356,8 @@ __global__ __launch_bounds__(128 * WM, gemm_waves_per_simd(MI, NI, STAGES, LORA,
             for (int i = 0; i < MI; ++i) {
 #pragma unroll
                 for (int j = 0; j < NI + (LORA ? 1 : 0); ++j) {
-#if defined(SLH_RING_PROBE) && (SLH_RING_PROBE & 2)
-                    if (j < NI) asm volatile("" ::"v"(wf[set][j]), "v"(xf[set][i]));      // ablation: no MFMA (fragments stay live)
-                    else asm volatile("" ::"v"(lf[set]), "v"(xf[set][i]));
-#else
-                    if (j < NI) acc[i][j] = mfma_slot(wf[set][j], xf[set][i], acc[i][j], set);
+                    if (j < NI) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[set][j], xf[set][i], acc[i][j], 0, 0, 0);
                     else if (set == wn) accl[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lf[set], xf[set][i], accl[i], 0, 0, 0);
-#endif
                     if (with_pieces) {
                         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -500,14 +441,18 @@ int launch_gemm3(const GemmArgs& a, int stages, hipStream_t s) {
     constexpr int stage_bytes = (32 * MI * WM + 64 * NI + (LORA ? 32 : 0)) * 128;
     constexpr bool can3 = 3 * stage_bytes <= 160 * 1024;
     constexpr bool can4 = 4 * stage_bytes <= 160 * 1024;
+#define SLH_LAUNCH_RING(ST_)                                                                                                  \
+    slh_launch<gemm_kernel<MI, NI, MODE, ST_, LORA, WM>>(grid, 128 * WM, s, a, "gemm_kernel<%d, %d, %d, %d, %s, %d, false>", MI, NI, \
+                                                         MODE, (int)(ST_), slh_tf(LORA), WM)
     if (stages == 4 && !can4) stages = 3;          // the deepest ring that fits the 160 KB of LDS
     if (stages == 3 && !can3) stages = 2;
     if (stages == 4)
-        hipLaunchKernelGGL((gemm_kernel<MI, NI, MODE, (can4 ? 4 : 2), LORA, WM>), dim3(grid), dim3(128 * WM), 0, s, a);
+        SLH_LAUNCH_RING((can4 ? 4 : 2));
     else if (stages == 3)
-        hipLaunchKernelGGL((gemm_kernel<MI, NI, MODE, (can3 ? 3 : 2), LORA, WM>), dim3(grid), dim3(128 * WM), 0, s, a);
+        SLH_LAUNCH_RING((can3 ? 3 : 2));
     else
-        hipLaunchKernelGGL((gemm_kernel<MI, NI, MODE, 2, LORA, WM>), dim3(grid), dim3(128 * WM), 0, s, a);
+        SLH_LAUNCH_RING(2);
+#undef SLH_LAUNCH_RING
     SLH_LAUNCH_CHECK("slh_gemm");
     return 0;
 }
@@ -516,7 +461,7 @@ int launch_gemm3(const GemmArgs& a, int stages, hipStream_t s) {
 // the double-buffered loop's 128 would spill the scores)
 int launch_gemm_xa(const GemmArgs& a, hipStream_t s) {
     const int grid = a.tiles_m * a.tiles_n + a.pf_blocks;
-    hipLaunchKernelGGL((gemm_kernel<1, 2, 0, 4, false, 4, true>), dim3(grid), dim3(512), 0, s, a);
+    slh_launch<gemm_kernel<1, 2, 0, 4, false, 4, true>>(grid, 512, s, a, "gemm_kernel<1, 2, 0, 4, false, 4, true>");
     SLH_LAUNCH_CHECK("slh_gemm (query projection + cross-attention)");
     return 0;
 }
@@ -591,6 +536,18 @@ static int pick_group_m(const slh_gemm_desc* d, int tiles_m) {
     return (tiles_m + G - 1) / G;
 }
 
+// the name of the kernel instantiation slh_gemm would launch for d, as rocprofv3 prints it ("gemm8pb_kernel<1, 5, 0, false>"): the
+// whole of slh_gemm runs - descriptor checks, tile choice, ring-depth fallback - with the launch itself replaced by a record of the
+// selected template (common.h: slh_launch).  No device needed, nothing launched.  0 / the descriptor's error.
+extern "C" int slh_gemm_kernel_name(const slh_gemm_desc* d, char* buf, int cap) {
+    SLH_CHECK(buf && cap >= 16, "slh_gemm_kernel_name: buffer");
+    slh_name_sink_set(buf, cap);
+    const int rc = slh_gemm(d, nullptr);
+    slh_name_sink_set(nullptr, 0);
+    if (rc == 0 && !buf[0]) { slh_set_error("slh_gemm_kernel_name: internal: no launch site recorded a name"); return -3; }
+    return rc;
+}
+
 // (MI<<8)|(NI<<4)|mode of the kernel instantiation slh_gemm would launch: gemm_kernel<MI, NI, mode>
 extern "C" int slh_gemm_variant(const slh_gemm_desc* d) {
     int MI, NI, WM;
@@ -608,6 +565,9 @@ extern "C" int slh_gemm(const slh_gemm_desc* d, slh_stream_t stream) {
     SLH_CHECK((d->a1 != nullptr) == (d->ca1 > 0), "slh_gemm: a1/ca1 mismatch");
     SLH_CHECK(d->lda0 % 8 == 0 && d->lda1 % 8 == 0 && d->ldw % 8 == 0 && d->ldc % 4 == 0,
               "slh_gemm: leading dimensions must keep 16-byte loads / 8-byte stores aligned");
+    SLH_CHECK(wt_span_ok(d->M, d->ldc, d->geglu == 2 ? 2 * d->N : d->geglu ? d->N / 2 : d->N),
+              "slh_gemm: the result tensor (M=%d rows of ldc=%d) reaches past 2 GiB from its base: the write-through row stores address it "
+              "with 32-bit offsets - split the batch", d->M, d->ldc);
     const int cin = d->ca0 + d->ca1;
     if (d->mode == 0) {
         SLH_CHECK(cin == d->K, "slh_gemm: dense K=%d != ca0+ca1=%d", d->K, cin);
@@ -710,11 +670,6 @@ extern "C" int slh_gemm(const slh_gemm_desc* d, slh_stream_t stream) {
         SLH_CHECK(((uintptr_t)d->ln_in & 7) == 0 && ((uintptr_t)d->ln_s & 15) == 0 && ((uintptr_t)d->ln_b & 15) == 0,
                   "slh_gemm: ln_in / ln_s / ln_b alignment");
     }
-#ifdef SLH_GEMM_PROBE
-    a.probe = d->reserved_;      // ablation builds only; the default library ignores the field (it is reserved)
-#else
-    a.probe = 0;
-#endif
     a.splitk = (d->tile >> 16) & 15;
     a.c32 = d->splitk_c32;
     a.t32 = d->splitk_t32;

@@ -349,14 +349,14 @@ int slh_gemm5_launch(const slh_gemm_desc* d, slh_stream_t stream) {
     a.group_m = g5_group_m(a.tiles_m, a.tiles_n);
     static const int skew_knob = getenv("SLH_G5_SKEW") ? atoi(getenv("SLH_G5_SKEW")) : 1;      // A/B: 0 = every sibling walks its panels in the same order
     a.skew = skew_knob;
-    const dim3 grid(a.tiles_m * a.tiles_n);
+    const int grid = a.tiles_m * a.tiles_n;
     const hipStream_t st = (hipStream_t)stream;
     if (((d->tile >> 8) & 15) == 5) {      // 5 ring slots
-        if (d->lora_down) hipLaunchKernelGGL((gemm5_kernel<true, 5>), grid, dim3(256), 0, st, a);
-        else hipLaunchKernelGGL((gemm5_kernel<false, 5>), grid, dim3(256), 0, st, a);
+        if (d->lora_down) slh_launch<gemm5_kernel<true, 5>>(grid, 256, st, a, "gemm5_kernel<true, 5>");
+        else slh_launch<gemm5_kernel<false, 5>>(grid, 256, st, a, "gemm5_kernel<false, 5>");
     } else {
-        if (d->lora_down) hipLaunchKernelGGL((gemm5_kernel<true, 4>), grid, dim3(256), 0, st, a);
-        else hipLaunchKernelGGL((gemm5_kernel<false, 4>), grid, dim3(256), 0, st, a);
+        if (d->lora_down) slh_launch<gemm5_kernel<true, 4>>(grid, 256, st, a, "gemm5_kernel<true, 4>");
+        else slh_launch<gemm5_kernel<false, 4>>(grid, 256, st, a, "gemm5_kernel<false, 4>");
     }
     SLH_LAUNCH_CHECK("slh_gemm (64 x 160 tile)");
     return 0;

@@ -645,13 +645,13 @@ int launch_gemm8p(const GemmArgs& a, int mode, int ni_b, hipStream_t s) {
     const int grid = a.tiles_m * a.tiles_n * (a.splitk > 1 ? a.splitk : 1);
 #define SLH_LAUNCH_B(NI_)                                                                                           \
     if (a.lora_down) {                                                                                              \
-        if (mode == 0) hipLaunchKernelGGL((gemm8pb_kernel<1, NI_, 0, true>), dim3(grid), dim3(512), 0, s, a);       \
-        else hipLaunchKernelGGL((gemm8pb_kernel<1, NI_, 1, true>), dim3(grid), dim3(512), 0, s, a);                 \
-    } else if (mode == 0) hipLaunchKernelGGL((gemm8pb_kernel<1, NI_, 0, false>), dim3(grid), dim3(512), 0, s, a);   \
-    else hipLaunchKernelGGL((gemm8pb_kernel<1, NI_, 1, false>), dim3(grid), dim3(512), 0, s, a)
+        if (mode == 0) slh_launch<gemm8pb_kernel<1, NI_, 0, true>>(grid, 512, s, a, "gemm8pb_kernel<1, %d, 0, true>", NI_);       \
+        else slh_launch<gemm8pb_kernel<1, NI_, 1, true>>(grid, 512, s, a, "gemm8pb_kernel<1, %d, 1, true>", NI_);                 \
+    } else if (mode == 0) slh_launch<gemm8pb_kernel<1, NI_, 0, false>>(grid, 512, s, a, "gemm8pb_kernel<1, %d, 0, false>", NI_);   \
+    else slh_launch<gemm8pb_kernel<1, NI_, 1, false>>(grid, 512, s, a, "gemm8pb_kernel<1, %d, 1, false>", NI_)
     if (ni_b == 0) {
-        if (mode == 0) hipLaunchKernelGGL((gemm8p_kernel<0, false>), dim3(grid), dim3(512), 0, s, a);
-        else hipLaunchKernelGGL((gemm8p_kernel<1, false>), dim3(grid), dim3(512), 0, s, a);
+        if (mode == 0) slh_launch<gemm8p_kernel<0, false>>(grid, 512, s, a, "gemm8p_kernel<0, false>");
+        else slh_launch<gemm8p_kernel<1, false>>(grid, 512, s, a, "gemm8p_kernel<1, false>");
     } else if (ni_b == 3) { SLH_LAUNCH_B(3); }
     else if (ni_b == 4) { SLH_LAUNCH_B(4); }
     else { SLH_LAUNCH_B(5); }

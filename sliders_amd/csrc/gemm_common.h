@@ -37,8 +37,6 @@ struct GemmArgs {
     const __bf16* xa_k; const __bf16* xa_vt; int xa_tk, xa_tq, xa_ldk, xa_ldvt, xa_vt_heads; float xa_scale;
     const float* ln_lora_s; const float* ln_lora_c;   // LayerNorm fold of the fused adapter's down-projection (slh_gemm_desc.ln_lora_*)
     const void* pf_ptr; long pf_bytes; int pf_blocks;   // weight touch by the launch's last pf_blocks workgroups (slh_gemm_desc.pf_*)
-    int probe;   // ablation builds only (-DSLH_GEMM_PROBE, scripts/build_variant.sh): 1 skip tile refills, 2 skip MFMA work,
-                 // 4 skip the epilogue, 8 skip the first tile fill, 16 return at once; the default build ignores it
 };
 
 constexpr int BK = 64;
@@ -439,14 +437,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, char* smem, f32
                         const float av = round_bf16(a[e]), gv = round_bf16(g[e]);   // the reference rounds proj(x) to bf16 before chunk / gelu
                         o[e] = (__bf16)(av * round_bf16(gelu_erf_fast_f(gv)));
                     }
-#ifdef SLH_GEGLU_STORE8
-                    if (m < p.M) *(bf16x4*)(p.c + (long)m * p.ldc + (nb >> 1) + q * 8 + lhi * 4) = o;
-#else
                     *(bf16x4*)(sG + lrow * GROW + j * 32 + q * 16 + lhi * 8) = o;
-#endif
                 }
             }
-#ifndef SLH_GEGLU_STORE8
             __builtin_amdgcn_wave_barrier();       // same-wave LDS ops retire in order; only the compiler must not reorder
 #pragma unroll
             for (int it = 0; it < SG / 2; ++it) {
@@ -466,7 +459,6 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, char* smem, f32
                 }
             }
             __builtin_amdgcn_wave_barrier();
-#endif
         }
         return;
     }

@@ -673,6 +673,7 @@ extern "C" int slh_gn_fused(const slh_gn_desc* d, slh_stream_t stream) {
     SLH_CHECK(d && d->x0 && d->stats && d->y && d->gamma && d->beta, "slh_gn_fused: null pointer");
     if (gn_check("slh_gn_fused", d->c0, d->c1, d->groups, d->ldx0, d->ldx1, d->x1)) return -1;
     SLH_CHECK(d->ldy % 8 == 0, "slh_gn_fused: ldy");
+    SLH_CHECK(wt_span_ok((long)d->batch * d->hw, d->ldy, d->c0 + d->c1), "slh_gn_fused: y reaches past 2 GiB from its base (32-bit store offsets)");
     const GnFusedGeom g = gn_fused_geom(d->c0 + d->c1, d->hw, d->groups);
     if (!g.ok) {
         const GnOneGeom o = gn_one_geom(d->c0, d->c1, d->hw, d->groups);
@@ -705,6 +706,7 @@ extern "C" int slh_gn_apply(const slh_gn_desc* d, slh_stream_t stream) {
     SLH_CHECK(d->y != d->x0 && (!d->x1 || d->y != d->x1), "slh_gn_apply: y must not alias x0 / x1 (the statistics' pivot is re-read from x)");
     if (gn_check("slh_gn_apply", d->c0, d->c1, d->groups, d->ldx0, d->ldx1, d->x1)) return -1;
     SLH_CHECK(d->ldy % 8 == 0, "slh_gn_apply: ldy");
+    SLH_CHECK(wt_span_ok((long)d->batch * d->hw, d->ldy, d->c0 + d->c1), "slh_gn_apply: y reaches past 2 GiB from its base (32-bit store offsets)");
     const GnGeom g = gn_geom(d->c0, d->c1, d->hw, d->groups);
     hipLaunchKernelGGL(gn_apply_kernel, dim3(g.row_blocks, d->batch), dim3(g.threads), 0, (hipStream_t)stream, *d,
                        g.nchunk, g.rpi, g.rows_per_block, g.cg, g.lpg, g.row_blocks);
@@ -737,6 +739,7 @@ extern "C" int slh_gn_bwd_apply(const slh_gn_bwd_desc* d, slh_stream_t stream) {
 extern "C" int slh_layernorm(const slh_ln_desc* d, slh_stream_t stream) {
     SLH_CHECK(d && d->x && d->y && d->gamma && d->beta, "slh_layernorm: null pointer");
     SLH_CHECK(d->C % 8 == 0 && d->C <= 1536 && d->ldx % 8 == 0 && d->ldy % 8 == 0, "slh_layernorm: C=%d unsupported", d->C);
+    SLH_CHECK(wt_span_ok(d->M, d->ldy, d->C), "slh_layernorm: y reaches past 2 GiB from its base (32-bit store offsets)");
     hipLaunchKernelGGL(layernorm_kernel, dim3((d->M + 3) / 4), dim3(256), 0, (hipStream_t)stream, *d);
     SLH_LAUNCH_CHECK("slh_layernorm");
     return 0;

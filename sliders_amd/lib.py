@@ -141,7 +141,7 @@ _ENTRY = {
 }
 
 EXPORTS = ["slh_version", "slh_last_error", "slh_run_program", "slh_desc_sizes", "slh_graph_capture", "slh_graph_launch",
-           "slh_graph_destroy", "slh_gemm_variant", "slh_gemm5_ok", "slh_gn_row_blocks", "slh_gn_clusters", "slh_gn32_row_blocks",
+           "slh_graph_destroy", "slh_gemm_variant", "slh_gemm_kernel_name", "slh_gemm5_ok", "slh_gn_row_blocks", "slh_gn_clusters", "slh_gn32_row_blocks",
            "slh_lora_wgrad_blocks", "slh_lora_wgrad_single_blocks", "slh_transpose_heads_blocks", "slh_gn_fused_ok"] + [v[0] for v in _ENTRY.values()]
 
 
@@ -280,6 +280,20 @@ def gemm_variant(desc) -> int:
     lib.slh_gemm_variant.argtypes = [C.POINTER(GemmDesc)]
     lib.slh_gemm_variant.restype = c_i32
     return lib.slh_gemm_variant(C.byref(desc))
+
+
+def gemm_kernel_name(desc) -> str:
+    """slh_gemm_kernel_name: the kernel instantiation slh_gemm would launch for this descriptor, spelled as rocprofv3 prints it
+    (e.g. 'gemm8pb_kernel<1, 5, 0, false>').  The library runs its whole dispatch with the launch replaced by a record of the template
+    it selected, so a new tile can never be mis-named here; raises (with the library's message) for a descriptor slh_gemm refuses."""
+    lib = load()
+    lib.slh_gemm_kernel_name.argtypes = [C.POINTER(GemmDesc), C.c_char_p, c_i32]
+    lib.slh_gemm_kernel_name.restype = c_i32
+    buf = C.create_string_buffer(160)
+    rc = lib.slh_gemm_kernel_name(C.byref(desc), buf, 160)
+    if rc != 0:
+        raise SlidersHipError(f"slh_gemm_kernel_name failed ({rc}): {lib.slh_last_error().decode()}")
+    return buf.value.decode()
 
 
 def call(opcode: int, desc, stream: int):

@@ -24,7 +24,7 @@ from . import lib
 from .arena import Arena, Buf
 from .config import UNetConfig
 from .lora_store import LoraEntry, LoraStore
-from .tuning import tuned_tile
+from .tuning import settle_tile, tuned_tile
 from .weights import WeightStore
 
 
@@ -420,6 +420,7 @@ class UNetPlan:
                 d.vt_out, d.vt_col0, d.vt_D, d.vt_heads, d.vt_tokens, d.vt_ld = vt.ptr, 2 * Cq, Dh, vt_heads, Tk, Tk
                 d.vt_also_c = 1 if self.train else 0      # the backward reads V row-major
                 self.last_vt = (vt.ptr, 0)
+        settle_tile(d)
         self.prog.add(lib.OP_GEMM, d, name)
         if self.train:
             self.tape.append(dict(op="gemm", x=tape_x if tape_x is not None else x,
@@ -1115,6 +1116,7 @@ class BackwardPlan:
                                  ldc=gp.ld, rows_per_sample=Ho * Wo, w_layout=1 if self.w.packed else 0)
                 self._splitk(d, name)
                 d.geglu, d.geglu_pre, d.ld_pre = 2, ps.ptr, ps.ld
+                settle_tile(d)
                 self.prog.add(lib.OP_GEMM, d, name + ".dgrad")
                 return
             if x1 is None:
@@ -1145,6 +1147,7 @@ class BackwardPlan:
                     d.vt_out, d.vt_col0, d.vt_D, d.vt_heads, d.vt_tokens, d.vt_ld = dot.ptr, 0, Dh, heads, Tq, Tq
                     d.vt_also_c = 1
                     self._dot_made[x0.buf.ptr] = (dot, Tq)
+            settle_tile(d)
             self.prog.add(lib.OP_GEMM, d, name + ".dgrad")
             for dA, nm in dA_after:
                 self._wgrad(dA, nm, defer=True)
@@ -1168,6 +1171,7 @@ class BackwardPlan:
                              ldw=9 * N, M=self.nb * HL * WL, N=cin, K=9 * N, ld_res=tgt.ld, ldc=tgt.ld,
                              rows_per_sample=HL * WL, w_layout=1 if self.w.packed else 0)
             self._splitk(d, name)
+            settle_tile(d)
             self.prog.add(lib.OP_GEMM, d, name + ".dgrad")
             if grp is not None:
                 d2 = lib.LoraCdgradDesc(u=U.ptr, a_down=self.lora.down_ptr(grp[0]), scale=self.scale_ptr, gx=tgt.ptr,

@@ -68,6 +68,17 @@ def tile_ok(d, tile: int) -> bool:
     return True
 
 
+def settle_tile(d) -> int:
+    """Last check before a GEMM descriptor is recorded: the table lookup (tuned_tile) happens while the descriptor is still being
+    filled in - the planner attaches V^T / dO^T stores, the GEGLU backward and training outputs AFTER it knows the tile - so an entry
+    of the 64 x 160 family (which names a shape, not a feature set) can end up on a launch that tile has no epilogue for.  Such a
+    launch goes back to the 128 x 128 ring tile the entry replaced (or to the library heuristic).  Returns the tile that will run."""
+    t = d.tile
+    if t and (t >> 12) & 15 == 5 and not tile_ok(d, t):
+        d.tile = 0x4412 if tile_ok(d, 0x4412) else 0
+    return d.tile
+
+
 def table() -> Dict[str, int]:
     global _TABLE
     if _TABLE is None:
