@@ -476,6 +476,7 @@ int launch_gemm(const GemmArgs& a, int mode, int stages, hipStream_t s) {
 }  // namespace
 
 int slh_gemm5_launch(const slh_gemm_desc* d, slh_stream_t stream);      // gemm5.hip
+int slh_gemm7_launch(const slh_gemm_desc* d, slh_stream_t stream);      // gemm7.hip
 
 static int slh_ncu() {
     static const int ncu = [] {
@@ -611,6 +612,7 @@ extern "C" int slh_gemm(const slh_gemm_desc* d, slh_stream_t stream) {
                   "slh_gemm: geglu = 3 (16 | 16 weight blocks) needs N %% 32 == 0 and excludes adapters, residual, row bias, geglu_pre, vt_out, ln_out");
     SLH_CHECK(d->geglu >= 0 && d->geglu <= 3, "slh_gemm: geglu is 0, 1 / 3 (forward epilogue, 32 | 32 or 16 | 16 weight blocks) or 2 (backward form)");
 
+    if (((d->tile >> 12) & 15) == 7) return slh_gemm7_launch(d, stream);      // the four-wave tiles (gemm7.hip): their own descriptor checks
     if (((d->tile >> 12) & 15) == 5) return slh_gemm5_launch(d, stream);      // the 64 x 160 tile (gemm5.hip): its own descriptor checks
     int MI = 2, NI = 2, WM = 2;
     pick_tile(d, MI, NI, WM);

@@ -141,7 +141,7 @@ _ENTRY = {
 }
 
 EXPORTS = ["slh_version", "slh_last_error", "slh_run_program", "slh_desc_sizes", "slh_graph_capture", "slh_graph_launch",
-           "slh_graph_destroy", "slh_gemm_variant", "slh_gemm_kernel_name", "slh_gemm5_ok", "slh_gn_row_blocks", "slh_gn_clusters", "slh_gn32_row_blocks",
+           "slh_graph_destroy", "slh_gemm_variant", "slh_gemm_kernel_name", "slh_gemm5_ok", "slh_gemm7_ok", "slh_gn_row_blocks", "slh_gn_clusters", "slh_gn32_row_blocks",
            "slh_lora_wgrad_blocks", "slh_lora_wgrad_single_blocks", "slh_transpose_heads_blocks", "slh_gn_fused_ok"] + [v[0] for v in _ENTRY.values()]
 
 
@@ -272,6 +272,19 @@ def wgrad_single_blocks(desc) -> int:
     if nb <= 0:
         raise SlidersHipError(f"slh_lora_wgrad_single_blocks: {last_error()}")
     return nb
+
+
+TILE_128x256 = 0x7648     # four-wave tiles of csrc/gemm7.hip (bits 12-15 = 7; ring slots | X blocks | W blocks of 16 rows per wave)
+TILE_128x320 = 0x754A
+TILE_128x160 = 0x7645
+
+
+def gemm7_ok(desc) -> bool:
+    """slh_gemm7_ok: the four-wave tile named by desc.tile (0x7648 / 0x754a / 0x7645) can run this descriptor"""
+    lib = load()
+    lib.slh_gemm7_ok.argtypes = [C.POINTER(GemmDesc)]
+    lib.slh_gemm7_ok.restype = c_i32
+    return bool(lib.slh_gemm7_ok(C.byref(desc)))
 
 
 def gemm_variant(desc) -> int:

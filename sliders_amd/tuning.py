@@ -34,6 +34,13 @@ def tile_ok(d, tile: int) -> bool:
         return tile == 0x4412
     if tile >> 20:                                # bits 20+ are reserved (round 4's stream-K form lived there; removed)
         return False
+    if wm == 7:                                   # the four-wave tiles (csrc/gemm7.hip): the library's own rule, asked with this tile code
+        from . import lib
+        keep, d.tile = d.tile, tile
+        try:
+            return lib.gemm7_ok(d)
+        finally:
+            d.tile = keep
     if wm == 5:                                   # the 64 x 160 tile (csrc/gemm5.hip): the library's own rule
         from . import lib
         return not (tile >> 16) & 15 and lib.gemm5_ok(d)
@@ -74,7 +81,7 @@ def settle_tile(d) -> int:
     of the 64 x 160 family (which names a shape, not a feature set) can end up on a launch that tile has no epilogue for.  Such a
     launch goes back to the 128 x 128 ring tile the entry replaced (or to the library heuristic).  Returns the tile that will run."""
     t = d.tile
-    if t and (t >> 12) & 15 == 5 and not tile_ok(d, t):
+    if t and (t >> 12) & 15 in (5, 7) and not tile_ok(d, t):
         d.tile = 0x4412 if tile_ok(d, 0x4412) else 0
     return d.tile
 
@@ -109,7 +116,7 @@ def tuned_tile(d) -> int:
     if t and not tile_ok(d, t):
         # an entry for the 64 x 160 tile names a shape, not a feature set (the key does not see row bias, V^T stores, training outputs):
         # where the launch needs more than that tile's epilogue offers, the 128 x 128 ring tile it replaced runs
-        t = 0x4412 if (t >> 12) & 15 == 5 and tile_ok(d, 0x4412) else 0
+        t = 0x4412 if (t >> 12) & 15 in (5, 7) and tile_ok(d, 0x4412) else 0
     force = os.environ.get("SLIDERS_FORCE_STAGES")     # experiment knob: 2 or 3 for every non-128x128 tile
     if force and t and (t & 0xFF) != 0x22:
         t = (t & 0xFF) | (int(force) << 8 if force == "3" else 0)
