@@ -55,7 +55,7 @@ __device__ __forceinline__ int g7_key(const int q) { return (0x78 >> (2 * q)) & 
 constexpr int G7_LNC = 6;      // chunk pairs a lane requests per row: chunk 0 (the shift) + its quarter of up to 20 chunks
 
 template <int XB, int WB, int S, bool LORA>
-__global__ __launch_bounds__(256) void gemm7_kernel(const G7Args p) {
+__global__ __launch_bounds__(512) void gemm7_kernel(const G7Args p) {
     static_assert(XB % 2 == 0 && WB >= 4 && S >= 4, "tile");
     constexpr int BM = 32 * XB, BN = 32 * WB;
     constexpr int WROWS = BN + (LORA ? 16 : 0);
@@ -85,73 +85,130 @@ __global__ __launch_bounds__(256) void gemm7_kernel(const G7Args p) {
     const int m0 = tile_m * BM, n0 = tile_n * BN;
     const int nk = p.K >> 5;                   // half tiles
 
-    // ---- fill geometry: one LDS-DMA instruction = 16 rows x 64 B; lane -> (row = lane / 4, physical slot = lane % 4)
-    const int frow = lane >> 2, fps = lane & 3;
-    const int fsl = fps ^ g7_key(frow >> 2);   // the logical 16-byte slot (k = 8 * fsl .. + 7 of the half tile) this lane fetches
-    const char* xsrc[NXP];
-    const char* wsrc[NWP + 1];
-#pragma unroll
-    for (int i = 0; i < NXP; ++i) {
-        const int row = (wave + 4 * i) * 16 + frow;
-        xsrc[i] = (const char*)(p.a + (long)(m0 + row) * p.lda + (fsl << 3));
-    }
-#pragma unroll
-    for (int i = 0; i < NWP + 1; ++i) {
-        int pc = wave + 4 * i;
-        pc = pc < 2 * WB ? pc : 2 * WB - 1;      // (the slot past the end belongs to waves < WREM only; the others never issue it)
-        const int n = n0 + pc * 16 + frow;
-        wsrc[i] = (const char*)(p.w + ((long)(n >> 6) * (p.K >> 6)) * 4096 + ((n & 63) << 6) + ((fsl ^ ((n >> 1) & 7)) << 3));
-    }
-    // second half of a packed 128-byte row: 64 bytes up or down, by bit 2 of the row's key = bit 3 of the row (tiles start at multiples of 16)
-    const int wd = (frow & 8) ? -64 : 64;
-    const bool extra = (wave < WREM) || (LORA && wave == 3);      // wave-uniform: one piece more per half tile
-    const char* lsrc = (const char*)slh_zero_page;
-    int ladv = 0;
-    if (LORA && frow < p.lora_rank) {
-        lsrc = (const char*)(p.lora_down + (long)frow * p.K + (fsl << 3));
-        ladv = 64;
-    }
-    const unsigned lds0 = lds_addr_of(smem);
-    // piece j of the half tile being staged into ring slot `slot`; PAR = parity of that half tile (decides the W step)
-    auto piece = [&](const int j, const int slot, auto par_c) {
-        constexpr int PAR = decltype(par_c)::value;
-        if (j < NXP) {
-            glds16_hidden(xsrc[j], lds0 + slot * SLOT + (wave + 4 * j) * 1024);
-            xsrc[j] += 64;
-        } else if (j < L) {
-            const int i = j - NXP;
-            glds16_hidden(wsrc[i], lds0 + slot * SLOT + XBYTES + (wave + 4 * i) * 1024);
-            wsrc[i] += PAR ? 8192 - wd : wd;
-        } else if (LORA && wave == 3) {
-            glds16_hidden(lsrc, lds0 + slot * SLOT + XBYTES + BN * 64);
-            lsrc += ladv;
-        } else {
-            glds16_hidden(wsrc[NWP], lds0 + slot * SLOT + XBYTES + (wave + 4 * NWP) * 1024);
-            wsrc[NWP] += PAR ? 8192 - wd : wd;
-        }
-    };
-    auto wait_keep = [&](auto keep_c) {      // my pieces of all but the last KEEP half tiles have landed
-        constexpr int KEEP = decltype(keep_c)::value;
-        if (extra) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(KEEP * (L + 1)) : "memory");
-        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(KEEP * L) : "memory");
-    };
-
-    // ---- folded LayerNorm, consumer side: the chunk pairs of this lane's rows are requested AHEAD of the prologue's LDS-DMA (older in
-    // the in-order vmcnt queue: the prologue's counted wait retires them); the four lanes of a row split the chunks
-    const bool ln_on = p.ln_in != nullptr;
-    f32x2 lnp[XB][G7_LNC];
     const int r16 = lane & 15, g4 = lane >> 4;
+    const bool ln_on = p.ln_in != nullptr;
+    using P0 = std::integral_constant<int, 0>;
+    using P1 = std::integral_constant<int, 1>;
+
+    if (wave >= 4) {
+        // ================= loader waves: nothing but the LDS-DMA stream of the ring =================================================
+        // One LDS-DMA instruction = 16 rows x 64 B; lane -> (row = lane / 4, physical slot = lane % 4).  Loader lw = wave - 4 takes the
+        // pieces lw, lw + 4, ... of every half tile: NXP of the X rows, NWP (+ 1 for lw < WREM) of the W rows, loader 3 the adapter's 16 rows.
+        const int lw = wave - 4;
+        const int frow = lane >> 2, fps = lane & 3;
+        const int fsl = fps ^ g7_key(frow >> 2);   // the logical 16-byte slot (k = 8 * fsl .. + 7 of the half tile) this lane fetches
+        const char* xsrc[NXP];
+        const char* wsrc[NWP + 1];
+#pragma unroll
+        for (int i = 0; i < NXP; ++i) {
+            const int row = (lw + 4 * i) * 16 + frow;
+            xsrc[i] = (const char*)(p.a + (long)(m0 + row) * p.lda + (fsl << 3));
+        }
+#pragma unroll
+        for (int i = 0; i < NWP + 1; ++i) {
+            int pc = lw + 4 * i;
+            pc = pc < 2 * WB ? pc : 2 * WB - 1;      // (the slot past the end belongs to loaders < WREM only; the others never issue it)
+            const int n = n0 + pc * 16 + frow;
+            wsrc[i] = (const char*)(p.w + ((long)(n >> 6) * (p.K >> 6)) * 4096 + ((n & 63) << 6) + ((fsl ^ ((n >> 1) & 7)) << 3));
+        }
+        // second half of a packed 128-byte row: 64 bytes up or down, by bit 2 of the row's key = bit 3 of the row (tiles start at
+        // multiples of 16); from the second half to the first half of the next 64-deep block: 8192 minus that
+        const int wd = (frow & 8) ? -64 : 64;
+        const bool extra = (lw < WREM) || (LORA && lw == 3);      // wave-uniform: one piece more per half tile
+        const char* lsrc = (const char*)slh_zero_page;
+        int ladv = 0;
+        if (LORA && frow < p.lora_rank) {
+            lsrc = (const char*)(p.lora_down + (long)frow * p.K + (fsl << 3));
+            ladv = 64;
+        }
+        const unsigned lds0 = lds_addr_of(smem);
+        auto stage = [&](const int t) {              // all of this loader's pieces of half tile t, into ring slot t % S
+            const unsigned base = lds0 + (t % S) * SLOT;
+            const int wstep = (t & 1) ? 8192 - wd : wd;
+#pragma unroll
+            for (int j = 0; j < NXP; ++j) {
+                glds16_hidden(xsrc[j], base + (lw + 4 * j) * 1024);
+                xsrc[j] += 64;
+            }
+#pragma unroll
+            for (int i = 0; i < NWP; ++i) {
+                glds16_hidden(wsrc[i], base + XBYTES + (lw + 4 * i) * 1024);
+                wsrc[i] += wstep;
+            }
+            if (LORA && lw == 3) {
+                glds16_hidden(lsrc, base + XBYTES + BN * 64);
+                lsrc += ladv;
+            } else if (extra) {
+                glds16_hidden(wsrc[NWP], base + XBYTES + (lw + 4 * NWP) * 1024);
+                wsrc[NWP] += wstep;
+            }
+        };
+        auto wait_keep = [&](auto keep_c) {      // this loader's pieces of all but the last KEEP half tiles have landed
+            constexpr int KEEP = decltype(keep_c)::value;
+            if (extra) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(KEEP * (L + 1)) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(KEEP * L) : "memory");
+        };
+        // prologue: half tiles 0 .. S-2 requested; barrier P = tile 0 has landed
+        for (int t = 0; t < S - 1; ++t) stage(t);
+        wait_keep(std::integral_constant<int, S - 2>{});
+        __builtin_amdgcn_s_barrier();
+        // barrier B_g (g = 0 .. nk-2) = half tile g+1 has landed.  A compute wave requests its fragments of tile t between B_(t-1) and
+        // B_t and has certainly received them when it arrives at B_(t+1) (its MFMAs of tile t consumed them): behind B_(g-1) the slot of
+        // tile g-2 is free and takes tile g+S-2 - S-3 half tiles stay in flight across every barrier, and no compute wave ever waits
+        // on LDS for the ring's sake.
+        int g = 0;
+        if (S - 1 < nk) { wait_keep(std::integral_constant<int, S - 3>{}); __builtin_amdgcn_s_barrier(); g = 1; }      // B_0: nothing to refill yet
+        for (; g + S - 2 < nk; ++g) {
+            stage(g + S - 2);
+            wait_keep(std::integral_constant<int, S - 3>{});
+            __builtin_amdgcn_s_barrier();
+        }
+        // the last S-3 barriers: nothing left to request; tile g+1 must have landed, the nk-2-g behind it stay in flight
+        auto tail = [&](auto k_c, auto&& self) {
+            constexpr int KK = decltype(k_c)::value;
+            if constexpr (KK >= 0) {
+                wait_keep(k_c);
+                __builtin_amdgcn_s_barrier();
+                self(std::integral_constant<int, KK - 1>{}, self);
+            }
+        };
+        tail(std::integral_constant<int, S - 4>{}, tail);
+        __syncthreads();                             // the epilogue's barriers, arrived at and left
+        if (LORA) __syncthreads();
+        return;
+    }
+
+    // ================= compute waves: fragment reads + MFMAs, no vector-memory instruction inside the loop ============================
+    // folded LayerNorm, consumer side: the four lanes of a row split its chunk pairs (ordinary loads: this wave's vmcnt is its own)
+    float ln_mean[XB], ln_rstd[XB];
     if (ln_on) {
+        const float nc = (float)(p.K / p.ln_in_chunks), inv_chunks = 1.f / (float)p.ln_in_chunks;
 #pragma unroll
         for (int i = 0; i < XB; ++i) {
             const int m = m0 + (wm * XB + i) * 16 + r16;
             const f32x2* src = (const f32x2*)p.ln_in + m;        // chunk-major [chunks][M]
+            f32x2 lnp[G7_LNC];
 #pragma unroll
             for (int c = 0; c < G7_LNC; ++c) {
                 const int ch = c == 0 ? 0 : g4 + 4 * (c - 1);
-                const f32x2* q = src + (long)(ch < p.ln_in_chunks ? ch : 0) * p.M;
-                asm volatile("global_load_dwordx2 %0, %1, off" : "=&v"(lnp[i][c]) : "v"(q) : "memory");
+                lnp[c] = src[(long)(ch < p.ln_in_chunks ? ch : 0) * p.M];
             }
+            // equal-sized chunks merged with the chunk means shifted by the first one (gemm_common.h: gemm_ln_finish): every lane its
+            // quarter of the chunks, the quarters added across the row's four lanes in a fixed order
+            const float m0v = lnp[0][0];
+            float sm = 0.f, pq = 0.f, q = 0.f;
+#pragma unroll
+            for (int c = 1; c < G7_LNC; ++c) {
+                const int ch = g4 + 4 * (c - 1);
+                if (ch < p.ln_in_chunks) { const float dl = lnp[c][0] - m0v; sm += dl; pq += dl * dl; q += lnp[c][1]; }
+            }
+            sm += __shfl_xor(sm, 16, 64); pq += __shfl_xor(pq, 16, 64); q += __shfl_xor(q, 16, 64);
+            sm += __shfl_xor(sm, 32, 64); pq += __shfl_xor(pq, 32, 64); q += __shfl_xor(q, 32, 64);
+            const float dm = sm * inv_chunks;
+            ln_mean[i] = m0v + dm;
+            const float M2 = q + nc * fmaxf(pq - sm * dm, 0.f);
+            ln_rstd[i] = 1.0f / sqrtf(M2 / (float)p.K + p.ln_eps);
+            if (p.ln_mr_out && tile_n == 0 && wn == 0 && g4 == 0) *(f32x2*)(p.ln_mr_out + (long)m * 2) = f32x2{ln_mean[i], ln_rstd[i]};
         }
     }
 
@@ -169,140 +226,66 @@ __global__ __launch_bounds__(256) void gemm7_kernel(const G7Args p) {
     // fragments: lane (g4, r16) holds row r16 of a 16-row block, k = 8 g4 .. + 7 of the half tile (16 bytes)
     const int foff = r16 * 64 + ((g4 ^ g7_key(r16 >> 2)) << 4);
     const int fx = foff + wm * (XB * 1024), fw = foff + XBYTES + wn * (WB * 1024), fl = foff + XBYTES + BN * 64;
-    bf16x8 xf[2][XB], wf[2][WB], lf[2];
-    auto load_frags = [&](auto set_c, const int slot) {
-        constexpr int SET = decltype(set_c)::value;
-        const char* b = smem + slot * SLOT;
-#pragma unroll
-        for (int i = 0; i < XB; ++i) xf[SET][i] = *(const bf16x8*)(b + fx + i * 1024);
-#pragma unroll
-        for (int j = 0; j < WB; ++j) wf[SET][j] = *(const bf16x8*)(b + fw + j * 1024);
-        if (LORA) lf[SET] = *(const bf16x8*)(b + fl);
-    };
-    // MFMAs of W blocks [J0, J1) (W rows feed the A operand: a lane ends up with 4 consecutive output columns of one row); ISSUE: the
-    // pieces of the half tile being staged are dealt out one behind each of the first MFMAs
-    auto mfmas = [&](auto set_c, auto j0_c, auto j1_c, auto issue_c, auto par_c, const int slot) {
-        constexpr int SET = decltype(set_c)::value, J0 = decltype(j0_c)::value, J1 = decltype(j1_c)::value;
-        constexpr bool ISSUE = decltype(issue_c)::value;
-        int m = 0;
-#pragma unroll
-        for (int j = J0; j < J1; ++j) {
-#pragma unroll
-            for (int i = 0; i < XB; ++i) {
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[SET][j], xf[SET][i], acc[i][j], 0, 0, 0);
-                if (ISSUE && m < L) {
-                    __builtin_amdgcn_sched_barrier(0);
-                    piece(m, slot, par_c);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-                ++m;
-            }
-        }
-        if (ISSUE) {
-            if (extra) piece(L, slot, par_c);
-        }
-        if (LORA && J0 == 0) {
-#pragma unroll
-            for (int ii = 0; ii < XB / 2; ++ii) {
-                const bf16x8 xs = wn ? xf[SET][2 * ii + 1] : xf[SET][2 * ii];      // both named, the scalar wn selects
-                accl[ii] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lf[SET], xs, accl[ii], 0, 0, 0);
-            }
-        }
-    };
-
-    using T_ = std::true_type;
-    using F_ = std::false_type;
-    using P0 = std::integral_constant<int, 0>;
-    using P1 = std::integral_constant<int, 1>;
-    // ---- prologue: half tiles 0 .. S-2 in flight, tile 0 landed, its fragments requested
-    {
-        auto stage = [&](const int t, auto par_c) {
-#pragma unroll
-            for (int j = 0; j < L; ++j) piece(j, t, par_c);
-            if (extra) piece(L, t, par_c);
-        };
-#pragma unroll
-        for (int t = 0; t < S - 1; ++t) {
-            if (t & 1) stage(t, P1{});
-            else stage(t, P0{});
-        }
-    }
-    wait_keep(std::integral_constant<int, S - 2>{});
-    __builtin_amdgcn_s_barrier();
-    load_frags(P0{}, 0);
-    float ln_mean[XB], ln_rstd[XB];
-    if (ln_on) {
-        // equal-sized chunks merged with the chunk means shifted by the first one (gemm_common.h: gemm_ln_finish): every lane its quarter
-        // of the chunks, the quarters added across the row's four lanes in a fixed order
-#pragma unroll
-        for (int i = 0; i < XB; ++i)
-#pragma unroll
-            for (int c = 0; c < G7_LNC; ++c) asm volatile("" : "+v"(lnp[i][c]));
-        const float nc = (float)(p.K / p.ln_in_chunks), inv_chunks = 1.f / (float)p.ln_in_chunks;
-#pragma unroll
-        for (int i = 0; i < XB; ++i) {
-            const float m0v = lnp[i][0][0];
-            float s = 0.f, pq = 0.f, q = 0.f;
-#pragma unroll
-            for (int c = 1; c < G7_LNC; ++c) {
-                const int ch = g4 + 4 * (c - 1);
-                if (ch < p.ln_in_chunks) { const float dl = lnp[i][c][0] - m0v; s += dl; pq += dl * dl; q += lnp[i][c][1]; }
-            }
-            s += __shfl_xor(s, 16, 64); pq += __shfl_xor(pq, 16, 64); q += __shfl_xor(q, 16, 64);
-            s += __shfl_xor(s, 32, 64); pq += __shfl_xor(pq, 32, 64); q += __shfl_xor(q, 32, 64);
-            const float dm = s * inv_chunks;
-            ln_mean[i] = m0v + dm;
-            const float M2 = q + nc * fmaxf(pq - s * dm, 0.f);
-            ln_rstd[i] = 1.0f / sqrtf(M2 / (float)p.K + p.ln_eps);
-            if (p.ln_mr_out && tile_n == 0 && wn == 0 && g4 == 0)
-                *(f32x2*)(p.ln_mr_out + (long)(m0 + (wm * XB + i) * 16 + r16) * 2) = f32x2{ln_mean[i], ln_rstd[i]};
-        }
-    }
-    __builtin_amdgcn_s_waitcnt(0xC07F);            // lgkmcnt(0)
-
+    // X fragments in two sets (all of them feed every column of MFMAs), W fragments in ONE: the MFMAs run column by column (j outer), so
+    // a column's fragment is dead behind its XB MFMAs and the next half tile's takes its registers right there (128 x 320: 160
+    // accumulator + 40 + 2 x 16 fragment registers fit the 256 of a two-waves-per-SIMD kernel; two full sets would not)
+    bf16x8 xf[2][XB], wf[WB], lf;
     int cur = 0;
-    // half tile g in ring slot cur, its fragments in set SET = g & 1.  MORE: a next tile exists; ISSUE: tile g+S-1 exists (staged into the
-    // slot of g-1); KEEP: tiles beyond g+1 whose LDS-DMA stays in flight across the barrier; IPAR: parity of the tile being staged.
-    // All compile-time: the body is straight-line code (hipcc falls back to lgkmcnt(0) at control-flow joins).
-    auto body = [&](auto set_c, auto more_c, auto issue_c, auto keep_c, auto ipar_c) {
+    // half tile g: X fragments in set SET.  MORE: behind barrier B_g (half tile g+1 has landed, ring slot nxt) the X fragments of g+1 are
+    // requested one behind each of the first MFMAs and W block j's behind the last MFMA of column j.  No waitcnt by hand: every LDS
+    // access of a compute wave is visible to hipcc, which counts lgkmcnt in front of each consumer.
+    auto body = [&](auto set_c, auto more_c) {
         constexpr int SET = decltype(set_c)::value;
         constexpr bool MORE = decltype(more_c)::value;
         const int nxt = cur == S - 1 ? 0 : cur + 1;
-        const int prv = cur == 0 ? S - 1 : cur - 1;
+        const char* nb = smem + nxt * SLOT;
+        if constexpr (MORE) __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
-        mfmas(set_c, P0{}, std::integral_constant<int, WB / 2>{}, F_{}, P0{}, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        if constexpr (MORE) {
-            wait_keep(keep_c);
-            __builtin_amdgcn_s_barrier();
-            __builtin_amdgcn_sched_barrier(0);
-            load_frags(std::integral_constant<int, 1 - SET>{}, nxt);
+#pragma unroll
+        for (int j = 0; j < WB; ++j) {
+#pragma unroll
+            for (int i = 0; i < XB; ++i) {
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], xf[SET][i], acc[i][j], 0, 0, 0);
+                if (MORE && j == 0) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    xf[1 - SET][i] = *(const bf16x8*)(nb + fx + i * 1024);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            if (MORE) {
+                __builtin_amdgcn_sched_barrier(0);
+                wf[j] = *(const bf16x8*)(nb + fw + j * 1024);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        if (LORA) {
+#pragma unroll
+            for (int ii = 0; ii < XB / 2; ++ii) {
+                const bf16x8 xs = wn ? xf[SET][2 * ii + 1] : xf[SET][2 * ii];      // both named, the scalar wn selects
+                accl[ii] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lf, xs, accl[ii], 0, 0, 0);
+            }
+            if (MORE) {
+                __builtin_amdgcn_sched_barrier(0);
+                lf = *(const bf16x8*)(nb + fl);
+            }
         }
         __builtin_amdgcn_sched_barrier(0);
-        mfmas(set_c, std::integral_constant<int, WB / 2>{}, std::integral_constant<int, WB>{}, issue_c, ipar_c, prv);
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_waitcnt(0xC07F);        // nothing pending across the loop edge
         cur = nxt;
     };
-    using KS = std::integral_constant<int, S - 3>;
-    int g = 0;
-    for (; g + S < nk; g += 2) {                   // g and g + 1 both stage a tile
-        body(P0{}, T_{}, T_{}, KS{}, std::integral_constant<int, (S - 1) & 1>{});
-        body(P1{}, T_{}, T_{}, KS{}, std::integral_constant<int, S & 1>{});
+    using T_ = std::true_type;
+    using F_ = std::false_type;
+    __builtin_amdgcn_s_barrier();                  // P: half tile 0 has landed
+#pragma unroll
+    for (int i = 0; i < XB; ++i) xf[0][i] = *(const bf16x8*)(smem + fx + i * 1024);
+#pragma unroll
+    for (int j = 0; j < WB; ++j) wf[j] = *(const bf16x8*)(smem + fw + j * 1024);
+    if (LORA) lf = *(const bf16x8*)(smem + fl);
+    for (int g = 0; g + 2 < nk; g += 2) {
+        body(P0{}, T_{});
+        body(P1{}, T_{});
     }
-    // g even, nk - g = R half tiles left (nk even, nk >= S): R = S for even S (the first of them still stages one), S - 1 for odd S
-    constexpr int R = (S % 2 == 0) ? S : S - 1;
-    auto tail = [&](auto t_c, auto&& self) {
-        constexpr int T = decltype(t_c)::value;
-        if constexpr (T < R) {
-            constexpr bool ISSUE = (T + S - 1) < R;
-            constexpr int KEEP = (R - 2 - T) < (S - 3) ? ((R - 2 - T) < 0 ? 0 : (R - 2 - T)) : (S - 3);
-            body(std::integral_constant<int, T & 1>{}, std::integral_constant<bool, (T < R - 1)>{}, std::integral_constant<bool, ISSUE>{},
-                 std::integral_constant<int, KEEP>{}, std::integral_constant<int, (T + S - 1) & 1>{});
-            self(std::integral_constant<int, T + 1>{}, self);
-        }
-    };
-    tail(P0{}, tail);
+    body(P0{}, T_{});
+    body(P1{}, F_{});
 
     // ---- epilogue ---------------------------------------------------------------------------------------------------------------
     // acc[i][j][e] = C[m = m0 + (wm XB + i) 16 + r16][n = n0 + (wn WB + j) 16 + 4 g4 + e]
@@ -416,13 +399,13 @@ __global__ __launch_bounds__(256) void gemm7_kernel(const G7Args p) {
     const bool to_vt = p.vt != nullptr && ncw >= p.vt_col0;      // wave-uniform: these columns are the V block slh_attn_fwd wants transposed
     constexpr int PLD = 32 * WB + 16;                  // bytes per staged row: 16 WB bf16 + 16 (the rows of a quad write fall on distinct banks)
     constexpr int TLD = 32 * XB + 16;                  // transposed patch: one column's 16 XB rows + 16
-    constexpr int PATCH = (16 * PLD > 16 * WB * TLD) ? 16 * PLD : 16 * WB * TLD;
+    constexpr int PATCH = 16 * PLD + 16 * WB * TLD;    // per wave: [16 rows][PLD] row patch, then [16 WB columns][TLD] transposed patch
     static_assert(EX_BYTES + 4 * PATCH <= S * SLOT, "epilogue staging must fit the ring");
     char* sE = smem + EX_BYTES + wave * PATCH;
+    char* sT = sE + 16 * PLD;
     constexpr int CW = (WB % 5 == 0) ? 80 : 64;        // LayerNorm chunk width of the producer side
-    constexpr int JC = CW / 16, NCH = 16 * WB / CW;    // blocks per chunk, chunks per wave
+    constexpr int JC = CW / 16;                        // blocks per chunk
     static_assert(WB % JC == 0, "chunks");
-    bf16x4 okeep[XB][WB];                              // rounded results (needed again by the transposed store)
 #pragma unroll
     for (int i = 0; i < XB; ++i) {
         bf16x4 rq[WB];
@@ -441,7 +424,6 @@ __global__ __launch_bounds__(256) void gemm7_kernel(const G7Args p) {
                 if (p.residual) v += (float)rq[j][e];
                 o[e] = (__bf16)v;
             }
-            okeep[i][j] = o;
             if (p.ln_out) {      // statistics of the stored (rounded) values of this row's CW columns, shifted by a sample of the row
                 if (j % JC == 0) { ln_k = __shfl((float)o[0], r16, 64); ln_s = 0.f; ln_q = 0.f; }
 #pragma unroll
@@ -455,6 +437,11 @@ __global__ __launch_bounds__(256) void gemm7_kernel(const G7Args p) {
                         *(f32x2*)(p.ln_out + ((long)chunk * p.M + mrow + i * 16) * 2) = f32x2{ln_k + dm, fmaxf(ln_q - ln_s * dm, 0.f)};
                     }
                 }
+            }
+            if (to_vt) {
+                // head-transposed: sT[column (16 WB)][row (16 XB)] - a column of the wave's tile becomes a 32 XB-byte run along the tokens
+#pragma unroll
+                for (int e = 0; e < 4; ++e) *(__bf16*)(sT + (j * 16 + 4 * g4 + e) * TLD + (i * 16 + r16) * 2) = o[e];
             }
             if (!to_vt || p.vt_also_c) *(bf16x4*)(sE + r16 * PLD + j * 32 + g4 * 8) = o;
         }
@@ -472,13 +459,6 @@ __global__ __launch_bounds__(256) void gemm7_kernel(const G7Args p) {
         __builtin_amdgcn_wave_barrier();
     }
     if (to_vt) {
-        // head-transposed store: sT[column (16 WB)][row (16 XB)] - a column of the wave's tile becomes a 32 XB-byte run along the tokens
-#pragma unroll
-        for (int i = 0; i < XB; ++i)
-#pragma unroll
-            for (int j = 0; j < WB; ++j)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) *(__bf16*)(sE + (j * 16 + 4 * g4 + e) * TLD + (i * 16 + r16) * 2) = okeep[i][j][e];
         __builtin_amdgcn_wave_barrier();
         const int Dp = (p.vt_D + 63) & ~63;
         const int mw = m0 + wm * (XB * 16);
@@ -488,7 +468,7 @@ __global__ __launch_bounds__(256) void gemm7_kernel(const G7Args p) {
         for (int it = 0; it < (16 * WB * SEGS) / 64; ++it) {
             const int item = it * 64 + lane;
             const int nl = item / SEGS, seg = item - nl * SEGS;
-            const bf16x8 v8 = *(const bf16x8*)(sE + nl * TLD + seg * 16);
+            const bf16x8 v8 = *(const bf16x8*)(sT + nl * TLD + seg * 16);
             const int nv = ncw + nl - p.vt_col0;
             const int hh = nv / p.vt_D, dd = nv - hh * p.vt_D;
             *(bf16x8*)(p.vt + (((long)bb * p.vt_heads + hh) * Dp + dd) * p.vt_ld + tt + seg * 8) = v8;
@@ -533,7 +513,6 @@ extern "C" int slh_gemm7_ok(const slh_gemm_desc* d) {
     if (d->ln_in) {
         if (!d->ln_s || !d->ln_b || d->bias || ((uintptr_t)d->ln_in & 7) || ((uintptr_t)d->ln_s & 15) || ((uintptr_t)d->ln_b & 15)) return 0;
         if (d->ln_in_chunks < 1 || d->ln_in_chunks > 20 || !(d->K == 64 * d->ln_in_chunks || d->K == 80 * d->ln_in_chunks)) return 0;
-        if (d->lora_down && !(d->ln_lora_s && d->ln_lora_c)) return 0;
     } else if (d->ln_mr_out || d->ln_lora_s) {
         return 0;
     }
@@ -564,6 +543,9 @@ int slh_gemm7_launch(const slh_gemm_desc* d, slh_stream_t stream) {
               "single-source products with packed weights, M %% 128 == 0, N %% (32 WB) == 0, K >= 32 S; bias / residual / ln_out / ln_in / "
               "fused adapter (128 x 256) / vt_out / geglu = 3 only (tile 0x%x M=%d N=%d K=%d)", d ? d->tile : 0, d ? d->M : 0, d ? d->N : 0,
               d ? d->K : 0);
+    // (not part of slh_gemm7_ok: the planner asks that before it has built the adapter's fold)
+    SLH_CHECK(!(d->ln_in && d->lora_down) || (d->ln_lora_s && d->ln_lora_c),
+              "slh_gemm: ln_in with a fused adapter needs ln_lora_s / ln_lora_c (lora_down = A . gamma)");
     int xb, wb, s;
     g7_shape(d->tile, xb, wb, s);
     G7Args a;
@@ -582,12 +564,12 @@ int slh_gemm7_launch(const slh_gemm_desc* d, slh_stream_t stream) {
     const int grid = a.tiles_m * a.tiles_n;
     const hipStream_t st = (hipStream_t)stream;
     if (wb == 8) {
-        if (d->lora_down) slh_launch<gemm7_kernel<4, 8, 6, true>>(grid, 256, st, a, "gemm7_kernel<4, 8, 6, true>");
-        else slh_launch<gemm7_kernel<4, 8, 6, false>>(grid, 256, st, a, "gemm7_kernel<4, 8, 6, false>");
+        if (d->lora_down) slh_launch<gemm7_kernel<4, 8, 6, true>>(grid, 512, st, a, "gemm7_kernel<4, 8, 6, true>");
+        else slh_launch<gemm7_kernel<4, 8, 6, false>>(grid, 512, st, a, "gemm7_kernel<4, 8, 6, false>");
     } else if (wb == 10) {
-        slh_launch<gemm7_kernel<4, 10, 5, false>>(grid, 256, st, a, "gemm7_kernel<4, 10, 5, false>");
+        slh_launch<gemm7_kernel<4, 10, 5, false>>(grid, 512, st, a, "gemm7_kernel<4, 10, 5, false>");
     } else {
-        slh_launch<gemm7_kernel<4, 5, 6, false>>(grid, 256, st, a, "gemm7_kernel<4, 5, 6, false>");
+        slh_launch<gemm7_kernel<4, 5, 6, false>>(grid, 512, st, a, "gemm7_kernel<4, 5, 6, false>");
     }
     SLH_LAUNCH_CHECK("slh_gemm (four-wave tile)");
     return 0;

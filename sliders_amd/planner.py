@@ -385,7 +385,9 @@ class UNetPlan:
             if ((d.tile >> 16) & 15) > 1 or (not d.tile and splitk_wanted(d)):
                 return None
             if grp is not None:
-                if not fused or ln_norm is None or (d.tile >> 12) & 15 != 8 or (d.tile >> 4) & 15 != 1 or (d.tile & 15) > 4:
+                fam = (d.tile >> 12) & 15
+                fits = (fam == 8 and (d.tile >> 4) & 15 == 1 and (d.tile & 15) <= 4) or (fam == 7 and (d.tile & 15) == 8)
+                if not fused or ln_norm is None or not fits:
                     return None                   # (the 128-register tiles of gemm.hip have no room for the second fold)
                 R = 4 * len(grp)
                 a2 = self.arena.alloc((R, K), torch.bfloat16, name + ".lnA")
@@ -404,6 +406,11 @@ class UNetPlan:
             st = self.f32((N // 80, M, 2), name + ".ln_chunks")      # the 64 x 160 tile leaves 80-column chunks (a wave's columns)
             d.ln_out = st.ptr
             out.ln = (st, N // 80)
+        elif want_ln_out and (d.tile >> 12) & 15 == 7:
+            cw = 80 if (d.tile & 15) % 5 == 0 else 64                # the four-wave tiles: 80-column chunks where a wave owns 80 / 160 columns
+            st = self.f32((N // cw, M, 2), name + ".ln_chunks")
+            d.ln_out = st.ptr
+            out.ln = (st, N // cw)
         elif want_ln_out and not d.splitk_c32 and (lib.gemm_variant(d) >> 4) & 15 == 2 and \
                 ((d.tile >> 12) & 15 != 8 or (d.tile >> 4) & 15 == 4):
             st = self.f32((N // 64, M, 2), name + ".ln_chunks")
@@ -415,6 +422,8 @@ class UNetPlan:
             Cq = N // 3
             Dh, Tk = Cq // vt_heads, Ho * Wo
             pp_ok = (d.tile >> 12) & 15 != 8 or (d.tile & 0xFF) in (0x42, 0x14)     # ping-pong tiles: 256 x 256 and 128 x 256 only
+            if (d.tile >> 12) & 15 == 7:                                            # four-wave tiles: whole tiles per sample, V block on a wave boundary
+                pp_ok = Tk % 128 == 0 and (2 * Cq) % (16 * (d.tile & 15)) == 0
             if Dh % 64 == 0 and (2 * Cq) % 128 == 0 and Tk % 64 == 0 and not (d.tile >> 16) & 15 and pp_ok:
                 vt = self.arena.alloc((B, vt_heads, Dh, Tk), torch.bfloat16, name + ".vt")
                 d.vt_out, d.vt_col0, d.vt_D, d.vt_heads, d.vt_tokens, d.vt_ld = vt.ptr, 2 * Cq, Dh, vt_heads, Tk, Tk
