@@ -143,7 +143,7 @@ for pname, prog in programs:
         bt = min(cand, key=cand.get)
         if args.incremental:
             tot_h += tt[-1]
-            if cand[bt] < 0.98 * tt[-1]:
+            if cand[bt] < float(os.environ.get("TUNE_KEEP", "0.96")) * tt[-1]:      # (2 % is inside the noise of an event pair: round-5 notes)
                 best_table[key] = bt
                 tot_b += cand[bt]
             else:

@@ -53,7 +53,19 @@ def build_parser() -> argparse.ArgumentParser:
     p.add_argument("--seed", type=int, default=0)
     p.add_argument("--device", type=int, default=0)
     p.add_argument("--out", default="images")
+    p.add_argument("--prompts_path", default=None,
+                   help="csv with prompt / evaluation_seed / case_number columns (eval-scripts/generate_images_sd1.py:104-107): images go to "
+                        "<out>/<slider name>/<scale>/<case_number>_<sample>.png - the layout eval-scripts/clip_score.py and "
+                        "sliders_amd.clip_score read")
+    p.add_argument("--num_samples", type=int, default=1)
+    p.add_argument("--from_case", type=int, default=0)
+    p.add_argument("--till_case", type=int, default=1000000)
     return p
+
+
+def scale_folder(scale: float) -> str:
+    """folder name of a slider scale as the reference writes it (generate_images_sd1.py:116-120: '0.5' -> 'half')"""
+    return f"{scale:g}".replace("0.5", "half")
 
 
 def main(argv=None):
@@ -94,12 +106,42 @@ def main(argv=None):
     smp = SliderSampler(eng, store, dec, scheduler=a.scheduler, scheduler_seed=a.seed)
     os.makedirs(a.out, exist_ok=True)
     from PIL import Image
-    for s in (float(v) for v in a.scales.split(",")):
+    scales = [float(v) for v in a.scales.split(",")]
+    if a.prompts_path:
+        # the reference's evaluation set-up: one row per case, every scale from the same seed, one folder per scale
+        import pandas as pd
+        df = pd.read_csv(a.prompts_path)
+        name = os.path.basename(a.lora_weight).rsplit(".", 1)[0] if a.lora_weight else "no_slider"
+        root = os.path.join(a.out, name)
+        for s in scales:
+            os.makedirs(os.path.join(root, scale_folder(s)), exist_ok=True)
+        for _, row in df.iterrows():
+            case = int(row.case_number)
+            if not (a.from_case <= case <= a.till_case):
+                continue
+            if a.synthetic:
+                c_row, p_row = ctx, pooled
+            elif xl:
+                (e_u, p_u), (e_t, p_t) = (model_util.encode_prompts_xl(toks, encs, [t]) for t in ("", str(row.prompt)))
+                c_row, p_row = torch.cat([e_u, e_t]), torch.cat([p_u, p_t])
+            else:
+                c_row, p_row = torch.cat([model_util.encode_prompts(tok, enc, [t]) for t in ("", str(row.prompt))]), None
+            for num in range(a.num_samples):
+                for s in scales:
+                    g = torch.Generator().manual_seed(int(row.evaluation_seed) + num)          # the same noise for every scale
+                    noise = torch.randn(1, 4, res // 8, res // 8, generator=g)
+                    img = smp.generate(c_row.to(dev), noise.to(dev), scale=s, start_noise=a.start_noise, ddim_steps=a.ddim_steps,
+                                       guidance_scale=a.guidance_scale, pooled=p_row.to(dev) if p_row is not None else None)
+                    Image.fromarray(img[0].cpu().numpy()).save(os.path.join(root, scale_folder(s), f"{case}_{num}.png"))
+            print(f"case {case}: {a.num_samples} sample(s) x {len(scales)} scales saved under {root}")
+        return root
+    for s in scales:
         noise = torch.randn(1, 4, res // 8, res // 8, generator=torch.Generator().manual_seed(a.seed))   # same seed per scale
         img = smp.generate(ctx.to(dev), noise.to(dev), scale=s, start_noise=a.start_noise, ddim_steps=a.ddim_steps,
                            guidance_scale=a.guidance_scale, pooled=pooled.to(dev) if pooled is not None else None)
         Image.fromarray(img[0].cpu().numpy()).save(os.path.join(a.out, f"scale_{s:g}.png"))
         print(f"scale {s:g}: saved {os.path.join(a.out, f'scale_{s:g}.png')}")
+    return a.out
 
 
 if __name__ == "__main__":

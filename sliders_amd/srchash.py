@@ -36,7 +36,7 @@ def kernel_files(kernel_name: str, all_files) -> list:
     """The files a kernel's code and its launches depend on: its translation unit, the headers it includes, the public header
     (descriptor layout) and every tuned tile table (they decide which launches run the kernel)."""
     unit = {"gemm_kernel": ["gemm.hip", "gemm_common.h"], "gemm8p": ["gemm8p.hip", "gemm_common.h"],
-            "gemm5": ["gemm5.hip", "gemm.hip", "gemm_common.h"],
+            "gemm5": ["gemm5.hip", "gemm.hip", "gemm_common.h"], "gemm7": ["gemm7.hip", "gemm.hip", "gemm_common.h"],
             "attn_fwd": ["attention.hip"], "attn_bwd": ["attention_bwd.hip"]}
     picked = None
     for prefix, files in unit.items():

@@ -125,3 +125,26 @@ def test_image_slider_cli_end_to_end(dev, tmp_path):
     assert files, "no checkpoint written"
     sd = torch.load(files[0], map_location="cpu")
     assert any(k.endswith("lora_up.weight") and float(v.float().abs().max()) > 0 for k, v in sd.items())
+
+
+def test_generate_from_evaluation_csv_then_clip_score(tmp_path):
+    """The acceptance pipeline end to end on the GPU engine, plumbing only (random-init UNet / VAE / CLIP): `sliders_amd.generate
+    --prompts_path` writes the reference's folder layout (eval-scripts/generate_images_sd1.py:110-215: one folder per slider scale,
+    <case>_<sample>.png, every scale of a case from the same seed) and `sliders_amd.clip_score` turns it into the reference's
+    clip_scores.csv (eval-scripts/clip_score.py:41-72) plus the slider's direction."""
+    import pandas as pd
+    from sliders_amd import clip_score, generate
+    csv = str(tmp_path / "prompts.csv")
+    pd.DataFrame({"case_number": [0, 1, 5], "prompt": ["a person", "a dog", "a car"], "evaluation_seed": [11, 12, 13]}).to_csv(csv, index=False)
+    root = generate.main(["--model", "sd1", "--synthetic", "--prompts_path", csv, "--scales=-1,0.5,2", "--ddim_steps", "3", "--res", "256",
+                          "--out", str(tmp_path / "images"), "--till_case", "1"])
+    assert sorted(os.listdir(root)) == ["-1", "2", "half"]
+    for s in ("-1", "2", "half"):
+        assert sorted(os.listdir(os.path.join(root, s))) == ["0_0.png", "1_0.png"]           # case 5 lies outside --till_case
+    from PIL import Image
+    im = Image.open(os.path.join(root, "2", "1_0.png"))
+    assert im.size == (256, 256)
+    means, d = clip_score.main(["--im_path", root, "--prompt", "old", "--prompts_path", csv, "--synthetic_clip"])
+    assert set(means) == {-1.0, 0.5, 2.0}
+    out = pd.read_csv(os.path.join(root, "clip_scores.csv"))
+    assert {"clip_-1", "clip_0.5", "clip_2"} <= set(out.columns) and out.loc[out.case_number == 5, "clip_2"].isna().all()

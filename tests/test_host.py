@@ -150,14 +150,17 @@ def test_tile_64x160_entries_and_fallback():
         gemms = [d for o, d in p.prog.ops if o == lib.OP_GEMM]
         g5 = [d for d in gemms if (d.tile >> 12) & 15 == 5]
         assert all(lib.gemm5_ok(d) and tile_ok(d, d.tile) for d in g5)
-        assert all(d.M % 64 == 0 and d.N % 160 == 0 and not d.lora_down and not d.ln_in for d in g5)
+        assert all(d.M % 64 == 0 and d.N % 160 == 0 and not d.ln_in for d in g5)      # (round 6: one entry carries a fused adapter, which the tile supports)
         if mode == "off":
             assert not g5                      # M = 3072: 1.5 rounds of 64 x 160 tiles, measured slower - no entries
             continue
-        assert len(g5) >= 150 and {d.tile for d in g5} == {0x5425, 0x5525}
+        assert len(g5) >= 120 and {d.tile for d in g5} == {0x5425, 0x5525}      # (the 8192 x 640 products moved on to the 128 x 160 four-wave tile in round 6)
         seen += len(g5)
         # chunk statistics: producers on the tile leave N / 80 chunks, and whoever folds that LayerNorm merges N / 80 chunks of it
-        prod = {d.ln_out: d.N // 80 for d in g5 if d.ln_out}
+        # (the four-wave tiles of gemm7.hip whose waves own 80 / 160 columns - 0x7645, 0x754a - leave 80-column chunks as well)
+        g7 = [d for d in gemms if (d.tile >> 12) & 15 == 7]
+        assert all(lib.gemm7_ok(d) for d in g7)
+        prod = {d.ln_out: d.N // 80 for d in g5 + [d for d in g7 if (d.tile & 15) % 5 == 0] if d.ln_out}
         cons = [d for d in gemms if d.ln_in in prod]
         assert prod and cons and all(d.ln_in_chunks == prod[d.ln_in] and d.K == 80 * d.ln_in_chunks for d in cons)
         assert all(d.ln_in_chunks * 64 == d.K for d in gemms if d.ln_in and d.ln_in not in prod)
