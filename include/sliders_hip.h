@@ -314,8 +314,14 @@ typedef struct slh_attn_desc {
     int32_t vt_batch_heads;  /* 0 = H.  Otherwise vt points into a wider [B][vt_batch_heads][..][ldvt] array (one transposed
                                 V for the cross-attention of every transformer block) at this layer's first head */
     int32_t reserved_;
+    /* Optional weight touch (as slh_gemm_desc.pf_*): pf_bytes bytes at pf_ptr (16-byte aligned) - the packed weights of a product a
+     * few launches later - are streamed through the memory-side cache by up to 64 extra workgroups dispatched behind the launch's own.
+     * A hint: taken only by the key-split form (the self-attention of the 32 x 32 level, whose workgroups all fit the chip at once, so
+     * the touch runs beside them); slh_attn_fwd_carries_touch(d) = 1 where it would be.  NULL / 0 = none. */
+    const void* pf_ptr; int64_t pf_bytes;
 } slh_attn_desc;
 int slh_attn_fwd(const slh_attn_desc* d, slh_stream_t stream);
+int slh_attn_fwd_carries_touch(const slh_attn_desc* d);
 
 /* src [B][T][ld] columns [h*64,(h+1)*64) -> dst [B][H][64][ldt] (columns >= T zero-filled up to ldt) */
 typedef struct slh_transpose_desc {

@@ -13,18 +13,24 @@ from sliders_amd.lora_store import LoraStore
 from sliders_amd.random_init import random_state_dict
 from sliders_amd.unet import UNetEngine
 
+import argparse
+ap = argparse.ArgumentParser()
+ap.add_argument("--model", default="sdxl")
+ap.add_argument("--hw", type=int, default=128)
+ap.add_argument("--attn", action="store_true", help="also list the attention launches by shape")
+args = ap.parse_args()
 dev = torch.device("cuda:0")
-cfg = CONFIGS["sdxl"]()
+cfg = CONFIGS[args.model]()
 eng = UNetEngine(cfg, random_state_dict(cfg, dev, 0), dev)
 store = LoraStore(cfg, rank=4, alpha=1.0, train_method="noxattn", device=dev)
 store.params.add_(0.01)
 eng.attach_lora(store)
 eng.set_lora(True, 1.0)
-hw, B = 128, 2
+hw, B = args.hw, 2
 x = torch.randn(B, 4, hw, hw, device=dev)
 ctx = torch.randn(B, 77, cfg.cross_attention_dim, device=dev)
 kw = {"text_embeds": torch.randn(B, cfg.pooled_dim, device=dev),
-      "time_ids": torch.tensor([[hw * 8.0, hw * 8.0, 0, 0, hw * 8.0, hw * 8.0]] * B, device=dev)}
+      "time_ids": torch.tensor([[hw * 8.0, hw * 8.0, 0, 0, hw * 8.0, hw * 8.0]] * B, device=dev)} if cfg.is_xl else None
 eng(x, torch.tensor(500), ctx, kw, mode="on")
 p = eng.plan(B, hw, hw, "on")
 stream = torch.cuda.current_stream()
@@ -53,6 +59,8 @@ for op, d, nm, e0, e1 in recs:
     us = e0.elapsed_time(e1) * 1e3
     if op != lib.OP_GEMM:
         k = lib._ENTRY[op][0] if op in lib._ENTRY else "memset"
+        if args.attn and op == lib.OP_ATTN_FWD:
+            k = f"slh_attn_fwd B{d.B} H{d.H} Tq{d.Tq} Tk{d.Tk} D{d.D}"
         other[k][0] += 1; other[k][1] += us
         continue
     for _ in range(2):
@@ -73,6 +81,7 @@ for k, a in sorted(agg.items(), key=lambda kv: -kv[1][1]):
     M, N, K = k[0], k[1], k[2]
     fl = 2.0 * M * N * K
     print(f"{M:6d} {N:7d} {K:6d} {k[3]} {int(k[4])}    {k[5]}  {k[6]:>6} {a[0]:3d}  {a[1] / a[0]:9.1f} {a[2] / a[0]:8.1f}   {fl * a[0] / a[1] / 1e6:8.0f}   {a[1] / 1e3:8.2f}  {a[3]}")
+print(f"all ops in situ: {sum(e0.elapsed_time(e1) for _, _, _, e0, e1 in recs):.2f} ms over {len(recs)} launches")
 print("other ops:")
 for k, v in sorted(other.items(), key=lambda kv: -kv[1][1]):
     print(f"  {k:24s} n={v[0]:4d} total {v[1] / 1e3:7.2f} ms avg {v[1] / v[0]:7.1f} us")

@@ -253,13 +253,18 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_ks_kernel(const slh_attn_desc
     const int lrow = lane & 31, lhi = lane >> 5;
     const int frow = lane >> 3, fslot = lane & 7;
     int vb = blockIdx.x;
+    const int nqb = p.Tq >> 6;
     {
-        const int nblk = gridDim.x;
+        // the launch's own workgroups come first; any behind them stream weights for a later product (slh_attn_desc.pf_*) and leave
+        const int nblk = nqb * p.H * p.B;
+        if (vb >= nblk) {
+            weight_touch(p.pf_ptr, p.pf_bytes, vb - nblk, (int)gridDim.x - nblk);
+            return;
+        }
         const int qd = nblk >> 3, rm = nblk & 7;
         const int xcd = vb & 7, idx = vb >> 3;
         vb = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + idx;
     }
-    const int nqb = p.Tq >> 6;
     const int qb = vb % nqb, hb = vb / nqb;
     const int h = hb % p.H, b = hb / p.H;
     const int qrow = qb * 64 + qi * 32 + lrow;
@@ -455,6 +460,16 @@ __global__ __launch_bounds__(256) void transpose_heads_batch_kernel(const slh_tr
     transpose_heads_body(d, D, DT, bx, rest % gy, rest / gy);
 }
 
+// the key-split form can run the launch (D = 64, whole key tiles in two equal halves) / is the form launch_fwd picks for it
+static bool attn_ks_ok(const slh_attn_desc* d, int DT) {
+    return DT == 1 && (d->Tk & 63) == 0 && (d->D == 0 || d->D == 64) && d->Tq % 64 == 0 && d->Tk % 128 == 0 && d->Tk >= 256;
+}
+static bool attn_ks_form(const slh_attn_desc* d, int DT) {
+    static const int knob_ks = getenv("SLH_ATTN_KS") ? atoi(getenv("SLH_ATTN_KS")) : 1;        // A/B: 0 = never
+    const long blocks4 = (long)((d->Tq + 127) / 128) * d->H * d->B, blocks2 = (long)(d->Tq / 64) * d->H * d->B;
+    return knob_ks && attn_ks_ok(d, DT) && blocks4 < 512 && blocks2 > 128 && blocks2 <= 768;
+}
+
 template <int DT>
 int launch_fwd(const slh_attn_desc* d, hipStream_t s) {
     const long blocks4 = (long)((d->Tq + 127) / 128) * d->H * d->B;
@@ -467,9 +482,10 @@ int launch_fwd(const slh_attn_desc* d, hipStream_t s) {
     // fills every SIMD twice (>= 1024 workgroups) nor is so small that one round of full-length waves is cheaper
     static const int knob_ks = getenv("SLH_ATTN_KS") ? atoi(getenv("SLH_ATTN_KS")) : 1;        // A/B: 0 = never
     const long blocks2 = (long)(d->Tq / 64) * d->H * d->B;
-    if (DT == 1 && !tail && knob_ks && (d->D == 0 || d->D == 64) && d->Tq % 64 == 0 && d->Tk % 128 == 0 && d->Tk >= 256 &&
-        ((blocks4 < 512 && blocks2 > 128 && blocks2 <= 768) || knob_ks == 2)) {      // 2 = whenever the shape allows (A/B)
-        hipLaunchKernelGGL(attn_fwd_ks_kernel, dim3((unsigned)blocks2), dim3(256), 0, s, *d);
+    if (attn_ks_form(d, DT) || (knob_ks == 2 && attn_ks_ok(d, DT))) {      // 2 = whenever the shape allows (A/B)
+        // weight touch (pf_*): up to 64 workgroups behind the launch's own; with three workgroups per CU they are resident beside them
+        const int pf_blocks = (d->pf_ptr && d->pf_bytes >= 16) ? 64 : 0;
+        hipLaunchKernelGGL(attn_fwd_ks_kernel, dim3((unsigned)blocks2 + pf_blocks), dim3(256), 0, s, *d);
         SLH_LAUNCH_CHECK("slh_attn_fwd (key split)");
         return 0;
     }
@@ -488,6 +504,12 @@ int launch_fwd(const slh_attn_desc* d, hipStream_t s) {
 
 }  // namespace
 
+extern "C" int slh_attn_fwd_carries_touch(const slh_attn_desc* d) {
+    if (!d || d->B <= 0 || d->H <= 0 || d->Tq <= 0 || d->Tk <= 0) return 0;
+    const int D = d->D > 0 ? d->D : 64;
+    return attn_ks_form(d, (D + 63) / 64) ? 1 : 0;
+}
+
 extern "C" int slh_attn_fwd(const slh_attn_desc* d, slh_stream_t stream) {
     SLH_CHECK(d && d->q && d->k && d->vt && d->o, "slh_attn_fwd: null pointer");
     SLH_CHECK(d->B > 0 && d->H > 0 && d->Tq > 0 && d->Tk > 0, "slh_attn_fwd: bad shape");
@@ -495,6 +517,7 @@ extern "C" int slh_attn_fwd(const slh_attn_desc* d, slh_stream_t stream) {
     SLH_CHECK(D % 8 == 0 && D <= 192, "slh_attn_fwd: head_dim %d unsupported (multiple of 8, <= 192)", D);
     SLH_CHECK(d->ldq % 8 == 0 && d->ldk % 8 == 0 && d->ldvt % 64 == 0 && d->ldo % 4 == 0, "slh_attn_fwd: alignment");
     SLH_CHECK(d->ldvt >= ((d->Tk + 63) / 64) * 64, "slh_attn_fwd: VT must be padded to a multiple of 64 keys");
+    SLH_CHECK(!d->pf_ptr || (((uintptr_t)d->pf_ptr & 15) == 0 && d->pf_bytes >= 0), "slh_attn_fwd: pf_ptr must be 16-byte aligned");
     const int DT = (D + 63) / 64;
     hipStream_t s = (hipStream_t)stream;
     if (DT == 1) return launch_fwd<1>(d, s);

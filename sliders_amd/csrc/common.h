@@ -92,6 +92,27 @@ __device__ __forceinline__ unsigned lds_addr_of(const void* p) {
     return (unsigned)(uintptr_t)(const __attribute__((address_space(3))) char*)p;
 }
 
+// ---- weight touch (slh_gemm_desc.pf_* / slh_attn_desc.pf_*) --------------------------------------------------------------------
+// Workgroup `idx` of `count` touch workgroups - dispatched behind every workgroup that does the launch's own work - streams its
+// share of a byte range a LATER launch will need through plain loads (they allocate in the memory-side cache) and exits.
+// 16 independent 16-byte loads per thread in flight (128 KB per workgroup): at ~2 us per HBM miss anything less leaves the touch
+// slower than the launch it rides on, and a launch does not end before its touch does.
+__device__ __forceinline__ void weight_touch(const void* ptr, const long bytes, const int idx, const int count) {
+    const uint4* src = (const uint4*)ptr;
+    const long n16 = bytes >> 4, stride = (long)count * blockDim.x;
+    unsigned acc = 0;
+    long i = (long)idx * blockDim.x + threadIdx.x;
+    for (; i + 15 * stride < n16; i += 16 * stride) {
+        uint4 v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) v[u] = src[i + u * stride];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) acc ^= v[u].x;
+    }
+    for (; i < n16; i += stride) acc ^= src[i].x;
+    asm volatile("" ::"v"(acc));       // the loads are the point
+}
+
 // ---- write-through result stores (round 5) ------------------------------------------------------------------------------------
 // A kernel's results are consumed by the NEXT launch, on other XCDs as much as on this one: the per-XCD L2s are not coherent, so
 // the end of every kernel writes this XCD's dirty lines back (the implicit release) before the next dispatch may start.  Stored

@@ -83,21 +83,7 @@ __device__ __forceinline__ void gemm_map_tile(const GemmArgs& p, int& tile_m, in
 __device__ __forceinline__ bool gemm_weight_touch(const GemmArgs& p) {
     const int first = (int)gridDim.x - p.pf_blocks;
     if (p.pf_blocks <= 0 || (int)blockIdx.x < first) return false;
-    const uint4* src = (const uint4*)p.pf_ptr;
-    const long n16 = p.pf_bytes >> 4, stride = (long)p.pf_blocks * blockDim.x;
-    unsigned acc = 0;
-    long i = (long)((int)blockIdx.x - first) * blockDim.x + threadIdx.x;
-    // 16 independent 16-byte loads per thread in flight (128 KB per workgroup): at ~2 us per HBM miss anything less leaves the touch
-    // slower than the launch it rides on, and the launch does not end before its touch does
-    for (; i + 15 * stride < n16; i += 16 * stride) {
-        uint4 v[16];
-#pragma unroll
-        for (int u = 0; u < 16; ++u) v[u] = src[i + u * stride];
-#pragma unroll
-        for (int u = 0; u < 16; ++u) acc ^= v[u].x;
-    }
-    for (; i < n16; i += stride) acc ^= src[i].x;
-    asm volatile("" ::"v"(acc));       // the loads are the point
+    weight_touch(p.pf_ptr, p.pf_bytes, (int)blockIdx.x - first, p.pf_blocks);      // common.h
     return true;
 }
 

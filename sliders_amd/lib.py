@@ -56,7 +56,7 @@ LnBwdDesc = _struct("LnBwdDesc", _ptrs("x", "gamma", "dy", "mean_rstd", "dx")
                     + _ints("M", "C", "ldx", "lddy", "lddx", "accumulate"))
 AttnDesc = _struct("AttnDesc", _ptrs("q", "k", "vt", "o", "lse")
                    + _ints("B", "H", "Tq", "Tk", "ldq", "ldk", "ldvt", "ldo") + [("scale", c_f32)]
-                   + _ints("D", "vt_batch_heads", "reserved_"))
+                   + _ints("D", "vt_batch_heads", "reserved_") + _ptrs("pf_ptr") + [("pf_bytes", c_i64)])
 TransposeDesc = _struct("TransposeDesc", _ptrs("src", "dst") + _ints("B", "H", "T", "ld", "ldt", "D"))
 AttnBwdDesc = _struct("AttnBwdDesc", _ptrs("q", "k", "v", "o", "d_o", "kt", "qt", "dot", "lse", "delta", "dq", "dk", "dv")
                       + _ints("B", "H", "Tq", "Tk", "ldq", "ldk", "ldv", "ldo", "lddo", "ldkt", "ldqt", "lddq", "lddk",
@@ -141,7 +141,7 @@ _ENTRY = {
 }
 
 EXPORTS = ["slh_version", "slh_last_error", "slh_run_program", "slh_desc_sizes", "slh_graph_capture", "slh_graph_launch",
-           "slh_graph_destroy", "slh_gemm_variant", "slh_gemm_kernel_name", "slh_gemm5_ok", "slh_gemm7_ok", "slh_gn_row_blocks", "slh_gn_clusters", "slh_gn32_row_blocks",
+           "slh_graph_destroy", "slh_gemm_variant", "slh_gemm_kernel_name", "slh_gemm5_ok", "slh_gemm7_ok", "slh_attn_fwd_carries_touch", "slh_gn_row_blocks", "slh_gn_clusters", "slh_gn32_row_blocks",
            "slh_lora_wgrad_blocks", "slh_lora_wgrad_single_blocks", "slh_transpose_heads_blocks", "slh_gn_fused_ok"] + [v[0] for v in _ENTRY.values()]
 
 
@@ -285,6 +285,15 @@ def gemm7_ok(desc) -> bool:
     lib.slh_gemm7_ok.argtypes = [C.POINTER(GemmDesc)]
     lib.slh_gemm7_ok.restype = c_i32
     return bool(lib.slh_gemm7_ok(C.byref(desc)))
+
+
+def attn_carries_touch(desc) -> bool:
+    """slh_attn_fwd_carries_touch: this attention launch runs the key-split form, whose idle workgroup slots can stream weights for a
+    later product (slh_attn_desc.pf_*)"""
+    lib = load()
+    lib.slh_attn_fwd_carries_touch.argtypes = [C.POINTER(AttnDesc)]
+    lib.slh_attn_fwd_carries_touch.restype = c_i32
+    return bool(lib.slh_attn_fwd_carries_touch(C.byref(desc)))
 
 
 def gemm_variant(desc) -> int:

@@ -145,13 +145,16 @@ def attach_weight_touch(prog: "lib.Program") -> "lib.Program":
     """The product path's weight prefetch (slh_gemm_desc.pf_*): every GEMM whose packed weights are 6-96 MB (GEGLU.proj 26 MB,
     ff.net.2 13 MB, q|k|v 10 MB at the 1280-channel level) has those bytes touched by the idle workgroup slots of an EARLIER
     launch that leaves >= 64 CUs free - the 160-tile products on the 128 x 128 ring tile (attention out-projections, attn2.to_q,
-    ff.net.2 itself) - the nearest such carrier within TOUCH_WINDOW ops that does not carry a touch yet.  No extra launch, no
+    ff.net.2 itself) - or, round 6, of the key-split self-attention launch (slh_attn_desc.pf_*: three workgroups per CU, 640 of 768
+    slots taken) - the nearest such carrier within TOUCH_WINDOW ops that does not carry a touch yet.  No extra launch, no
     second stream.  SLIDERS_NO_WEIGHT_TOUCH=1 returns the program unchanged."""
     if os.environ.get("SLIDERS_NO_WEIGHT_TOUCH") is not None:
         return prog
     ops = list(prog.ops)
 
     def carrier(o, d):
+        if o == lib.OP_ATTN_FWD:          # round 6: the key-split self-attention of the 32 x 32 level (its workgroups leave a slot per CU)
+            return os.environ.get("SLIDERS_NO_ATTN_TOUCH") is None and lib.attn_carries_touch(d)
         if o != lib.OP_GEMM or d.mode != 0 or (d.tile & 0xFFFFFF) != 0x4412:
             return False
         return ((d.M + 127) // 128) * ((d.N + 127) // 128) <= 192

@@ -1005,6 +1005,15 @@ def test_attention_fwd(dev, B, H, Tq, Tk, D):
     ref = (torch.softmax(s, -1) @ vf).transpose(1, 2).reshape(B * Tq, C)
     report(f"attn_fwd B{B} H{H} Tq{Tq} Tk{Tk} D{D}", o, ref, 8e-3)
     report("attn_lse", lse, torch.logsumexp(s, -1) * 1.4426950408889634, 1e-4)
+    # weight touch (slh_attn_desc.pf_*): a hint - extra workgroups stream a byte range and leave; results bit-identical, any odd size
+    wbuf = torch.randn(3_000_017, device=dev)
+    o2 = torch.zeros_like(o)
+    d.o, d.pf_ptr, d.pf_bytes = p(o2), p(wbuf), wbuf.numel() * 4
+    assert lib.attn_carries_touch(d) == ((B, H, Tq, Tk, D) in ((2, 5, 1024, 1024, 64), (2, 20, 1024, 1024, 64), (2, 10, 1024, 1024, 64),
+                                                              (2, 10, 512, 256, 64)))
+    lib.call(lib.OP_ATTN_FWD, d, stream())
+    torch.cuda.synchronize()
+    assert torch.equal(o, o2)
 
 
 def test_timestep_embed_and_conv_in(dev):
