@@ -64,14 +64,17 @@ def gemm_flops(d):
     return 2.0 * d.M * n * d.K
 
 
-def pmc_traffic_for(kname, profiles_dir=None):
-    """(bytes per launch, source note) of kernel `kname` from the newest committed counter passes (profiles/r*_pmc_traffic.json), or
-    (None, why): the figures are attached only when the tree this runs from is the tree the passes were taken on - as a whole, or in
-    every file the kernel is built from (sliders_amd/srchash.py)."""
+def pmc_traffic_for(kname, profiles_dir=None, tag=""):
+    """(bytes per launch, source note) of kernel `kname` from the newest committed counter passes (profiles/r*_pmc_traffic<tag>.json;
+    tag "" = the SDXL 1024x1024 LoRA-on pass, "_sd1_64" / "_sdxl_64" = the passes of the other configurations), or (None, why): the
+    figures are attached only when the tree this runs from is the tree the passes were taken on - as a whole, or in every file the
+    kernel is built from (sliders_amd/srchash.py) - and only to the configuration the passes ran."""
     import glob
     traffic, tsrc = None, None
     profiles_dir = profiles_dir or os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
-    cands = sorted(glob.glob(os.path.join(profiles_dir, "r*_pmc_traffic.json")))
+    cands = sorted(glob.glob(os.path.join(profiles_dir, f"r[0-9][0-9]_pmc_traffic{tag}.json")))
+    if not cands:
+        return None, f"none: no counter passes of this configuration are committed (profiles/r*_pmc_traffic{tag}.json)"
     if cands:                                   # PMC counters cannot be read from inside the timed process: the
         tpath = cands[-1]                       # per-launch HBM-side bytes come from the newest committed --pmc passes
         with open(tpath) as f:
@@ -103,7 +106,7 @@ def pmc_traffic_for(kname, profiles_dir=None):
     return traffic, tsrc
 
 
-def measure_roofline(eng, plan):
+def measure_roofline(eng, plan, pmc_tag=""):
     """Time EVERY launch of one LoRA-on UNet denoise pass IN SITU: the pass is replayed op by op in program order on the
     launch stream with a HIP event pair around each launch, so every kernel sees the cache state it sees in the real pass
     (frozen weights cold in HBM, activations warm in L2/MALL).  GEMM launches are grouped by kernel instantiation under
@@ -177,12 +180,15 @@ def measure_roofline(eng, plan):
     achieved = g["flops"] / (g["ms"] * 1e-3) / 1e12
     table = {k: dict(calls_per_pass=x["calls"], ms_per_pass=round(x["ms"], 3),
                      tflops=round(x["flops"] / (x["ms"] * 1e-3) / 1e12, 1)) for k, x in sorted(groups.items())}
-    traffic, tsrc = pmc_traffic_for(kname)
+    traffic, tsrc = pmc_traffic_for(kname, tag=pmc_tag) if pmc_tag is not None else (None, "none: no counter passes exist for this pass kind")
     import glob
     # MFMA utilisation from the newest committed counter pass: SQ_VALU_MFMA_BUSY_CYCLES (32 per 32x32x16 MFMA, summed over
     # the SIMDs) / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs)
     def mfma_util(kernel_prefix):
-        c2 = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r*_pmc_mfma_busy_fwd_lora_on.csv")))
+        if pmc_tag is None:           # a measurement of another configuration's pass is not a measurement of this one
+            return None
+        c2 = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles",
+                                           f"r[0-9][0-9]_pmc_mfma_busy_fwd_lora_on{pmc_tag}.csv")))
         if not c2:
             return None
         import csv
@@ -689,6 +695,11 @@ def run_config(a, dev, world, rank, main_line):
                                 f"not run and not counted)"),
                    "bench_step": "one training iteration", "unet_denoise_steps_timed": unet_steps * world,
                    "iterations_per_s": round(a.steps * world / dt, 4), "prompt_pairs": len(pairs),
+                   "frozen_weights_gib": round(eng.weights.nbytes() / 2 ** 30, 2),
+                   "weights_note": ("packed forward copies + transposed / flipped-tap copies for the backward-data products; GEGLU.proj is kept "
+                                    "twice (32|32 row blocks for the training forward, 16|16 blocks for the no-grad passes: +3.6 GB for SDXL, "
+                                    "SLIDERS_GEGLU16=0 drops the second copy and the 128 x 320 tile with it)"
+                                    if getattr(eng.weights, "geglu16", False) else "GEGLU.proj kept once (SLIDERS_GEGLU16=0)"),
                    "parallelism": f"dp{world}", "final_loss": loss,
                    "steps_per_s_with_frozen_predictions_run_as_3_cfg_pairs": value_no_dedup},
     }
@@ -698,7 +709,10 @@ def run_config(a, dev, world, rank, main_line):
         print("[bench] timed region done: " + json.dumps({k: res[k] for k in ("value", "ms_per_step")}), file=sys.stderr, flush=True)
     if rank == 0 and not a.no_roofline:
         eng.set_lora(True, 1.0)
-        res["roofline"] = measure_roofline(eng, eng.plan(2, hw, hw, "on" if a.workload == "text" else "train"))
+        # counter passes exist for the LoRA-on no-grad pass of each configuration (scripts/measure_round.sh); the image slider's
+        # training-pass roofline gets none
+        tag = None if a.workload != "text" else ("" if (a.model, hw) == ("sdxl", 128) else f"_{a.model}_{hw}")
+        res["roofline"] = measure_roofline(eng, eng.plan(2, hw, hw, "on" if a.workload == "text" else "train"), pmc_tag=tag)
         if a.workload == "image":
             res["vae_roofline"] = measure_vae_roofline(vae, vae_sd, imgs[0], a.res)
     if rank == 0 and world == 1:

@@ -30,8 +30,8 @@ for r in rows(write):
     hit, miss = float(r["TCC_HIT_sum"]), float(r["TCC_MISS_sum"])
     k["l2_hit_rate"] = round(hit / (hit + miss), 3) if hit + miss > 0 else None
 res = {"tree_head": tree_head, "kernel_source_hash": kernel_source_hash(), "file_hashes": file_hashes(), "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum (separate passes, --kernel-trace only) over "
-                 "LoRA-on SDXL 1024x1024 B=2 UNet passes (scripts/bench_forward.py --lora --warm 0 --iters 1: the first call "
-                 "plus one replay); FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports 64 B per 128-B request); "
+                 "LoRA-on B=2 UNet passes of the configuration in the file name (scripts/bench_forward.py --lora --warm 1 --iters 1: first call, "
+                 "warm-up, one replay - the first call's dispatches dropped per kernel, scripts/pmc_summary.py --drop-first-third); FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports 64 B per 128-B request); "
                  "WRITE_SIZE uncalibrated; KB -> bytes",
        "kernels": {k: v for k, v in kern.items() if "fetch_bytes_per_launch" in v and "write_bytes_per_launch" in v}}
 with open(out, "w") as f:
