@@ -15,7 +15,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--shapes", default="2048x3840x256,2048x3840x640,2048x3840x1280,2048x3840x2560")
 ap.add_argument("--tiles", default="8014,7648")
 ap.add_argument("--reps", type=int, default=40)
-ap.add_argument("--epi", default="none", choices=["none", "bias_res"])
+ap.add_argument("--epi", default="none", choices=["none", "bias_res", "geglu", "geglu_ln"])
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 stream = torch.cuda.current_stream()
@@ -43,14 +43,23 @@ for shp in a.shapes.split(","):
     nc = max(2, min(48, int(600e6 // (N * K * 2)) + 1))
     w = (torch.randn(N, K, device=dev) / math.sqrt(K)).bfloat16()
     wps = [pack_gemm_w(w) for _ in range(nc)]
-    c = torch.zeros(M, N, device=dev, dtype=torch.bfloat16)
+    geglu = a.epi.startswith("geglu")
+    c = torch.zeros(M, N // 2 if geglu else N, device=dev, dtype=torch.bfloat16)
     ref = x.float() @ w.float().t() + ((bias.float() + res.float()) if a.epi == "bias_res" else 0)
+    lnkw = {}
+    if geglu:      # timing only (16 | 16 block order taken as given); the LayerNorm-fold variant gets unit statistics
+        ref = None
+        if a.epi == "geglu_ln":
+            ch = torch.zeros(K // 64, M, 2, device=dev); ch[..., 1] = 64.0
+            sv, bp = torch.zeros(N, device=dev), torch.zeros(N, device=dev)
+            lnkw = dict(ln_in=ch.data_ptr(), ln_in_chunks=K // 64, ln_s=sv.data_ptr(), ln_b=bp.data_ptr(), ln_eps=1e-5)
     row = []
     for t in a.tiles.split(","):
         tile = int(t, 16)
-        mk = lambda wp: lib.GemmDesc(a0=x.data_ptr(), w=wp.data_ptr(), bias=bias.data_ptr() if a.epi == "bias_res" else 0,
+        mk = lambda wp: lib.GemmDesc(a0=x.data_ptr(), w=wp.data_ptr(), bias=bias.data_ptr() if a.epi in ("bias_res", "geglu") else 0,
                                      residual=res.data_ptr() if a.epi == "bias_res" else 0, c=c.data_ptr(), lda0=K, ca0=K, mode=0, stride=1,
-                                     ldw=0, M=M, N=N, K=K, ld_res=N, ldc=N, rows_per_sample=M, tile=tile, w_layout=1)
+                                     ldw=0, M=M, N=N, K=K, ld_res=N, ldc=c.shape[1], rows_per_sample=M, tile=tile, w_layout=1,
+                                     geglu=3 if geglu else 0, **lnkw)
         descs = [mk(wp) for wp in wps]
         c.zero_()
         try:
@@ -59,7 +68,7 @@ for shp in a.shapes.split(","):
             row.append(f"{tile:x}: refused")
             continue
         torch.cuda.synchronize()
-        e = ((c.float() - ref).norm() / ref.norm()).item()
+        e = ((c.float() - ref).norm() / ref.norm()).item() if ref is not None else 0.0
         cold = time_it(descs, a.reps)
         warm = time_it(descs[:1], a.reps)
         row.append(f"{tile:x}: cold {cold:6.1f} warm {warm:6.1f} us ({2.0 * M * N * K / warm / 1e6:5.0f} TF){'' if e < 5e-3 else ' WRONG %.2e' % e}")

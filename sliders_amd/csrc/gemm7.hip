@@ -476,6 +476,329 @@ __global__ __launch_bounds__(512) void gemm7_kernel(const G7Args p) {
     }
 }
 
+// ---- 256 x (32 WB) tile on EIGHT compute waves (tile code 0x7<S>8<WB>; round 6) ---------------------------------------------------
+// GEGLU.proj (2048 x 10240 x 1280) as 128 x 320 tiles is 512 workgroups = two rounds of the chip: two prologues, two GEGLU epilogues and
+// 56 KB staged per 64 of K for every 128 x 320 of output.  As 256 x 320 tiles it is 8 x 32 = 256 workgroups = ONE round, and a
+// workgroup stages (256 + 320) rows for twice the MFMA work: 36 % fewer bytes through the L2 -> LDS stream that bounds these loops
+// (DESIGN 3.5).  Eight waves = two per SIMD, each the (64 x 160) register tile of the four-wave kernel above (160 accumulator + 40 W-fragment
+// + 2 x 16 X-fragment registers of the 256 a wave may use); no room for loader waves, so the waves stage the ring themselves, one LDS-DMA
+// piece behind an MFMA, addressed as SGPR base + 32-bit lane offset (three lane registers for all pieces: the K walk lives in the scalar
+// bases).  Ring of S half K tiles (36 KB each), S - 2 in flight across a barrier (the barrier sits in the middle of a half tile's MFMAs: see
+// the loop body).
+// Epilogue: the LayerNorm fold / bias vectors of the tile's columns through LDS once, then bias / residual or GEGLU (16 | 16 blocks).
+template <int WB, int S>
+__global__ __launch_bounds__(512) void gemm7w_kernel(const G7Args p) {
+    constexpr int XB = 4;                                  // 16-row blocks per wave: waves form a 4 x 2 grid
+    constexpr int BM = 256, BN = 32 * WB;
+    constexpr int XBYTES = BM * 64, SLOT = (BM + BN) * 64;
+    constexpr int NPIECE = (BM + BN) / 16;                 // 1 KB pieces per half tile
+    constexpr int L = NPIECE / 8, REM = NPIECE % 8;        // every wave L pieces, waves < REM one more
+    constexpr int NXPC = BM / 16;                          // the first NXPC pieces are X rows
+    static_assert(S * SLOT <= 160 * 1024 && S >= 4, "LDS");
+    __shared__ __attribute__((aligned(16))) char smem[S * SLOT];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    int tile_m, tile_n;
+    {
+        const int nblk = (int)gridDim.x;
+        const int bid = gemm_remap_bid(nblk);
+        const int gsz = p.group_m * p.tiles_n;
+        const int g = bid / gsz;
+        const int first_m = g * p.group_m;
+        const int gm = min(p.group_m, p.tiles_m - first_m);
+        const int r = bid - g * gsz;
+        tile_n = r / gm;
+        tile_m = first_m + r - tile_n * gm;
+    }
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int nk = p.K >> 5;
+    const int r16 = lane & 15, g4 = lane >> 4;
+    const bool ln_on = p.ln_in != nullptr;
+
+    // ---- staging: piece q = wave + 8 k; lane -> (row = lane / 4, physical slot = lane % 4), logical slot fsl (see the kernel above)
+    const int frow = lane >> 2, fps = lane & 3;
+    const int fsl = fps ^ g7_key(frow >> 2);
+    const unsigned vx = (unsigned)(frow * p.lda * 2 + fsl * 16);                                   // X: row pitch, 64-byte K step in the base
+    const int wkey = (frow >> 1) & 7;                                                               // a piece starts at a multiple of 16 rows
+    const unsigned vw0 = (unsigned)(frow * 128 + ((fsl ^ wkey) << 4));                              // W, first half of the 64-deep block
+    const unsigned vw1 = (unsigned)(frow * 128 + (((4 + fsl) ^ wkey) << 4));                        // ... second half
+    const bool extra = wave < REM;
+    const char* base[L + 1];                               // scalar: this wave's pieces, at half tile 0
+#pragma unroll
+    for (int k = 0; k < L + 1; ++k) {
+        int q = wave + 8 * k;
+        q = q < NPIECE ? q : NPIECE - 1;
+        if (q < NXPC) base[k] = (const char*)(p.a + (long)(m0 + q * 16) * p.lda);
+        else {
+            const int pw = q - NXPC;
+            base[k] = (const char*)(p.w + ((long)((n0 >> 6) + (pw >> 2)) * (p.K >> 6)) * 4096 + (pw & 3) * (16 * 64));
+        }
+    }
+    const unsigned lds0 = lds_addr_of(smem);
+    // piece k of half tile t (PAR = t & 1, compile time) into ring slot `slot`
+    auto piece = [&](const int k, const int slot, auto par_c) {
+        constexpr int PAR = decltype(par_c)::value;
+        int q = wave + 8 * k;
+        q = q < NPIECE ? q : NPIECE - 1;
+        const bool is_x = (8 * k + 7 < NXPC) || (8 * k < NXPC && q < NXPC);      // (compile time for the pieces every wave shares a kind)
+        const unsigned dst = lds0 + slot * SLOT + q * 1024;
+        if (is_x) {
+            asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(vx), "s"(base[k]), "s"(dst) : "memory");
+            base[k] += 64;
+        } else {
+            asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(PAR ? vw1 : vw0), "s"(base[k]), "s"(dst) : "memory");
+            if (PAR) base[k] += 8192;
+        }
+    };
+    auto wait_keep = [&](auto keep_c) {
+        constexpr int KEEP = decltype(keep_c)::value;
+        if (extra) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(KEEP * (L + 1)) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(KEEP * L) : "memory");
+    };
+    using P0 = std::integral_constant<int, 0>;
+    using P1 = std::integral_constant<int, 1>;
+    using T_ = std::true_type;
+    using F_ = std::false_type;
+
+    // folded LayerNorm, consumer side (as above: ordinary loads ahead of the first LDS-DMA; hipcc waits for them before the prologue's asm)
+    float ln_mean[XB], ln_rstd[XB];
+    if (ln_on) {
+        const float nc = (float)(p.K / p.ln_in_chunks), inv_chunks = 1.f / (float)p.ln_in_chunks;
+#pragma unroll
+        for (int i = 0; i < XB; ++i) {
+            const int m = m0 + (wm * XB + i) * 16 + r16;
+            const f32x2* src = (const f32x2*)p.ln_in + m;
+            f32x2 lnp[G7_LNC];
+#pragma unroll
+            for (int c = 0; c < G7_LNC; ++c) {
+                const int ch = c == 0 ? 0 : g4 + 4 * (c - 1);
+                lnp[c] = src[(long)(ch < p.ln_in_chunks ? ch : 0) * p.M];
+            }
+            const float m0v = lnp[0][0];
+            float sm = 0.f, pq = 0.f, q = 0.f;
+#pragma unroll
+            for (int c = 1; c < G7_LNC; ++c) {
+                const int ch = g4 + 4 * (c - 1);
+                if (ch < p.ln_in_chunks) { const float dl = lnp[c][0] - m0v; sm += dl; pq += dl * dl; q += lnp[c][1]; }
+            }
+            sm += __shfl_xor(sm, 16, 64); pq += __shfl_xor(pq, 16, 64); q += __shfl_xor(q, 16, 64);
+            sm += __shfl_xor(sm, 32, 64); pq += __shfl_xor(pq, 32, 64); q += __shfl_xor(q, 32, 64);
+            const float dm = sm * inv_chunks;
+            ln_mean[i] = m0v + dm;
+            const float M2 = q + nc * fmaxf(pq - sm * dm, 0.f);
+            ln_rstd[i] = 1.0f / sqrtf(M2 / (float)p.K + p.ln_eps);
+            if (p.ln_mr_out && tile_n == 0 && wn == 0 && g4 == 0) *(f32x2*)(p.ln_mr_out + (long)m * 2) = f32x2{ln_mean[i], ln_rstd[i]};
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the counted waits below count LDS-DMA pieces only
+    }
+
+    f32x4_t acc[XB][WB];
+#pragma unroll
+    for (int i = 0; i < XB; ++i)
+#pragma unroll
+        for (int j = 0; j < WB; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    const int foff = r16 * 64 + ((g4 ^ g7_key(r16 >> 2)) << 4);
+    const int fx = foff + wm * (XB * 1024), fw = foff + XBYTES + wn * (WB * 1024);
+    bf16x8 xf[2][XB], wf[WB];
+
+    // prologue: half tiles 0 .. S-2 requested, tile 0 landed
+    {
+        auto stage = [&](const int t, auto par_c) {
+#pragma unroll
+            for (int k = 0; k < L; ++k) piece(k, t, par_c);
+            if (extra) piece(L, t, par_c);
+        };
+#pragma unroll
+        for (int t = 0; t < S - 1; ++t) {
+            if (t & 1) stage(t, P1{});
+            else stage(t, P0{});
+        }
+    }
+    wait_keep(std::integral_constant<int, S - 2>{});
+    __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int i = 0; i < XB; ++i) xf[0][i] = *(const bf16x8*)(smem + fx + i * 1024);
+#pragma unroll
+    for (int j = 0; j < WB; ++j) wf[j] = *(const bf16x8*)(smem + fw + j * 1024);
+
+    int cur = 0;
+    // half tile g (ring slot cur, X fragments in set SET), barrier in the MIDDLE of its MFMAs:
+    //   first half = columns 0 .. WB/2-1, with this wave's pieces of half tile g+S-1 dealt out behind them (into the slot of g-1: every wave
+    //   passed the previous body's barrier, i.e. finished the body before it, whose MFMAs consumed the last fragments of g-1);
+    //   s_waitcnt vmcnt(KEEP pieces): my pieces of g+1 have landed - g+2 .. g+S-1 stay in flight: S-2 half tiles cross every barrier
+    //   (with the barrier at the top of the body, the first version, it was S-3 = one: 0.96 -> see DESIGN 3.5);  s_barrier;
+    //   second half = columns WB/2 .. WB-1, the fragments of g+1 requested behind them: X behind the first XB MFMAs, behind every column its
+    //   own W fragment and the one of its first-half partner (both dead by then).
+    // MORE: a next tile exists; ISSUE: half tile g+S-1 exists; IPAR: its parity.  All compile time.
+    auto body = [&](auto set_c, auto more_c, auto issue_c, auto keep_c, auto ipar_c) {
+        constexpr int SET = decltype(set_c)::value;
+        constexpr bool MORE = decltype(more_c)::value, ISSUE = decltype(issue_c)::value;
+        constexpr int H = WB / 2;
+        const int nxt = cur == S - 1 ? 0 : cur + 1;
+        const int prv = cur == 0 ? S - 1 : cur - 1;
+        const char* nb = smem + nxt * SLOT;
+        __builtin_amdgcn_sched_barrier(0);
+        int m = 0;
+#pragma unroll
+        for (int j = 0; j < H; ++j) {
+#pragma unroll
+            for (int i = 0; i < XB; ++i) {
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], xf[SET][i], acc[i][j], 0, 0, 0);
+                if (ISSUE && (i & 1) == 1 && m < L) {       // a piece behind every second MFMA
+                    __builtin_amdgcn_sched_barrier(0);
+                    piece(m, prv, ipar_c);
+                    __builtin_amdgcn_sched_barrier(0);
+                    ++m;
+                }
+            }
+        }
+        if (ISSUE) {
+            if (extra) piece(L, prv, ipar_c);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (MORE) {
+            wait_keep(keep_c);
+            __builtin_amdgcn_s_barrier();
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = H; j < WB; ++j) {
+#pragma unroll
+            for (int i = 0; i < XB; ++i) {
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], xf[SET][i], acc[i][j], 0, 0, 0);
+                if (MORE && j == H) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    xf[1 - SET][i] = *(const bf16x8*)(nb + fx + i * 1024);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            if (MORE) {
+                __builtin_amdgcn_sched_barrier(0);
+                wf[j] = *(const bf16x8*)(nb + fw + j * 1024);
+                wf[j - H] = *(const bf16x8*)(nb + fw + (j - H) * 1024);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        cur = nxt;
+    };
+    using KS = std::integral_constant<int, S - 2>;
+    int g = 0;
+    for (; g + S < nk; g += 2) {
+        body(P0{}, T_{}, T_{}, KS{}, std::integral_constant<int, (S - 1) & 1>{});
+        body(P1{}, T_{}, T_{}, KS{}, std::integral_constant<int, S & 1>{});
+    }
+    constexpr int R = (S % 2 == 0) ? S : S - 1;                // half tiles left (nk even, nk >= S)
+    auto tail = [&](auto t_c, auto&& self) {
+        constexpr int T = decltype(t_c)::value;
+        if constexpr (T < R) {
+            constexpr bool ISSUE = (T + S - 1) < R;
+            // at the barrier of body T half tile T+1 must have landed; requested beyond it: up to min(R-1, T+S-1)
+            constexpr int LASTREQ = (T + S - 1) < (R - 1) ? (T + S - 1) : (R - 1);
+            constexpr int KEEP = LASTREQ - (T + 1) > 0 ? LASTREQ - (T + 1) : 0;
+            body(std::integral_constant<int, T & 1>{}, std::integral_constant<bool, (T < R - 1)>{}, std::integral_constant<bool, ISSUE>{},
+                 std::integral_constant<int, KEEP>{}, std::integral_constant<int, (T + S - 1) & 1>{});
+            self(std::integral_constant<int, T + 1>{}, self);
+        }
+    };
+    tail(P0{}, tail);
+
+    // ---- epilogue ---------------------------------------------------------------------------------------------------------------
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    // the tile's column vectors (LayerNorm fold s / b', or the bias) through LDS once per workgroup
+    float* sCol = (float*)smem;                             // [2][BN]
+    {
+        const int n = n0 + tid;
+        if (tid < BN) {
+            sCol[tid] = ln_on ? p.ln_s[n] : (p.bias ? (float)p.bias[n] : 0.f);
+            sCol[BN + tid] = ln_on ? p.ln_b[n] : 0.f;
+        }
+    }
+    __syncthreads();
+    const int mrow = m0 + wm * (XB * 16) + r16;
+    const int ncw = n0 + wn * (WB * 16);
+    const int cl0 = wn * (WB * 16) + 4 * g4;               // this lane's first column inside the tile (+ 16 j)
+#pragma unroll
+    for (int j = 0; j < WB; ++j) {
+        const f32x4_t s4 = *(const f32x4_t*)(sCol + cl0 + j * 16), b4 = *(const f32x4_t*)(sCol + BN + cl0 + j * 16);
+#pragma unroll
+        for (int i = 0; i < XB; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                acc[i][j][e] = ln_on ? ln_rstd[i] * (acc[i][j][e] - ln_mean[i] * s4[e]) + b4[e] : acc[i][j][e] + s4[e];
+    }
+    const __amdgpu_buffer_rsrc_t crs = wt_rsrc(p.c);
+    constexpr int COLB = 2 * BN * 4;                        // bytes of the column vectors in front of the patches
+    if (p.geglu == 3) {
+        constexpr int GSEG = WB;
+        constexpr int GLD = 16 * WB + 16;
+        static_assert(COLB + 8 * 16 * GLD <= S * SLOT, "epilogue staging");
+        char* sG = smem + COLB + wave * (16 * GLD);
+#pragma unroll
+        for (int i = 0; i < XB; ++i) {
+#pragma unroll
+            for (int j = 0; j < WB; j += 2) {
+                bf16x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float av = round_bf16(acc[i][j][e]), gv = round_bf16(acc[i][j + 1][e]);
+                    o[e] = (__bf16)(av * round_bf16(gelu_erf_fast_f(gv)));
+                }
+                *(bf16x4*)(sG + r16 * GLD + (j >> 1) * 32 + g4 * 8) = o;
+            }
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int it = 0; it < (16 * GSEG + 63) / 64; ++it) {
+                const int item = it * 64 + lane;
+                const int row = item / GSEG, seg = item - row * GSEG;
+                if (item < 16 * GSEG) {
+                    const bf16x8 v8 = *(const bf16x8*)(sG + row * GLD + seg * 16);
+                    wt_store16(crs, ((long)(m0 + (wm * XB + i) * 16 + row) * p.ldc + (ncw >> 1) + seg * 8) * 2, v8);
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        return;
+    }
+    constexpr int PLD = 32 * WB + 16;
+    static_assert(COLB + 8 * 16 * PLD <= S * SLOT, "epilogue staging");
+    char* sE = smem + COLB + wave * (16 * PLD);
+    const int ncol = ncw + 4 * g4;
+#pragma unroll
+    for (int i = 0; i < XB; ++i) {
+        bf16x4 rq[WB];
+        if (p.residual) {
+#pragma unroll
+            for (int j = 0; j < WB; ++j) rq[j] = *(const bf16x4*)(p.residual + (long)(mrow + i * 16) * p.ld_res + ncol + j * 16);
+        }
+#pragma unroll
+        for (int j = 0; j < WB; ++j) {
+            bf16x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float v = acc[i][j][e];
+                if (p.residual) v += (float)rq[j][e];
+                o[e] = (__bf16)v;
+            }
+            *(bf16x4*)(sE + r16 * PLD + j * 32 + g4 * 8) = o;
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int it = 0; it < (16 * 2 * WB + 63) / 64; ++it) {
+            const int item = it * 64 + lane;
+            const int row = item / (2 * WB), seg = item - row * (2 * WB);
+            if ((16 * 2 * WB) % 64 == 0 || item < 16 * 2 * WB) {
+                const bf16x8 v8 = *(const bf16x8*)(sE + row * PLD + seg * 16);
+                wt_store16(crs, ((long)(m0 + (wm * XB + i) * 16 + row) * p.ldc + ncw + seg * 8) * 2, v8);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 }  // namespace
 
 // group_m of the grouped tile order (gemm5.hip): the gm that minimises the operand rows an XCD pulls through its L2
@@ -493,7 +816,8 @@ static int g7_group_m(int tiles_m, int tiles_n, int bm, int bn) {
 
 static bool g7_shape(int tile, int& xb, int& wb, int& s) {
     s = (tile >> 8) & 15; xb = (tile >> 4) & 15; wb = tile & 15;
-    return (xb == 4 && wb == 8 && s == 6) || (xb == 4 && wb == 10 && s == 5) || (xb == 4 && wb == 5 && s == 6);
+    return (xb == 4 && wb == 8 && s == 6) || (xb == 4 && wb == 10 && s == 5) || (xb == 4 && wb == 5 && s == 6) ||
+           (xb == 8 && wb == 10 && s == 4);      // 0x748a: 256 x 320 on eight compute waves
 }
 
 // called by slh_gemm (gemm.hip) for tile codes whose bits 12-15 are 7; 1 where the tile named by d->tile can run the descriptor
@@ -516,6 +840,7 @@ extern "C" int slh_gemm7_ok(const slh_gemm_desc* d) {
     } else if (d->ln_mr_out || d->ln_lora_s) {
         return 0;
     }
+    if (xb == 8 && (d->lora_down || d->vt_out || d->ln_out)) return 0;      // the 256-row tile: bias / residual / ln_in / geglu = 3 only
     if (d->lora_down) {      // fused adapter, forward form: rank 4 * groups <= 12, each tile inside one column group
         if (wb != 8) return 0;                       // (instantiated on the 128 x 256 tile only)
         if (!d->lora_up || !d->lora_scale || d->lora_up_rmajor || d->lora_groups < 1 || d->lora_groups > 3 ||
@@ -563,7 +888,9 @@ int slh_gemm7_launch(const slh_gemm_desc* d, slh_stream_t stream) {
     a.vt_also_c = d->vt_also_c; a.geglu = d->geglu;
     const int grid = a.tiles_m * a.tiles_n;
     const hipStream_t st = (hipStream_t)stream;
-    if (wb == 8) {
+    if (xb == 8) {
+        slh_launch<gemm7w_kernel<10, 4>>(grid, 512, st, a, "gemm7w_kernel<10, 4>");
+    } else if (wb == 8) {
         if (d->lora_down) slh_launch<gemm7_kernel<4, 8, 6, true>>(grid, 512, st, a, "gemm7_kernel<4, 8, 6, true>");
         else slh_launch<gemm7_kernel<4, 8, 6, false>>(grid, 512, st, a, "gemm7_kernel<4, 8, 6, false>");
     } else if (wb == 10) {
