@@ -225,13 +225,16 @@ def test_planner_fusions_of_the_no_grad_pass(name, hw):
     for i, (o, d) in enumerate(ops):
         if o == lib.OP_GEMM:
             wpos.setdefault(d.w, i)
-    touches = [(i, d) for i, (o, d) in enumerate(ops) if o == lib.OP_GEMM and d.pf_ptr]
+    touches = [(i, d) for i, (o, d) in enumerate(ops) if o in (lib.OP_GEMM, lib.OP_ATTN_FWD) and d.pf_ptr]
     if name == "sdxl":
-        # (round 5: attn2.to_out / proj_out / ff.net.2 of the 1280-channel level run on the 64 x 160 tile - 256 workgroups, no idle slots -
-        # so a block is left with two carriers, attn1.to_out and attn2.to_q, for its three big matrices: GEGLU.proj and ff.net.2 are
-        # touched, the next block's q|k|v is not; measured with this assignment)
+        # (round 5: attn2.to_out / proj_out / ff.net.2 of the 1280-channel level run on the 64 x 160 tile - 256 workgroups, no idle slots;
+        # round 6: attn1.to_out as well, its touch rides on the key-split self-attention launch in front of it (slh_attn_desc.pf_*) - so a
+        # block has two carriers, attn1.sdpa and attn2.to_q, for its three big matrices: GEGLU.proj and ff.net.2 are touched, the next
+        # block's q|k|v is not; measured with this assignment)
         assert len(touches) >= 120
-    assert all((d.tile & 0xFFFFFF) == 0x4412 and d.pf_bytes >= 6 << 20 for _, d in touches)
+        assert sum(1 for i, d in touches if ops[i][0] == lib.OP_ATTN_FWD) >= 55
+    assert all(d.pf_bytes >= 6 << 20 and (ops[i][0] == lib.OP_ATTN_FWD and lib.attn_carries_touch(d) or (d.tile & 0xFFFFFF) == 0x4412)
+               for i, d in touches)
     for j, dj in touches:       # the bytes a launch touches are the packed weights of a product at most TOUCH_WINDOW ops LATER
         later = [d for o, d in ops[j + 1:j + 1 + TOUCH_WINDOW] if o == lib.OP_GEMM and d.w == dj.pf_ptr]
         assert later and dj.pf_bytes == (later[0].N + 63) // 64 * 64 * later[0].K * 2, (j, hex(dj.pf_ptr))
