@@ -258,7 +258,7 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_ks_kernel(const slh_attn_desc
         // the launch's own workgroups come first; any behind them stream weights for a later product (slh_attn_desc.pf_*) and leave
         const int nblk = nqb * p.H * p.B;
         if (vb >= nblk) {
-            weight_touch(p.pf_ptr, p.pf_bytes, vb - nblk, (int)gridDim.x - nblk);
+            weight_touch<8>(p.pf_ptr, p.pf_bytes, vb - nblk, (int)gridDim.x - nblk);
             return;
         }
         const int qd = nblk >> 3, rm = nblk & 7;

@@ -97,17 +97,18 @@ __device__ __forceinline__ unsigned lds_addr_of(const void* p) {
 // share of a byte range a LATER launch will need through plain loads (they allocate in the memory-side cache) and exits.
 // 16 independent 16-byte loads per thread in flight (128 KB per workgroup): at ~2 us per HBM miss anything less leaves the touch
 // slower than the launch it rides on, and a launch does not end before its touch does.
+template <int U = 16>      // independent 16-byte loads per thread (a kernel with a tight register budget takes fewer)
 __device__ __forceinline__ void weight_touch(const void* ptr, const long bytes, const int idx, const int count) {
     const uint4* src = (const uint4*)ptr;
     const long n16 = bytes >> 4, stride = (long)count * blockDim.x;
     unsigned acc = 0;
     long i = (long)idx * blockDim.x + threadIdx.x;
-    for (; i + 15 * stride < n16; i += 16 * stride) {
-        uint4 v[16];
+    for (; i + (U - 1) * stride < n16; i += U * stride) {
+        uint4 v[U];
 #pragma unroll
-        for (int u = 0; u < 16; ++u) v[u] = src[i + u * stride];
+        for (int u = 0; u < U; ++u) v[u] = src[i + u * stride];
 #pragma unroll
-        for (int u = 0; u < 16; ++u) acc ^= v[u].x;
+        for (int u = 0; u < U; ++u) acc ^= v[u].x;
     }
     for (; i < n16; i += stride) acc ^= src[i].x;
     asm volatile("" ::"v"(acc));       // the loads are the point
