@@ -170,13 +170,14 @@ int slh_gemm_kernel_name(const slh_gemm_desc* d, char* buf, int cap);
  * weights (w_layout = 1), M % 64 == 0, N % 160 == 0; epilogue: bias, residual, ln_out - whose chunks are then 80 COLUMNS wide:
  * ln_out [N/80][M][2], and the consumer's ln_in_chunks = K / 80.  slh_gemm5_ok(d) = 1 where it can run the descriptor. */
 int slh_gemm5_ok(const slh_gemm_desc* d);
-/* The four-wave tiles (tile code bits 12-15 = 7: 0x7<S><XB><WB>; csrc/gemm7.hip): 128 x 256 (0x7648), 128 x 320 (0x754a), 128 x 160
- * (0x7645) - one wave per SIMD, each a (16 XB) x (16 WB) register tile of 16 x 16 x 32 MFMAs, ring of S half K tiles (32 deep) so that
- * 2-3 of them stay in flight across every barrier.  Dense single-source products with packed weights (w_layout = 1, w 128-byte aligned),
- * M % 128 == 0, N % (32 WB) == 0, K % 64 == 0, K >= 32 S.  Epilogue: bias, residual, ln_out (64-column chunks; 80-column chunks where
- * WB % 5 == 0), ln_in (also with the fused adapter's own fold: ln_lora_s / ln_lora_c), ln_mr_out, one fused adapter of 1-3 column groups
- * (forward form, 128 x 256 only; every tile inside one group), lora_t_out, vt_out / vt_also_c (vt_col0 % (16 WB) == 0, vt_tokens % 128 ==
- * 0), geglu = 3.  No split-K, row bias, external T, geglu 1 / 2, cross-attention.  slh_gemm7_ok(d) = 1 where d->tile can run d. */
+/* The tiles of csrc/gemm7.hip (tile code bits 12-15 = 7: 0x7<S><XB><WB>): 128 x 256 (0x7648) and 128 x 160 (0x7645) - four loader waves
+ * that issue the ring's LDS-DMA + four compute waves, one per SIMD, each a 64 x (16 WB) register tile of 16 x 16 x 32 MFMAs - and 256 x 320
+ * (0x748a) on eight compute waves that stage the ring themselves (GEGLU.proj as one round of 256 workgroups); ring of S half K tiles (32
+ * deep).  Dense single-source products with packed weights (w_layout = 1, w 128-byte aligned), M % (32 XB) == 0, N % (32 WB) == 0,
+ * K % 64 == 0, K >= 32 S.  Epilogue: bias, residual, ln_in, geglu = 3 on all three; on the 128-row tiles also ln_out (64-column chunks;
+ * 80-column chunks on 0x7645), ln_mr_out, vt_out / vt_also_c (vt_col0 % (16 WB) == 0, vt_tokens % 128 == 0) and - 0x7648 only - one fused
+ * adapter of 1-3 column groups (forward form, every tile inside one group; with ln_in also its own fold: ln_lora_s / ln_lora_c) and
+ * lora_t_out.  No split-K, row bias, external T, geglu 1 / 2, cross-attention.  slh_gemm7_ok(d) = 1 where d->tile can run d. */
 int slh_gemm7_ok(const slh_gemm_desc* d);
 
 /* ------------------------------------------------------------------------------------------------

@@ -1,4 +1,5 @@
-// 128 x (32 WB) tiles of the bf16 MFMA GEMM on FOUR waves with big register tiles (round 6; tile codes 0x7<S><XB><WB>).
+// 128 x (32 WB) tiles of the bf16 MFMA GEMM on FOUR compute waves with big register tiles, and a 256 x 320 tile on eight (round 6; tile
+// codes 0x7<S><XB><WB>: 0x7648, 0x7645; 0x748a).
 //
 // Why another K loop.  scripts/ubench_l2fill.hip (profiles/r06_l2_fill_ubench.txt): with nothing else going on a CU pulls 56-65 B/clk of
 // L2-resident data into LDS by LDS-DMA - the rate of its address path (one 1 KB wave-instruction per 16 clocks) - while the GEMM K loops
@@ -494,8 +495,9 @@ __global__ __launch_bounds__(512) void gemm7w_kernel(const G7Args p) {
     constexpr int NPIECE = (BM + BN) / 16;                 // 1 KB pieces per half tile
     constexpr int L = NPIECE / 8, REM = NPIECE % 8;        // every wave L pieces, waves < REM one more
     constexpr int NXPC = BM / 16;                          // the first NXPC pieces are X rows
-    static_assert(S * SLOT <= 160 * 1024 && S >= 4, "LDS");
-    __shared__ __attribute__((aligned(16))) char smem[S * SLOT];
+    constexpr int LNB = BM * 8;                            // (mean, rstd) of the tile's rows, parked behind the ring during the K loop
+    static_assert(S * SLOT + LNB <= 160 * 1024 && S >= 4, "LDS");
+    __shared__ __attribute__((aligned(16))) char smem[S * SLOT + LNB];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -563,7 +565,8 @@ __global__ __launch_bounds__(512) void gemm7w_kernel(const G7Args p) {
     using F_ = std::false_type;
 
     // folded LayerNorm, consumer side (as above: ordinary loads ahead of the first LDS-DMA; hipcc waits for them before the prologue's asm)
-    float ln_mean[XB], ln_rstd[XB];
+    // (kept in LDS, not in registers: the loop uses all 256 of them and hipcc would carry these eight through it in scratch)
+    f32x2* sLn = (f32x2*)(smem + S * SLOT);
     if (ln_on) {
         const float nc = (float)(p.K / p.ln_in_chunks), inv_chunks = 1.f / (float)p.ln_in_chunks;
 #pragma unroll
@@ -586,10 +589,11 @@ __global__ __launch_bounds__(512) void gemm7w_kernel(const G7Args p) {
             sm += __shfl_xor(sm, 16, 64); pq += __shfl_xor(pq, 16, 64); q += __shfl_xor(q, 16, 64);
             sm += __shfl_xor(sm, 32, 64); pq += __shfl_xor(pq, 32, 64); q += __shfl_xor(q, 32, 64);
             const float dm = sm * inv_chunks;
-            ln_mean[i] = m0v + dm;
+            const float mean = m0v + dm;
             const float M2 = q + nc * fmaxf(pq - sm * dm, 0.f);
-            ln_rstd[i] = 1.0f / sqrtf(M2 / (float)p.K + p.ln_eps);
-            if (p.ln_mr_out && tile_n == 0 && wn == 0 && g4 == 0) *(f32x2*)(p.ln_mr_out + (long)m * 2) = f32x2{ln_mean[i], ln_rstd[i]};
+            const float rstd = 1.0f / sqrtf(M2 / (float)p.K + p.ln_eps);
+            if (wn == 0 && g4 == 0) sLn[(wm * XB + i) * 16 + r16] = f32x2{mean, rstd};      // (the wn = 1 wave of the row block computes the same pair)
+            if (p.ln_mr_out && tile_n == 0 && wn == 0 && g4 == 0) *(f32x2*)(p.ln_mr_out + (long)m * 2) = f32x2{mean, rstd};
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the counted waits below count LDS-DMA pieces only
     }
@@ -721,6 +725,9 @@ __global__ __launch_bounds__(512) void gemm7w_kernel(const G7Args p) {
     const int mrow = m0 + wm * (XB * 16) + r16;
     const int ncw = n0 + wn * (WB * 16);
     const int cl0 = wn * (WB * 16) + 4 * g4;               // this lane's first column inside the tile (+ 16 j)
+    f32x2 lnr[XB];
+#pragma unroll
+    for (int i = 0; i < XB; ++i) lnr[i] = ln_on ? sLn[(wm * XB + i) * 16 + r16] : f32x2{0.f, 1.f};      // (written before the first barrier of the kernel)
 #pragma unroll
     for (int j = 0; j < WB; ++j) {
         const f32x4_t s4 = *(const f32x4_t*)(sCol + cl0 + j * 16), b4 = *(const f32x4_t*)(sCol + BN + cl0 + j * 16);
@@ -728,7 +735,7 @@ __global__ __launch_bounds__(512) void gemm7w_kernel(const G7Args p) {
         for (int i = 0; i < XB; ++i)
 #pragma unroll
             for (int e = 0; e < 4; ++e)
-                acc[i][j][e] = ln_on ? ln_rstd[i] * (acc[i][j][e] - ln_mean[i] * s4[e]) + b4[e] : acc[i][j][e] + s4[e];
+                acc[i][j][e] = ln_on ? lnr[i][1] * (acc[i][j][e] - lnr[i][0] * s4[e]) + b4[e] : acc[i][j][e] + s4[e];
     }
     const __amdgpu_buffer_rsrc_t crs = wt_rsrc(p.c);
     constexpr int COLB = 2 * BN * 4;                        // bytes of the column vectors in front of the patches
@@ -816,7 +823,9 @@ static int g7_group_m(int tiles_m, int tiles_n, int bm, int bn) {
 
 static bool g7_shape(int tile, int& xb, int& wb, int& s) {
     s = (tile >> 8) & 15; xb = (tile >> 4) & 15; wb = tile & 15;
-    return (xb == 4 && wb == 8 && s == 6) || (xb == 4 && wb == 10 && s == 5) || (xb == 4 && wb == 5 && s == 6) ||
+    // (a 128 x 320 four-wave instantiation, 0x754a, was measured and removed: it lost to the ping-pong tile in the pass and is
+    // superseded by the 256 x 320 tile - profiles/r06_gemm7_insitu_ab.txt, r06_tile_256x320.txt)
+    return (xb == 4 && wb == 8 && s == 6) || (xb == 4 && wb == 5 && s == 6) ||
            (xb == 8 && wb == 10 && s == 4);      // 0x748a: 256 x 320 on eight compute waves
 }
 
@@ -864,9 +873,9 @@ extern "C" int slh_gemm7_ok(const slh_gemm_desc* d) {
 
 int slh_gemm7_launch(const slh_gemm_desc* d, slh_stream_t stream) {
     SLH_CHECK(slh_gemm7_ok(d),
-              "slh_gemm: the four-wave tiles (0x7<S><XB><WB>: 0x7648 = 128 x 256, 0x754a = 128 x 320, 0x7645 = 128 x 160) run dense "
-              "single-source products with packed weights, M %% 128 == 0, N %% (32 WB) == 0, K >= 32 S; bias / residual / ln_out / ln_in / "
-              "fused adapter (128 x 256) / vt_out / geglu = 3 only (tile 0x%x M=%d N=%d K=%d)", d ? d->tile : 0, d ? d->M : 0, d ? d->N : 0,
+              "slh_gemm: the tiles of gemm7.hip (0x7<S><XB><WB>: 0x7648 = 128 x 256, 0x7645 = 128 x 160, 0x748a = 256 x 320) run dense "
+              "single-source products with packed weights, M %% (32 XB) == 0, N %% (32 WB) == 0, K >= 32 S; bias / residual / ln_out / ln_in / "
+              "fused adapter (128 x 256) / vt_out / geglu = 3 only (256 x 320: bias / residual / ln_in / geglu = 3) (tile 0x%x M=%d N=%d K=%d)", d ? d->tile : 0, d ? d->M : 0, d ? d->N : 0,
               d ? d->K : 0);
     // (not part of slh_gemm7_ok: the planner asks that before it has built the adapter's fold)
     SLH_CHECK(!(d->ln_in && d->lora_down) || (d->ln_lora_s && d->ln_lora_c),
@@ -893,8 +902,6 @@ int slh_gemm7_launch(const slh_gemm_desc* d, slh_stream_t stream) {
     } else if (wb == 8) {
         if (d->lora_down) slh_launch<gemm7_kernel<4, 8, 6, true>>(grid, 512, st, a, "gemm7_kernel<4, 8, 6, true>");
         else slh_launch<gemm7_kernel<4, 8, 6, false>>(grid, 512, st, a, "gemm7_kernel<4, 8, 6, false>");
-    } else if (wb == 10) {
-        slh_launch<gemm7_kernel<4, 10, 5, false>>(grid, 512, st, a, "gemm7_kernel<4, 10, 5, false>");
     } else {
         slh_launch<gemm7_kernel<4, 5, 6, false>>(grid, 512, st, a, "gemm7_kernel<4, 5, 6, false>");
     }

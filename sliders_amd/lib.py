@@ -275,13 +275,12 @@ def wgrad_single_blocks(desc) -> int:
 
 
 TILE_128x256 = 0x7648     # four-wave tiles of csrc/gemm7.hip (bits 12-15 = 7; ring slots | X blocks | W blocks of 16 rows per wave)
-TILE_128x320 = 0x754A
 TILE_128x160 = 0x7645
 TILE_256x320 = 0x748A     # eight compute waves (gemm7w_kernel): GEGLU.proj as one round of 256 workgroups
 
 
 def gemm7_ok(desc) -> bool:
-    """slh_gemm7_ok: the four-wave tile named by desc.tile (0x7648 / 0x754a / 0x7645) can run this descriptor"""
+    """slh_gemm7_ok: the tile of csrc/gemm7.hip named by desc.tile (0x7648 / 0x7645 / 0x748a) can run this descriptor"""
     lib = load()
     lib.slh_gemm7_ok.argtypes = [C.POINTER(GemmDesc)]
     lib.slh_gemm7_ok.restype = c_i32
