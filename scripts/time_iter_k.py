@@ -1,0 +1,57 @@
+"""Per-denoise-step cost inside the real training iteration (development aid): iteration time at k = 1, 9, 17, 33 -> slope (ms per
+step) against the replayed pass alone, and the k-independent part (frozen B=3 pass || training forward, backward, optimizer)."""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+
+from sliders_amd.config import CONFIGS
+from sliders_amd.lora_store import LoraStore
+from sliders_amd.random_init import random_state_dict
+from sliders_amd.trainer import PairEmbeds, SliderTrainer
+from sliders_amd.unet import UNetEngine
+
+dev = torch.device("cuda:0")
+cfg = CONFIGS["sdxl"]()
+hw = 128
+eng = UNetEngine(cfg, random_state_dict(cfg, dev, 0), dev)
+store = LoraStore(cfg, rank=4, alpha=1.0, train_method="noxattn", device=dev)
+tr = SliderTrainer(eng, store, hw, hw, batch_size=1, lr=2e-4)
+g = torch.Generator(device="cpu").manual_seed(1234)
+e = [torch.randn(1, 77, cfg.cross_attention_dim, generator=g).to(dev, torch.bfloat16) for _ in range(4)]
+pl = [torch.randn(1, cfg.pooled_dim, generator=g).to(dev, torch.bfloat16) for _ in range(4)]
+cat = lambda x: torch.cat([e[3], x]).contiguous()
+pcat = lambda x: torch.cat([pl[3], x]).contiguous()
+pair = PairEmbeds(cat(e[0]), cat(e[1]), cat(e[2]), cat(e[3]), pcat(pl[0]), pcat(pl[1]), pcat(pl[2]), pcat(pl[3]), guidance_scale=4.0, action="enhance")
+noise = torch.randn(1, 4, hw, hw, device=dev)
+for k in (3, 3):
+    tr.iteration(pair, k, noise)
+torch.cuda.synchronize()
+res = {}
+for k in (1, 9, 17, 33, 1, 9, 17, 33):
+    torch.cuda.synchronize()
+    t0 = time.time()
+    for _ in range(2):
+        tr.iteration(pair, k, noise)
+    torch.cuda.synchronize()
+    res.setdefault(k, []).append((time.time() - t0) / 2 * 1e3)
+for k, v in res.items():
+    print(f"k = {k:2d}: iteration {min(v):7.2f} ms")
+ks = sorted(res)
+slope = (min(res[33]) - min(res[1])) / 32
+print(f"per denoise step inside the iteration: {slope:.3f} ms; k-independent part: {min(res[1]) - slope:.2f} ms")
+p = eng.plan(2, hw, hw, "on")
+s = torch.cuda.current_stream().cuda_stream
+for prog, nm in ((p.prog, "full program"), (p.prog_text_cached, "text K/V cached")):
+    if prog is None:
+        continue
+    for _ in range(3):
+        prog.run(s)
+    torch.cuda.synchronize()
+    t0 = time.time()
+    for _ in range(10):
+        prog.run(s)
+    torch.cuda.synchronize()
+    print(f"replayed pass alone ({nm}): {(time.time() - t0) / 10 * 1e3:.3f} ms")
