@@ -26,7 +26,7 @@ def _chunks(x, cw):
 
 
 @pytest.mark.parametrize("tile", sorted(TILES))
-@pytest.mark.parametrize("mt,nt,K", [(1, 1, 192), (1, 1, 256), (2, 1, 320), (1, 2, 384), (3, 3, 448), (2, 2, 1280), (16, 5, 640)])
+@pytest.mark.parametrize("mt,nt,K", [(1, 1, 128), (1, 1, 192), (1, 1, 256), (2, 1, 320), (1, 2, 384), (3, 3, 448), (2, 2, 1280), (16, 5, 640), (9, 7, 2560)])
 def test_gemm7_dense(dev, tile, mt, nt, K):
     """plain / bias / bias + residual, every tail class of the half-tile ring (K / 32 = S, S + 1, ... and many), strided operands;
     bit-equal between runs"""
