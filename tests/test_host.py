@@ -157,7 +157,7 @@ def test_tile_64x160_entries_and_fallback():
         assert len(g5) >= 120 and {d.tile for d in g5} == {0x5425, 0x5525}      # (the 8192 x 640 products moved on to the 128 x 160 four-wave tile in round 6)
         seen += len(g5)
         # chunk statistics: producers on the tile leave N / 80 chunks, and whoever folds that LayerNorm merges N / 80 chunks of it
-        # (the four-wave tiles of gemm7.hip whose waves own 80 / 160 columns - 0x7645, 0x754a - leave 80-column chunks as well)
+        # (the four-wave tile of gemm7.hip whose waves own 80 columns - 0x7645 - leaves 80-column chunks as well)
         g7 = [d for d in gemms if (d.tile >> 12) & 15 == 7]
         assert all(lib.gemm7_ok(d) for d in g7)
         prod = {d.ln_out: d.N // 80 for d in g5 + [d for d in g7 if (d.tile & 15) % 5 == 0] if d.ln_out}
