@@ -9,7 +9,7 @@ make -C $src -s
 mkdir -p $src/build/var_$name
 hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wno-unused-result "$@" -c $src/$unit -o $src/build/var_$name/${unit%.hip}.o
 objs=""
-for o in gemm gemm8p lora norm attention attention_bwd ops vae program error; do
+for o in gemm gemm8p gemm5 gemm7 lora norm attention attention_bwd ops vae program error; do
   if [ "$o.hip" == "$unit" ]; then objs="$objs $src/build/var_$name/$o.o"; else objs="$objs $src/build/$o.o"; fi
 done
 hipcc --offload-arch=gfx950 -shared -fPIC -o $root/sliders_amd/libsliders_hip_$name.so $objs

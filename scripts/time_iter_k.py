@@ -29,19 +29,22 @@ noise = torch.randn(1, 4, hw, hw, device=dev)
 for k in (3, 3):
     tr.iteration(pair, k, noise)
 torch.cuda.synchronize()
-res = {}
-for k in (1, 9, 17, 33, 1, 9, 17, 33):
-    torch.cuda.synchronize()
-    t0 = time.time()
-    for _ in range(2):
-        tr.iteration(pair, k, noise)
-    torch.cuda.synchronize()
-    res.setdefault(k, []).append((time.time() - t0) / 2 * 1e3)
-for k, v in res.items():
-    print(f"k = {k:2d}: iteration {min(v):7.2f} ms")
-ks = sorted(res)
-slope = (min(res[33]) - min(res[1])) / 32
-print(f"per denoise step inside the iteration: {slope:.3f} ms; k-independent part: {min(res[1]) - slope:.2f} ms")
+for step_graphs in (False, True, False, True):
+    tr.step_graphs = step_graphs
+    res = {}
+    tr.iteration(pair, 3, noise)
+    for k in (1, 9, 17, 33, 1, 9, 17, 33):
+        torch.cuda.synchronize()
+        t0 = time.time()
+        for _ in range(2):
+            tr.iteration(pair, k, noise)
+        torch.cuda.synchronize()
+        res.setdefault(k, []).append((time.time() - t0) / 2 * 1e3)
+    print("one program per step (pass + combine + DDIM update)" if step_graphs else "fill + pass + combine launch per step")
+    for k, v in res.items():
+        print(f"  k = {k:2d}: iteration {min(v):7.2f} ms")
+    slope = (min(res[33]) - min(res[1])) / 32
+    print(f"  per denoise step inside the iteration: {slope:.3f} ms; k-independent part: {min(res[1]) - slope:.2f} ms")
 p = eng.plan(2, hw, hw, "on")
 s = torch.cuda.current_stream().cuda_stream
 for prog, nm in ((p.prog, "full program"), (p.prog_text_cached, "text K/V cached")):

@@ -401,15 +401,24 @@ class Program:
             self._buf = C.create_string_buffer(data, len(data))
         return self._buf
 
+    def capture(self) -> bool:
+        """Capture the graph now instead of after GRAPH_AFTER plain replays (recording launches nothing).  For programs
+        whose kernels have all run before: the trainer's per-step variants of a pass it has already replayed."""
+        if self._graphs is None and self.n_ops >= self.GRAPH_MIN_OPS and _GRAPHS_ON:
+            buf = self.finalize()
+            h = c_vp()
+            check(load().slh_graph_capture(C.cast(buf, c_vp), len(buf), C.byref(h)), "slh_graph_capture")
+            self._graphs = h
+        return self._graphs is not None
+
     def run(self, stream: int, graph: bool = True):
         buf = self.finalize()
         lib = load()
         if graph and self.n_ops >= self.GRAPH_MIN_OPS and _GRAPHS_ON:
             g = self._graphs
             if g is None and self._runs >= self.GRAPH_AFTER:
-                h = c_vp()
-                check(lib.slh_graph_capture(C.cast(buf, c_vp), len(buf), C.byref(h)), "slh_graph_capture")
-                g = self._graphs = h
+                self.capture()
+                g = self._graphs
             if g is not None:
                 check(lib.slh_graph_launch(g, c_vp(stream)), "slh_graph_launch")
                 return

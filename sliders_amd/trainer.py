@@ -72,6 +72,53 @@ class _ShapeState:
                                          dtype=torch.float32, device=dev)
 
 
+class _StepPrograms:
+    """The fused-scheduler denoise loop of one plan, one lib.Program per step index (SliderTrainer._step_programs)."""
+
+    def __init__(self, tr: "SliderTrainer", p_on, key):
+        self.key, self.tr, self.p = key, tr, p_on
+        B = 2 * tr.bs
+        n = len(tr.t50)
+        self.t_table = torch.tensor([[float(t)] * B for t in tr.t50], dtype=torch.float32, device=tr.eng.device).reshape(n, B)
+        self.progs = [None] * n
+        self.captured = False
+
+    def program(self, i: int) -> lib.Program:
+        pr = self.progs[i]
+        if pr is not None:
+            return pr
+        tr, p = self.tr, self.p
+        # the prompt embeddings do not change inside the loop: after the first step the text K/V are already there
+        base = p.prog if (i == 0 or p.prog_text_cached is None) else p.prog_text_cached
+        t_io = p.io["t"].ptr
+        pr = lib.Program()
+        patched = 0
+        for (op, d), nm in zip(base.ops, base.op_names):
+            if op == lib.OP_TEMBED and d.vals == t_io:
+                d = lib.TembedDesc.from_buffer_copy(bytes(d))
+                d.vals = self.t_table.data_ptr() + i * self.t_table.shape[1] * 4
+                patched += 1
+            pr.add(op, d, nm)
+        if patched != 1:
+            raise RuntimeError(f"step program: {patched} timestep projections read io['t'] (expected one)")
+        smp = p.io["sample"]
+        half = tr.bs * tr.chw * 2
+        pr.add(lib.OP_CFG_DDIM, tr._cfg_desc(p, smp.ptr, tr.denoise_guidance, tr.sched.step_fields(tr.t50[i], tr.nsteps),
+                                             out2=smp.ptr + half, x=smp.ptr), "cfg_ddim_step")
+        self.progs[i] = pr
+        return pr
+
+    def capture_all(self):
+        """After the first loop (every kernel of the pass has run): record the graphs of all steps a later k can reach, so
+        that no iteration pays a capture in its denoise loop."""
+        if self.captured:
+            return
+        self.captured = True
+        for i in range(max(1, self.tr.nsteps - 1)):
+            if not self.program(i).capture():
+                break
+
+
 class SliderTrainer:
     def __init__(self, engine: UNetEngine, store: LoraStore, H: int, W: int, batch_size: int = 1,
                  lr: float = 2e-4, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.01,
@@ -117,6 +164,8 @@ class SliderTrainer:
         # passes either way, including the bit-equality checks).  SLIDERS_OVERLAP_FROZEN=0 runs them back to back.
         self.overlap_frozen = os.environ.get("SLIDERS_OVERLAP_FROZEN", "1") == "1"
         self._side = torch.cuda.Stream(device=engine.device) if self.overlap_frozen else None
+        # one program (one hipGraph) per denoise step instead of fill + pass + combine launch; SLIDERS_STEP_GRAPHS=0: the latter
+        self.step_graphs = os.environ.get("SLIDERS_STEP_GRAPHS", "1") == "1"
         self._states = {}
         self._use(batch_size, H, W)
 
@@ -170,13 +219,27 @@ class SliderTrainer:
         sch.set_timesteps(1000, device=self.eng.device)
         return sch.timesteps[int(k * 1000 / self.nsteps)]
 
-    def _cfg(self, p, out, guidance, coeff=None, out2=None, x=None, eps_text=None):
+    def _cfg_desc(self, p, out, guidance, coeff=None, out2=None, x=None, eps_text=None):
         d = lib.CfgDdimDesc(eps=p.io["eps"].ptr, x=x or 0, out=out, out2=out2 or 0, eps_text=eps_text or 0,
                             nb=self.bs, chw=self.chw, guidance=guidance, do_step=0)
         if coeff is not None:
             for kf, vf in coeff.items():
                 setattr(d, kf, vf)
-        lib.call(lib.OP_CFG_DDIM, d, _stream())
+        return d
+
+    def _cfg(self, p, out, guidance, coeff=None, out2=None, x=None, eps_text=None):
+        lib.call(lib.OP_CFG_DDIM, self._cfg_desc(p, out, guidance, coeff, out2, x, eps_text), _stream())
+
+    def _step_programs(self, p_on) -> "_StepPrograms":
+        """Denoise step i as ONE replayable program: the pass reading its timestep from row i of a device table instead of
+        io["t"], followed by the guided combine + DDIM update with step i's coefficients (train_util.py:263-294 per
+        step: scale_model_input, predict_noise_xl, scheduler.step).  The loop then submits one graph per step - no fill
+        kernel and no separate launch between two passes (scripts/time_iter_k.py: 0.32 ms per step of the SDXL bench)."""
+        key = (id(self), self.bs, self.chw, self.nsteps, float(self.denoise_guidance))
+        sp = getattr(p_on, "_step_progs", None)
+        if sp is None or sp.key != key:
+            sp = p_on._step_progs = _StepPrograms(self, p_on, key)
+        return sp
 
     def _predict(self, p, lat, ctx, pooled, t, out):
         self._load_latents(p, self._model_input(lat, t))
@@ -242,14 +305,20 @@ class SliderTrainer:
             self._load_latents(p_on, noise.to(torch.bfloat16))
             smp = p_on.io["sample"]
             half = bs * self.chw * 2
+            sp = self._step_programs(p_on) if self.step_graphs else None
             for i in range(k):
+                self.unet_passes += 1
+                if sp is not None:
+                    sp.program(i).run(s)
+                    continue
                 t = self.t50[i]
                 p_on.io["t"].tensor.fill_(float(t))
                 # the prompt embeddings do not change inside the loop: after the first step the text K/V are already there
                 (p_on.prog if (i == 0 or p_on.prog_text_cached is None) else p_on.prog_text_cached).run(s)
-                self.unet_passes += 1
                 self._cfg(p_on, smp.ptr, self.denoise_guidance, self.sched.step_fields(t, self.nsteps),
                           out2=smp.ptr + half, x=smp.ptr)
+            if sp is not None:
+                sp.capture_all()
             self.denoised.copy_(smp.tensor[:bs])
             t_cur = self.t1000[int(k * 1000 / self.nsteps)]
         else:

@@ -164,6 +164,42 @@ def test_iterations_through_graphs_equal_plain_launches(dev, k, monkeypatch):
             assert torch.equal(x, y), f"iteration {it}: {name} differs between graph replay and plain launches"
 
 
+@pytest.mark.parametrize("name", ["tiny_sdxl", "tiny_sd1"])
+def test_step_programs_equal_fill_pass_combine_launches(dev, name):
+    """The denoise loop as one program per step (timestep from a device table row, guided combine + DDIM update as the
+    program's last op; every step's graph captured after the first loop) against the loop as it was: fill io['t'], replay
+    the pass, launch slh_cfg_ddim.  Five iterations with k walking over captured and not-yet-run step indices: denoised
+    latents, loss, gradients and parameters equal bit for bit."""
+    from sliders_amd import lib
+
+    def run(step_graphs):
+        cfg, store, emb, pool, noise = _setup(dev, name)
+        eng = UNetEngine(cfg, build_unet(name, seed=0).state_dict(), dev)
+        tr = SliderTrainer(eng, store, 16, 16, lr=2e-4)
+        tr.step_graphs = step_graphs
+        pair = _pair(emb, pool, dev)
+        out = []
+        for k in (2, 7, 1, 49, 4):
+            loss = tr.iteration(pair, k, noise.to(dev)).item()
+            out.append((loss, tr.denoised.clone(), store.grads.clone(), store.params.clone()))
+        p_on = eng.plan(2 * tr.bs, 16, 16, "on")
+        sp = getattr(p_on, "_step_progs", None)
+        assert (sp is not None) == step_graphs
+        if step_graphs:
+            assert sp.captured and all(pr is not None for pr in sp.progs[:49])
+            if p_on.prog.n_ops >= lib.Program.GRAPH_MIN_OPS and lib._GRAPHS_ON:
+                assert all(pr._graphs is not None for pr in sp.progs[:49])
+            assert sp.progs[3].op_names[-1] == "cfg_ddim_step" and sp.progs[3].n_ops == (p_on.prog_text_cached or p_on.prog).n_ops + 1
+            assert sp.progs[0].n_ops == p_on.prog.n_ops + 1
+        return out
+
+    old, new = run(False), run(True)
+    for it, (a, b) in enumerate(zip(old, new)):
+        assert a[0] == b[0], f"iteration {it}: loss {b[0]} with step programs, {a[0]} with separate launches"
+        for nm, x, y in zip(("denoised", "grads", "params"), a[1:], b[1:]):
+            assert torch.equal(x, y), f"iteration {it}: {nm} differs"
+
+
 def test_dedup_frozen_equals_three_cfg_pairs(dev):
     """Same engine, same denoised latents, same timestep: the one-pass [uncond, positive, neutral] evaluation
     against the reference's three CFG-pair passes.  Every reduction of the pass runs in a fixed order (round 3), rows of different
