@@ -10,7 +10,8 @@
 //
 // Scope: dense single-source products with packed weights, M % 64 == 0, N % 160 == 0, K % 64 == 0; epilogue = bias + residual, one
 // rounding, 16-byte write-through row stores through a per-wave LDS patch, and the producer side of a folded LayerNorm with
-// 80-COLUMN chunks (ln_out [N/80][M][2]: the consumer merges equal-sized chunks of any width); optionally ONE fused rank-4 adapter
+// 80-COLUMN chunks (ln_out [N/80][M][2]: the consumer merges equal-sized chunks of any width), or its consumer side (ln_in: the
+// chunk statistics of a row are merged by its four lanes behind the K loop, round 6); optionally ONE fused rank-4 adapter
 // (lora.py:108-112: the down matrix rides as 8 extra rows of the W tile - 4 of them zero -, T = x . A^T costs one MFMA per row block
 // and K tile in each wave, the up-projection one MFMA per accumulator block in the epilogue).  No split-K, no GEGLU, no row bias.
 // Replaces F.linear inside diffusers' Attention.to_out[0] / Transformer2DModel.proj_out / FeedForward.net[2] as called from
@@ -30,8 +31,11 @@ constexpr int G5_PATCH_LD = 176;                      // bytes per row of a wave
 struct G5Args {
     const __bf16* a; const __bf16* w; const __bf16* bias; const __bf16* residual; __bf16* c; float* ln_out;
     const __bf16* lora_down; const __bf16* lora_up; const float* lora_scale; float* lora_t_out;
+    const float* ln_in; const float* ln_s; const float* ln_b; float* ln_mr_out;
     int lda, ldc, ld_res, M, N, K, tiles_m, tiles_n, group_m, ld_t, skew;
+    int ln_in_chunks; float ln_eps;
 };
+constexpr int G5_LNC = 6;      // chunk pairs a lane requests per row: chunk 0 (the shift) + its quarter of up to 20 chunks
 
 typedef __attribute__((ext_vector_type(4))) float f32x4_t;
 
@@ -96,6 +100,21 @@ __global__ __launch_bounds__(256) void gemm5_kernel(const G5Args p) {
         lsrc = (const char*)(p.lora_down + (long)frow * p.K + ((fslot ^ ((frow >> 1) & 7)) << 3));
         ladv = 128;
     }
+    // folded LayerNorm, consumer side: the chunk statistics of this wave's rows are requested HERE, ahead of every LDS-DMA piece
+    // (loads retire in order: older ordinary loads never make a counted wait on the pieces too short), and merged behind the K loop
+    const int r16 = lane & 15, g4 = lane >> 4;
+    f32x2 lnp[2][G5_LNC];
+    if (p.ln_in) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const f32x2* src = (const f32x2*)p.ln_in + m0 + wm * 32 + i * 16 + r16;        // chunk-major [chunks][M]
+#pragma unroll
+            for (int c = 0; c < G5_LNC; ++c) {
+                const int ch = c == 0 ? 0 : g4 + 4 * (c - 1);
+                lnp[i][c] = src[(long)(ch < p.ln_in_chunks ? ch : 0) * p.M];
+            }
+        }
+    }
     const unsigned lds0 = lds_addr_of(smem);
     auto piece = [&](const int j, const int slot) {
         if (j < G5_XI) {
@@ -118,7 +137,6 @@ __global__ __launch_bounds__(256) void gemm5_kernel(const G5Args p) {
         for (int j = 0; j < 5; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
     // fragments: lane (g4 = lane / 16, r16 = lane % 16) holds row r16 of a 16-row block, k = 32 * ks + 8 * g4 .. + 7 (16 bytes)
-    const int r16 = lane & 15, g4 = lane >> 4;
     bf16x8 xf[2][2], wf[2][5], lf[2];
     f32x4_t accl[2];     // LORA: accl[i][e] = T[m = ..i*16 + r16][rank 4*g4 + e]; ranks 0-3 (the lanes with g4 == 0) are live
     accl[0] = f32x4_t{0.f, 0.f, 0.f, 0.f}; accl[1] = f32x4_t{0.f, 0.f, 0.f, 0.f};
@@ -231,6 +249,38 @@ __global__ __launch_bounds__(256) void gemm5_kernel(const G5Args p) {
 #pragma unroll
             for (int j = 0; j < 5; ++j) rq[i][j] = *(const bf16x4*)(p.residual + (long)(mrow + i * 16) * p.ld_res + ncol + j * 16);
     }
+    if (p.ln_in) {
+        // LN(x) . W^T = rstd (x . W'^T - mean s) + b'   (W' = W gamma, s = row sums of W', b' = bias + W beta).  Equal-sized chunks
+        // merged with the chunk means shifted by the first one (gemm_common.h: gemm_ln_finish): every lane its quarter of the chunks,
+        // the quarters added across the row's four lanes in a fixed order - the arithmetic of the 128-row tiles (gemm7.hip)
+        const float nc = (float)(p.K / p.ln_in_chunks), inv_chunks = 1.f / (float)p.ln_in_chunks;
+        float ln_mean[2], ln_rstd[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const float m0v = lnp[i][0][0];
+            float sm = 0.f, pq = 0.f, q = 0.f;
+#pragma unroll
+            for (int c = 1; c < G5_LNC; ++c) {
+                const int ch = g4 + 4 * (c - 1);
+                if (ch < p.ln_in_chunks) { const float dl = lnp[i][c][0] - m0v; sm += dl; pq += dl * dl; q += lnp[i][c][1]; }
+            }
+            sm += __shfl_xor(sm, 16, 64); pq += __shfl_xor(pq, 16, 64); q += __shfl_xor(q, 16, 64);
+            sm += __shfl_xor(sm, 32, 64); pq += __shfl_xor(pq, 32, 64); q += __shfl_xor(q, 32, 64);
+            const float dm = sm * inv_chunks;
+            ln_mean[i] = m0v + dm;
+            const float M2 = q + nc * fmaxf(pq - sm * dm, 0.f);
+            ln_rstd[i] = 1.0f / sqrtf(M2 / (float)p.K + p.ln_eps);
+            if (p.ln_mr_out && tile_n == 0 && wn == 0 && g4 == 0) *(f32x2*)(p.ln_mr_out + (long)(mrow + i * 16) * 2) = f32x2{ln_mean[i], ln_rstd[i]};
+        }
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+            const f32x4_t s4 = *(const f32x4_t*)(p.ln_s + ncol + j * 16), b4 = *(const f32x4_t*)(p.ln_b + ncol + j * 16);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[i][j][e] = ln_rstd[i] * (acc[i][j][e] - ln_mean[i] * s4[e]) + b4[e];
+        }
+    }
     if (LORA) {
         // up-projection: acc += B[n][0..3] . bf16(scale * T[m][0..3]) - one more MFMA per accumulator block, its 32-deep k axis carrying
         // the rank index (k = 8 * g4 + e <-> rank 4 * g4 + e: T sits in the accumulator layout of a B operand already); the reference's
@@ -319,7 +369,14 @@ extern "C" int slh_gemm5_ok(const slh_gemm_desc* d) {
     if (!d || !d->a0 || !d->w || !d->c) return 0;
     if (d->mode != 0 || d->a1 || d->ca1 || d->w_layout != 1) return 0;
     if (d->M <= 0 || d->M % 64 || d->N <= 0 || d->N % 160 || d->K < 64 || d->K % 64 || d->ca0 != d->K) return 0;
-    if (d->lora_t || d->rowbias || d->geglu || d->vt_out || d->ln_in || d->xa_k || d->geglu_pre || d->ln_mr_out) return 0;
+    if (d->lora_t || d->rowbias || d->geglu || d->vt_out || d->xa_k || d->geglu_pre) return 0;
+    if (d->ln_in) {          // consumer side of a folded LayerNorm (as the 128-row tiles: gemm7.hip), without an adapter
+        if (!d->ln_s || !d->ln_b || d->bias || d->lora_down || ((uintptr_t)d->ln_in & 7) || ((uintptr_t)d->ln_s & 15) || ((uintptr_t)d->ln_b & 15)) return 0;
+        if (d->ln_in_chunks < 1 || d->ln_in_chunks > 20 || !(d->K == 64 * d->ln_in_chunks || d->K == 80 * d->ln_in_chunks)) return 0;
+        if (d->ln_mr_out && ((uintptr_t)d->ln_mr_out & 7)) return 0;
+    } else if (d->ln_mr_out) {
+        return 0;
+    }
     if (d->lora_down) {      // one fused rank-4 adapter, forward form
         if (!d->lora_up || !d->lora_scale || d->lora_up_rmajor || d->lora_groups != 1 || d->lora_rank != 4 || d->ln_lora_s) return 0;
         if (((uintptr_t)d->lora_down & 15) || ((uintptr_t)d->lora_up & 7)) return 0;
@@ -337,13 +394,14 @@ extern "C" int slh_gemm5_ok(const slh_gemm_desc* d) {
 int slh_gemm5_launch(const slh_gemm_desc* d, slh_stream_t stream) {
     SLH_CHECK(slh_gemm5_ok(d),
               "slh_gemm: the 64 x 160 tile (0x5xxx) runs dense single-source products with packed weights, M %% 64 == 0, N %% 160 == 0, "
-              "bias / residual / ln_out / one fused rank-4 adapter only (M=%d N=%d K=%d)", d ? d->M : 0, d ? d->N : 0, d ? d->K : 0);
+              "bias / residual / ln_out / ln_in / one fused rank-4 adapter only (M=%d N=%d K=%d)", d ? d->M : 0, d ? d->N : 0, d ? d->K : 0);
     SLH_CHECK(((d->tile >> 16) & 15) <= 1, "slh_gemm: the 64 x 160 tile has no split-K");
     G5Args a;
     a.a = (const __bf16*)d->a0; a.w = (const __bf16*)d->w; a.bias = (const __bf16*)d->bias; a.residual = (const __bf16*)d->residual;
     a.c = (__bf16*)d->c; a.ln_out = d->ln_out;
     a.lora_down = (const __bf16*)d->lora_down; a.lora_up = (const __bf16*)d->lora_up; a.lora_scale = d->lora_scale;
     a.lora_t_out = d->lora_t_out; a.ld_t = d->ld_t;
+    a.ln_in = d->ln_in; a.ln_s = d->ln_s; a.ln_b = d->ln_b; a.ln_mr_out = d->ln_mr_out; a.ln_in_chunks = d->ln_in_chunks; a.ln_eps = d->ln_eps;
     a.lda = d->lda0; a.ldc = d->ldc; a.ld_res = d->ld_res; a.M = d->M; a.N = d->N; a.K = d->K;
     a.tiles_m = d->M / G5_BM; a.tiles_n = d->N / G5_BN;
     a.group_m = g5_group_m(a.tiles_m, a.tiles_n);

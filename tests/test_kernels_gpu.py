@@ -513,6 +513,25 @@ def test_gemm_tile_64x160_layernorm_producer(dev, C, offset):
         hd = h.double()
         assert float((mr[:, 0].double() - hd.mean(-1)).abs().max()) < 1e-5 * max(1.0, float(hd.mean(-1).abs().max()))
         assert float((mr[:, 1].double() * torch.sqrt(hd.var(-1, unbiased=False) + 1e-5) - 1).abs().max()) < 1e-4
+    # the tile's own consumer side (round 6: attn2.to_q with norm2 folded in), packed weights; also over 64-column chunks
+    wfp = pack_gemm_w(wf)
+    hc64 = h.float().view(M, C // 64, 64).double()
+    m64 = hc64.mean(-1)
+    chunks64 = torch.stack([m64, ((hc64 - m64[..., None]) ** 2).sum(-1)], -1).permute(1, 0, 2).contiguous().float()
+    outs = {}
+    for tile, ch, nch in ((lib.TILE_64x160, chunks, C // 80), (0x5525, chunks, C // 80), (lib.TILE_64x160, chunks64, C // 64)):
+        c = torch.full((M, N), float("nan"), device=dev, dtype=torch.bfloat16)
+        mr = torch.full((M, 2), float("nan"), device=dev)
+        d = lib.GemmDesc(a0=p(h), w=p(wfp), c=p(c), lda0=C, ca0=C, mode=0, stride=1, ldw=0, M=M, N=N, K=C, ldc=N, rows_per_sample=M, tile=tile,
+                         w_layout=1, ln_in=p(ch), ln_in_chunks=nch, ln_s=p(sv), ln_b=p(bp), ln_eps=1e-5, ln_mr_out=p(mr))
+        assert lib.gemm5_ok(d)
+        lib.call(lib.OP_GEMM, d, stream())
+        torch.cuda.synchronize()
+        report(f"ln consumer ON the 64x160 tile{tile:x} chunks{nch} C{C} off{offset}", c, ln.float() @ w.float().t(), TOL)
+        assert float((mr[:, 0].double() - hd.mean(-1)).abs().max()) < 1e-5 * max(1.0, float(hd.mean(-1).abs().max()))
+        assert float((mr[:, 1].double() * torch.sqrt(hd.var(-1, unbiased=False) + 1e-5) - 1).abs().max()) < 1e-4
+        outs[(tile, nch)] = c
+    assert torch.equal(outs[(lib.TILE_64x160, C // 80)], outs[(0x5525, C // 80)]), "the ring depth does not change the arithmetic"
 
 
 @pytest.mark.parametrize("M,N,K", [(64, 160, 64), (192, 320, 192), (2048, 1280, 1280), (128, 160, 2560)])
@@ -572,7 +591,8 @@ def test_gemm_tile_64x160_rejections(dev):
                 tile=lib.TILE_64x160, w_layout=1)
     assert lib.gemm5_ok(lib.GemmDesc(**base))
     for bad in (dict(N=256), dict(M=100), dict(w_layout=0, ldw=K), dict(geglu=1), dict(rowbias=p(c), ld_rowbias=N),
-                dict(ln_in=p(c), ln_in_chunks=2, ln_s=p(c), ln_b=p(c)), dict(tile=lib.TILE_64x160 | 0x20000)):
+                dict(ln_in=p(c), ln_in_chunks=3, ln_s=p(c), ln_b=p(c)), dict(ln_in=p(c), ln_in_chunks=2, ln_s=p(c), ln_b=p(c), bias=p(c)),
+                dict(ln_mr_out=p(c)), dict(tile=lib.TILE_64x160 | 0x20000)):
         d = lib.GemmDesc(**{**base, **bad})
         if "tile" not in bad:
             assert not lib.gemm5_ok(d)
