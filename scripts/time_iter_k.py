@@ -45,8 +45,58 @@ for step_graphs in (False, True, False, True):
         print(f"  k = {k:2d}: iteration {min(v):7.2f} ms")
     slope = (min(res[33]) - min(res[1])) / 32
     print(f"  per denoise step inside the iteration: {slope:.3f} ms; k-independent part: {min(res[1]) - slope:.2f} ms")
+# where the k-dependent time sits: phase stamps on the main stream (the frozen pass runs beside the training forward on a side stream)
+for k in (1, 33, 1, 33):
+    tr.phase_events = []
+    torch.cuda.synchronize()
+    tr.iteration(pair, k, noise)
+    torch.cuda.synchronize()
+    ev = tr.phase_events
+    tr.phase_events = None
+    print(f"k = {k:2d}: " + "  ".join(f"{b[0]} {a[1].elapsed_time(b[1]):7.2f} ms" for a, b in zip(ev, ev[1:])))
+tr.phase_events, tr.phase_steps = [], True
+torch.cuda.synchronize()
+tr.iteration(pair, 33, noise)
+torch.cuda.synchronize()
+ev = tr.phase_events
+tr.phase_events, tr.phase_steps = None, False
+print("k = 33, per step: " + " ".join(f"{a[1].elapsed_time(b[1]):.2f}" for a, b in zip(ev, ev[1:]) if b[0].startswith("step")))
 p = eng.plan(2, hw, hw, "on")
 s = torch.cuda.current_stream().cuda_stream
+# the denoise loop alone (per-step programs, latents evolving as in the iteration) - separates the loop's own cost per step from
+# whatever a longer loop does to the passes behind it
+eng.set_lora(True, 1.0)
+sp = tr._step_programs(p)
+sp.capture_all()
+for n in (33, 33):
+    tr._load_latents(p, noise.to(torch.bfloat16))
+    torch.cuda.synchronize()
+    t0 = time.time()
+    for i in range(n):
+        sp.program(i).run(s)
+    torch.cuda.synchronize()
+    print(f"denoise loop alone, {n} per-step programs: {(time.time() - t0) / n * 1e3:.3f} ms per step")
+# the same loop right behind a training iteration, no synchronisation in between (what the next iteration's loop sees)
+for rep in range(2):
+    tr.iteration(pair, 1, noise)
+    eng.set_lora(True, 1.0)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(torch.cuda.current_stream())
+    for i in range(33):
+        sp.program(i).run(s)
+    e1.record(torch.cuda.current_stream())
+    torch.cuda.synchronize()
+    print(f"the same loop right behind an iteration: {e0.elapsed_time(e1) / 33:.3f} ms per step")
+# ... and with the iteration's own host work in front of every step (none is expected to matter: the host runs ahead)
+for rep in range(2):
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(torch.cuda.current_stream())
+    for i in range(33):
+        sp.program(i).run(s)
+    e1.record(torch.cuda.current_stream())
+    torch.cuda.synchronize()
+    print(f"loop alone, event-timed: {e0.elapsed_time(e1) / 33:.3f} ms per step")
 for prog, nm in ((p.prog, "full program"), (p.prog_text_cached, "text K/V cached")):
     if prog is None:
         continue
@@ -58,3 +108,8 @@ for prog, nm in ((p.prog, "full program"), (p.prog_text_cached, "text K/V cached
         prog.run(s)
     torch.cuda.synchronize()
     print(f"replayed pass alone ({nm}): {(time.time() - t0) / 10 * 1e3:.3f} ms")
+    t0 = time.time()
+    for _ in range(100):       # as long as a k = 100 denoise loop: the clocks settle where a training iteration runs
+        prog.run(s)
+    torch.cuda.synchronize()
+    print(f"replayed pass alone ({nm}), 100 replays back to back: {(time.time() - t0) / 100 * 1e3:.3f} ms")

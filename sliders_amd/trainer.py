@@ -166,6 +166,10 @@ class SliderTrainer:
         self._side = torch.cuda.Stream(device=engine.device) if self.overlap_frozen else None
         # one program (one hipGraph) per denoise step instead of fill + pass + combine launch; SLIDERS_STEP_GRAPHS=0: the latter
         self.step_graphs = os.environ.get("SLIDERS_STEP_GRAPHS", "1") == "1"
+        # steps of the denoise loop left when the side stream's work is queued (0 = as soon as the host gets there)
+        self.frozen_gate = int(os.environ.get("SLIDERS_FROZEN_GATE", "2"))
+        self.phase_events = None
+        self.phase_steps = False
         self._states = {}
         self._use(batch_size, H, W)
 
@@ -290,6 +294,7 @@ class SliderTrainer:
         this is also how tests run N data-parallel ranks in one process).
         Returns the device loss scalar."""
         self._use(noise.shape[0], noise.shape[2], noise.shape[3])
+        self._mark("start")
         if time_ids is not None:
             self.time_ids = time_ids.to(device=self.eng.device, dtype=torch.float32).reshape(2 * self.bs, 6)
         if lr is not None:
@@ -297,6 +302,7 @@ class SliderTrainer:
         eng, st, bs = self.eng, self.store, self.bs
         B = 2 * bs
         s = _stream()
+        gate = None
         # 1. partial denoise with the adapters on (train_lora_xl.py:205-227)
         eng.set_lora(True, 1.0)
         p_on = eng.plan(B, self.H, self.W, "on")
@@ -306,10 +312,16 @@ class SliderTrainer:
             smp = p_on.io["sample"]
             half = bs * self.chw * 2
             sp = self._step_programs(p_on) if self.step_graphs else None
+            gate_at = k - 1 - self.frozen_gate if (self.overlap_frozen and self.frozen_gate > 0) else -1
             for i in range(k):
                 self.unet_passes += 1
+                if i == gate_at:
+                    gate = torch.cuda.Event()
+                    gate.record(torch.cuda.current_stream())
                 if sp is not None:
                     sp.program(i).run(s)
+                    if self.phase_events is not None and self.phase_steps:
+                        self._mark(f"step{i}")
                     continue
                 t = self.t50[i]
                 p_on.io["t"].tensor.fill_(float(t))
@@ -319,6 +331,7 @@ class SliderTrainer:
                           out2=smp.ptr + half, x=smp.ptr)
             if sp is not None:
                 sp.capture_all()
+            self._mark("denoise")
             self.denoised.copy_(smp.tensor[:bs])
             t_cur = self.t1000[int(k * 1000 / self.nsteps)]
         else:
@@ -341,6 +354,13 @@ class SliderTrainer:
             eng.plan(3 * bs if self.dedup_frozen else B, self.H, self.W, "off")      # built (and arenas sized) on the main stream
             eng.plan(B, self.H, self.W, "train")
             main = torch.cuda.current_stream()
+            if gate is not None:
+                # The host runs ~25 steps ahead of the device; work queued on the side stream THEN sits in a second hardware queue behind
+                # its cross-queue wait for the rest of the loop, and every step of the loop runs 2 % slower while it does (SDXL 1024^2:
+                # 22.36 -> 22.88 ms from the step at which the host got there; profiles/r06_iteration_k_sweep.txt) - about what the
+                # overlap gains.  So the host holds the submission back until the loop has `frozen_gate` steps left (a wait on an event,
+                # no data comes back); those steps are more than the time it takes to queue the two passes.
+                gate.synchronize()
             self._side.wait_stream(main)
             with torch.cuda.stream(self._side):
                 frozen()
@@ -354,6 +374,7 @@ class SliderTrainer:
         self._predict(p_tr, self.denoised, pair.ctx_target, pair.pooled_target, t_cur, self.e_tgt)
         if frozen_done is not None:
             torch.cuda.current_stream().wait_event(frozen_done)
+        self._mark("predictions")
         # 4. loss + its gradient, written straight into the backward plan's input (prompt_util.py:108-148)
         self.loss.zero_()
         bw = p_tr.backward
@@ -367,9 +388,18 @@ class SliderTrainer:
         if zero_grads:
             st.grads.zero_()
         bw.prog.run(s)
+        self._mark("backward")
         if step:
             self.reduce_and_step()
+            self._mark("optimizer")
         return self.loss
+
+    def _mark(self, name: str):
+        """Phase stamps for scripts/time_iter_k.py: with `phase_events` set to a list, an event per phase boundary on the main stream."""
+        if self.phase_events is not None:
+            e = torch.cuda.Event(enable_timing=True)
+            e.record(torch.cuda.current_stream())
+            self.phase_events.append((name, e))
 
     def reduce_and_step(self, n_accumulated: int = 1):
         """The exchange step of data parallelism and the optimizer: ONE sum all-reduce of the flat fp32 gradient buffer per
