@@ -168,6 +168,7 @@ class SliderTrainer:
         self.step_graphs = os.environ.get("SLIDERS_STEP_GRAPHS", "1") == "1"
         # steps of the denoise loop left when the side stream's work is queued (0 = as soon as the host gets there)
         self.frozen_gate = int(os.environ.get("SLIDERS_FROZEN_GATE", "2"))
+        self._captured = set()
         self.phase_events = None
         self.phase_steps = False
         self._states = {}
@@ -392,6 +393,17 @@ class SliderTrainer:
         if step:
             self.reduce_and_step()
             self._mark("optimizer")
+        if self.step_graphs:
+            # the once-per-iteration programs of this shape (frozen pass, training forward, backward): recorded as graphs behind their
+            # FIRST run - every kernel of theirs has been launched by then - instead of inside the third iteration (lib.Program.run's
+            # own rule), so that a run with one warm-up iteration has every capture behind it when its timing starts
+            key = (B, self.H, self.W, self.dedup_frozen)
+            if key not in self._captured:
+                self._captured.add(key)
+                off = eng.plan(3 * bs if self.dedup_frozen else B, self.H, self.W, "off")
+                for prog in (off.prog, p_tr.prog, bw.prog):
+                    if prog._runs >= 1:
+                        prog.capture()
         return self.loss
 
     def _mark(self, name: str):
