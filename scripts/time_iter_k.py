@@ -13,17 +13,22 @@ from sliders_amd.random_init import random_state_dict
 from sliders_amd.trainer import PairEmbeds, SliderTrainer
 from sliders_amd.unet import UNetEngine
 
+import argparse
+ap = argparse.ArgumentParser()
+ap.add_argument("--model", default="sdxl")
+ap.add_argument("--hw", type=int, default=128)
+args = ap.parse_args()
 dev = torch.device("cuda:0")
-cfg = CONFIGS["sdxl"]()
-hw = 128
+cfg = CONFIGS[args.model]()
+hw = args.hw
 eng = UNetEngine(cfg, random_state_dict(cfg, dev, 0), dev)
 store = LoraStore(cfg, rank=4, alpha=1.0, train_method="noxattn", device=dev)
 tr = SliderTrainer(eng, store, hw, hw, batch_size=1, lr=2e-4)
 g = torch.Generator(device="cpu").manual_seed(1234)
 e = [torch.randn(1, 77, cfg.cross_attention_dim, generator=g).to(dev, torch.bfloat16) for _ in range(4)]
-pl = [torch.randn(1, cfg.pooled_dim, generator=g).to(dev, torch.bfloat16) for _ in range(4)]
+pl = [torch.randn(1, cfg.pooled_dim, generator=g).to(dev, torch.bfloat16) if cfg.is_xl else None for _ in range(4)]
 cat = lambda x: torch.cat([e[3], x]).contiguous()
-pcat = lambda x: torch.cat([pl[3], x]).contiguous()
+pcat = lambda x: torch.cat([pl[3], x]).contiguous() if cfg.is_xl else None
 pair = PairEmbeds(cat(e[0]), cat(e[1]), cat(e[2]), cat(e[3]), pcat(pl[0]), pcat(pl[1]), pcat(pl[2]), pcat(pl[3]), guidance_scale=4.0, action="enhance")
 noise = torch.randn(1, 4, hw, hw, device=dev)
 for k in (3, 3):
