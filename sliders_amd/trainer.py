@@ -167,7 +167,7 @@ class SliderTrainer:
         # one program (one hipGraph) per denoise step instead of fill + pass + combine launch; SLIDERS_STEP_GRAPHS=0: the latter
         self.step_graphs = os.environ.get("SLIDERS_STEP_GRAPHS", "1") == "1"
         # steps of the denoise loop left when the side stream's work is queued (0 = as soon as the host gets there)
-        self.frozen_gate = int(os.environ.get("SLIDERS_FROZEN_GATE", "2"))
+        self.frozen_gate = int(os.environ.get("SLIDERS_FROZEN_GATE", "1"))
         self._captured = set()
         self.phase_events = None
         self.phase_steps = False
@@ -313,7 +313,8 @@ class SliderTrainer:
             smp = p_on.io["sample"]
             half = bs * self.chw * 2
             sp = self._step_programs(p_on) if self.step_graphs else None
-            gate_at = k - 1 - self.frozen_gate if (self.overlap_frozen and self.frozen_gate > 0) else -1
+            # (the event sits in front of step k - frozen_gate: it fires when exactly `frozen_gate` steps are left)
+            gate_at = k - self.frozen_gate if (self.overlap_frozen and self.frozen_gate > 0) else -1
             for i in range(k):
                 self.unet_passes += 1
                 if i == gate_at:
