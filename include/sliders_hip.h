@@ -168,9 +168,7 @@ int slh_gemm_kernel_name(const slh_gemm_desc* d, char* buf, int cap);
 /* The 64 x 160 tile (tile code bits 12-15 = 5, e.g. 0x5425; csrc/gemm5.hip): 4 waves of 32 x 80 on the 16 x 16 x 32 MFMA, 4-slot LDS
  * ring - the M = 2048, N = 1280 products as 256 workgroups = one full round of the chip.  Dense single-source products with packed
  * weights (w_layout = 1), M % 64 == 0, N % 160 == 0; epilogue: bias, residual, ln_out - whose chunks are then 80 COLUMNS wide:
- * ln_out [N/80][M][2], and the consumer's ln_in_chunks = K / 80 -, one fused rank-4 adapter, or (round 6) the consumer side of the fold:
- * ln_in / ln_s / ln_b (64- or 80-column chunks, no bias, no adapter; ln_mr_out optional).  slh_gemm5_ok(d) = 1 where it can run the
- * descriptor. */
+ * ln_out [N/80][M][2], and the consumer's ln_in_chunks = K / 80.  slh_gemm5_ok(d) = 1 where it can run the descriptor. */
 int slh_gemm5_ok(const slh_gemm_desc* d);
 /* The tiles of csrc/gemm7.hip (tile code bits 12-15 = 7: 0x7<S><XB><WB>): 128 x 256 (0x7648) and 128 x 160 (0x7645) - four loader waves
  * that issue the ring's LDS-DMA + four compute waves, one per SIMD, each a 64 x (16 WB) register tile of 16 x 16 x 32 MFMAs - and 256 x 320
